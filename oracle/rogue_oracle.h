@@ -1,0 +1,114 @@
+/*
+ * rogue_oracle.h -- CPU restatement of the kngwyu/rogue-gym hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is the parity ORACLE: a plain-C, single-env-at-a-time restatement of the reference
+ * Rust engine (dungeon generation + turn step + screen draw + observation encode). It exists
+ * only so tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg can check / time
+ * the HIP product path against it.  The product (rogue-gym_amd/) never links or imports it.
+ *
+ * Pinning: the reference cannot be compiled or imported here (no Rust toolchain, no vendored
+ * crates), so the oracle is pinned by the reference's own golden vectors
+ * (python/tests/data.py, test_ff_env.py, test_st_env.py, test_parallel.py,
+ * core/src/dungeon/rogue/mod.rs:566-578) -- see tests/test_oracle_golden.py.
+ * Behaviour not covered by those goldens (levels >= 4, death, level-up, bats, search, ...)
+ * follows the reference source text only: "parity unpinned" for those paths.
+ *
+ * All file:line citations are relative to /root/reference.
+ */
+#ifndef ROGUE_ORACLE_H
+#define ROGUE_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Flat config (the test harness parses the JSON; the oracle stays JSON-free).
+ * Field defaults: core/src/lib.rs:134-140, dungeon/rogue/mod.rs:23-134,
+ * character/enemies.rs:56-85, character/player.rs:37-66, item/gold.rs:27-52. */
+typedef struct orc_config {
+    int32_t width, height;
+    uint64_t seed_lo, seed_hi; /* u128 seed */
+    int32_t hide_dungeon;
+    int32_t room_num_x, room_num_y, min_room_x, min_room_y;
+    uint32_t max_empty_rooms, amulet_level, maze_rate_inv, dark_level;
+    uint32_t hidden_passage_rate_inv, locked_door_rate_inv, max_extra_edges;
+    uint32_t door_unlock_rate_inv, passage_unlock_rate_inv;
+    uint32_t gold_rate_inv, gold_base, gold_per_level, gold_minimum;
+    uint32_t hunger_time;
+    int64_t init_hp;
+    uint32_t appear_rate_gold, appear_rate_nogold;
+    int32_t n_enemies;          /* number of entries of enemy_builtin in use (0 = no enemies) */
+    int32_t enemy_builtin[32];  /* indices into BUILTIN_ENEMIES (enemies.rs:474-761) */
+    int32_t choose_width;       /* 64 (what reproduces the goldens) or 32; SliceRandom::choose */
+} orc_config;
+
+void orc_config_default(orc_config *c);
+
+typedef struct orc_env orc_env;
+
+/* GameStateImpl::new (python/src/state_impls.rs:20-38). Returns NULL on invalid size. */
+orc_env *orc_new(const orc_config *cfg, uint64_t max_steps);
+void orc_free(orc_env *e);
+/* GameState.set_seed / Instruction::Seed: takes effect at the next reset. */
+void orc_set_seed(orc_env *e, uint64_t lo, uint64_t hi);
+/* GameStateImpl::reset (state_impls.rs:38-44) */
+int orc_reset(orc_env *e);
+/* GameStateImpl::react (state_impls.rs:51-79).  0 = ok, 1 = invalid key, 2 = ignored input
+ * (action key while in the Grave modal, core/src/lib.rs:301-315). */
+int orc_react(orc_env *e, uint8_t key);
+/* one env of ThreadConductor::step (thread_impls.rs:61-81): react, then auto-reset on
+ * terminal with is_terminal forced true.  Returns the error code of react. */
+int orc_step_autoreset(orc_env *e, uint8_t key);
+
+/* ---- mirrors (PlayerState, python/src/lib.rs:29-38) ---- */
+void orc_screen(const orc_env *e, uint8_t *out /* H*W */);
+void orc_hist(const orc_env *e, uint8_t *out /* H*W, 0/1 */);
+void orc_status(const orc_env *e, uint32_t out[10]); /* Status::to_vec order, player.rs:418-430 */
+/* out[0]=is_terminal out[1]=message flags out[2]=steps out[3]=dead(grave) out[4]=symbols */
+void orc_flags(const orc_env *e, uint32_t out[5]);
+
+/* ---- internal state, for deep GPU==oracle comparison ---- */
+typedef struct orc_monster {
+    int32_t x, y, type /* builtin index */, active, running;
+    int64_t hp, max_hp, level;
+    int32_t defense;
+    uint32_t exp;
+} orc_monster;
+/* surface: 0 Passage 1 Floor 2 WallX 3 WallY 4 Stair 5 Door 6 Trap 7 None (rogue/mod.rs:137-147)
+ * attr: CellAttr bits (dungeon/field.rs:107-124) */
+void orc_grid(const orc_env *e, uint8_t *surface, uint8_t *attr, uint8_t *doors, int32_t *gold);
+/* out: px,py,level,hp,hp_max,exp,plevel,food_left,quiet,gold,n_monsters */
+void orc_scalars(const orc_env *e, int64_t out[16]);
+int orc_monsters(const orc_env *e, orc_monster *out, int cap); /* sorted by (x,y) */
+/* rng state: 3 streams (dungeon,item,enemy) x {x,y,z,w}; counts = u32 outputs consumed */
+void orc_rng(const orc_env *e, uint32_t state[12], uint64_t counts[3]);
+/* Dungeon::move_enemy with skip = |_| false (rogue/mod.rs:339-375), for the reference KAT
+ * rogue/mod.rs:566-578.  Returns 0 CantMove, 1 CanMove (nx,ny set), 2 Reach. */
+int orc_move_enemy_kat(orc_env *e, int fx, int fy, int tx, int ty, int *nx, int *ny);
+
+/* ---- observation encoders (python/src/lib.rs:72-205, flags.rs:67-115, symbol.rs:17-71) ---- */
+int orc_status_vec(const uint32_t status[10], uint32_t flag, int32_t *out); /* returns len */
+/* out is [C,H,W] f32 with C = 1 + popcount(flag) (+1 with hist). returns 0, or 1 on bad tile */
+int orc_gray_image(const uint8_t *screen, int h, int w, int symbols, const uint32_t status[10],
+                   uint32_t flag, const uint8_t *hist /* NULL = no hist plane */, float *out);
+/* C = symbols + popcount(flag) (+1).  returns 1 if a tile's symbol >= symbols-1 (e.g. 'Z') */
+int orc_symbol_image(const uint8_t *screen, int h, int w, int symbols, const uint32_t status[10],
+                     uint32_t flag, const uint8_t *hist, float *out);
+
+/* ---- xorshift / rand-0.7 primitives exposed for known-answer tests ---- */
+void orc_kat_u32(uint64_t seed_lo, uint64_t seed_hi, int n, uint32_t *out);
+uint64_t orc_kat_range64(uint64_t seed_lo, uint64_t seed_hi, uint64_t lo, uint64_t hi, int n_skip);
+
+/* ---- batch driver (CPU baseline timing; one env per task over a pthread pool) ---- */
+typedef struct orc_batch orc_batch;
+orc_batch *orc_batch_new(const orc_config *cfgs, int n, uint64_t max_steps, int n_threads);
+void orc_batch_free(orc_batch *b);
+orc_env *orc_batch_env(orc_batch *b, int i);
+/* lock-step ThreadConductor::step over all envs + gray obs encode into obs [n,1,H,W] (may be NULL) */
+int orc_batch_step(orc_batch *b, const uint8_t *keys, float *obs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
