@@ -1,0 +1,123 @@
+/*
+ * rogue_gym_hip.h -- C ABI of the MI355X-native batched Rogue-Gym stepper (librogue_gym_hip.so).
+ *
+ * This is the drop-in boundary: the entry points are what the reference's FFI crate
+ * (`rogue_gym_python._rogue_gym`, /root/reference/python/src/lib.rs) would bind in place of
+ * its per-env `GameStateImpl` + one-OS-thread-per-env `ThreadConductor`.  Plain pointers and
+ * sizes only -- no torch / PyO3 types.  All buffers named "dev" live in HBM on the handle's
+ * device; observations are written into caller-owned device buffers (e.g. torch tensors) and
+ * never leave HBM.
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure; the message is
+ * available from rg_last_error() (the Python shim raises
+ * RuntimeError("Error in rogue-gym: " + msg), mirroring python/src/lib.rs:20-26).
+ * A handle is not thread-safe; distinct handles are independent.  Calls are asynchronous on the
+ * handle's HIP stream unless stated otherwise.
+ *
+ * file:line citations are relative to /root/reference.
+ */
+#ifndef ROGUE_GYM_HIP_H
+#define ROGUE_GYM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rg_handle rg_t;
+
+/* bits of the per-env flag word returned by rg_flags()/rg_fetch_states() */
+#define RG_FLAG_TERMINAL   0x00000001u  /* PlayerState.is_terminal (state_impls.rs:77) */
+#define RG_FLAG_DEAD       0x00000002u  /* engine is in the Grave modal (core/src/lib.rs:301-315) */
+#define RG_FLAG_REDRAW     0x00000004u  /* internal: screen mirror refresh pending */
+#define RG_FLAG_HIST_STALE 0x00000008u  /* internal: this Redraw keeps the old level's history */
+#define RG_FLAG_MSG_SHIFT  8            /* bits 8..14: MessageFlagInner (python/src/flags.rs:6-39) */
+#define RG_FLAG_MSG_MASK   0x00007f00u
+#define RG_FLAG_ERR_KEY    0x00010000u  /* ErrorKind::InvalidInput: key not in KeyMap::ai (input.rs:73-100) */
+#define RG_FLAG_ERR_DEAD   0x00020000u  /* ErrorKind::IgnoredInput: action key while dead */
+#define RG_FLAG_ERR_TILE   0x00040000u  /* symbol image: glyph with symbol >= symbols-1 (python/src/lib.rs:96-102) */
+#define RG_FLAG_ERR_MASK   0x00ff0000u
+
+/* Replaces GameState::__new__ / ParallelGameState::new (python/src/lib.rs:217-225,270-294) and
+ * ThreadConductor::new (thread_impls.rs:14-34): parses one GameConfig JSON per env
+ * (core/src/lib.rs:42-86; all envs must agree on everything except `seed`), allocates the SoA
+ * state for n_env environments on HIP device `device`, generates every level-1 dungeon and
+ * draws the first screens.  auto_reset != 0 selects ThreadConductor::step semantics (terminal
+ * envs are rebuilt inside rg_step and report the post-reset state with is_terminal forced
+ * true, thread_impls.rs:69-79); 0 selects single GameState semantics.
+ * cfg_json[i] may be NULL (= GameConfig::default()). */
+int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int device, int auto_reset, rg_t **out);
+void rg_destroy(rg_t *h);
+/* error text of the last failed call on `h` (h == NULL: last failed rg_create on this thread) */
+const char *rg_last_error(const rg_t *h);
+
+/* GameState::screen_size / symbols (python/src/lib.rs:226-228,255-257,295-300) */
+int rg_dims(const rg_t *h, int *height, int *width, int *symbols, int *n_env);
+/* Run all later work of this handle on `hip_stream` (a hipStream_t; NULL = default stream). */
+int rg_set_stream(rg_t *h, void *hip_stream);
+
+/* GameState::set_seed / ParallelGameState::seed (python/src/lib.rs:229-232,301-307;
+ * thread_impls.rs:45-50,125-128): u128 seeds as (lo, hi) words, used at the next reset. n may be
+ * smaller than n_env (zip semantics). Host pointers. */
+int rg_seed(rg_t *h, const uint64_t *seed_lo, const uint64_t *seed_hi, int n);
+/* GameState::reset / ParallelGameState::reset: rebuild every env from its config (+ seed). */
+int rg_reset(rg_t *h);
+/* GameState::react / ParallelGameState::step (python/src/lib.rs:241-243,315-321 ->
+ * state_impls.rs:51-79, thread_impls.rs:61-81): one key byte per env.  `keys` is a device pointer
+ * when keys_on_device != 0, else a host pointer (copied H2D on the stream). */
+int rg_step(rg_t *h, const uint8_t *keys, int keys_on_device);
+/* Wait for the stream; returns non-zero (and sets the error text) if any env raised an error flag
+ * since the last call (invalid key / action while dead), like the PyRuntimeError of lib.rs:20-26. */
+int rg_sync(rg_t *h);
+
+/* Device-resident mirrors (PlayerState, python/src/lib.rs:29-38), valid until rg_destroy:
+ *   screen  u8  [n_env][H][W]   glyph bytes, refreshed only on Reaction::Redraw
+ *   hist    u8  [n_env][H][W]   0/1 visited-history plane (copy_hist, lib.rs:105-111)
+ *   status  i32 [n_env][10]     Status::to_vec order (player.rs:418-430), refreshed on StatusUpdated
+ *   flags   u32 [n_env]         RG_FLAG_* bits
+ *   reward  f32 [n_env]         max(0, gold_after - gold_before) of the last rg_step (parallel.py:60-63)
+ * Reading them (rg_screen/rg_hist/rg_obs_*) flushes the pending screen render first. */
+int rg_screen(rg_t *h, uint8_t **dev);
+int rg_hist(rg_t *h, uint8_t **dev);
+int rg_status(rg_t *h, int32_t **dev);
+int rg_flags(rg_t *h, uint32_t **dev);
+int rg_reward(rg_t *h, float **dev);
+
+/* PlayerState::gray_image[_with_hist] / symbol_image[_with_hist] for the whole batch
+ * (python/src/lib.rs:72-111,162-205; flags.rs:88-115; symbol.rs:17-71), written straight into
+ * out_dev = f32 [n_env][C][H][W] with C = 1 (gray) or `symbols` (one-hot) + popcount(status_flag)
+ * (+1 with hist).  Bit layout of status_flag: StatusFlagInner (flags.rs:45-55). */
+int rg_obs_gray(rg_t *h, uint32_t status_flag, int with_hist, float *out_dev);
+int rg_obs_symbol(rg_t *h, uint32_t status_flag, int with_hist, float *out_dev);
+int rg_obs_channels(const rg_t *h, int symbol, uint32_t status_flag, int with_hist);
+
+/* Host copies for the value-object API (ParallelGameState::states/step return Vec<PlayerState>):
+ * synchronous D2H of the mirrors; any pointer may be NULL. */
+int rg_fetch_states(rg_t *h, uint8_t *screen, uint8_t *hist, int32_t *status, uint32_t *flags);
+
+/* Stateless encode of ONE host-side PlayerState snapshot on the GPU (PlayerState.gray_image &c.
+ * called on a cloned value object): uploads, runs the same encode kernel, downloads.
+ * kind 0 = gray, 1 = symbol.  Returns non-zero on the symbol-image tile error. */
+int rg_encode_host(int device, const uint8_t *screen, const uint8_t *hist, const int32_t *status, int height, int width,
+                   int symbols, uint32_t status_flag, int with_hist, int kind, float *out_host);
+
+/* GameState::dump_config (python/src/lib.rs:252-254): canonical JSON of env i's effective config. */
+int rg_dump_config(const rg_t *h, int env, char *buf, size_t cap);
+
+/* Parity/debug: synchronous copy of env i's internal state to the host. */
+typedef struct rg_debug_state {
+    int32_t px, py, dungeon_level, hp, hp_max, player_level, n_monsters, n_gold;
+    uint32_t exp, food_left, quiet, pack_gold, steps;
+    uint32_t rng[12];        /* dungeon, item, enemy streams x {x,y,z,w} */
+    int32_t mon_x[32], mon_y[32], mon_type[32], mon_active[32], mon_hp[32];
+    uint32_t mon_exp[32];
+    int32_t gold_x[32], gold_y[32], gold_amount[32];
+} rg_debug_state;
+/* cells: u16 [H][W] = surface (bits 0-2, rogue/mod.rs:137-147) | door<<3 | CellAttr<<4 (field.rs:107-124) */
+int rg_debug_fetch(rg_t *h, int env, rg_debug_state *out, uint16_t *cells);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -160,6 +160,15 @@ typedef struct {
 
 typedef struct { uint32_t *map; int kx, ky; } dcache_t;
 
+/* Reaction list (core/src/lib.rs:378-403) and message flags (python/src/flags.rs:6-39) */
+enum { RE_REDRAW = 1, RE_STATUS = 2, RE_GRAVE = 4, RE_NOTIFY = 8 };
+enum { MSG_HIT_FROM = 1, MSG_HIT_TO = 2, MSG_MISS_TO = 4, MSG_MISS_FROM = 8, MSG_KILLED = 16, MSG_SECRET_DOOR = 32, MSG_NO_DOWNSTAIR = 64 };
+typedef struct { int kind; uint32_t msg; } reaction_t;
+typedef struct { reaction_t v[4096]; int n; } rlist_t;
+static void rpush(rlist_t *l, int kind, uint32_t msg) { if (l->n < 4096) l->v[l->n++] = (reaction_t){kind, msg}; }
+
+
+
 struct orc_env {
     orc_config cfg;
     uint64_t max_steps;
@@ -185,6 +194,7 @@ struct orc_env {
     uint32_t status[10];
     uint32_t message;
     int is_terminal;
+    rlist_t scratch_a, scratch_b; /* reaction lists of the current react (no per-step malloc) */
 };
 
 static inline int IDX(const orc_env *e, int x, int y) { return y * e->W + x; }
@@ -826,12 +836,6 @@ static uint32_t attack_rate(int64_t level, int armor, int64_t revision) { /* fig
 #define WEAPON_HIT 1     /* mace +1,+1 2d4 (weapon.rs:179-188,200-203) */
 #define WEAPON_DAM 1
 
-enum { RE_REDRAW = 1, RE_STATUS = 2, RE_GRAVE = 4, RE_NOTIFY = 8 };
-enum { MSG_HIT_FROM = 1, MSG_HIT_TO = 2, MSG_MISS_TO = 4, MSG_MISS_FROM = 8, MSG_KILLED = 16, MSG_SECRET_DOOR = 32, MSG_NO_DOWNSTAIR = 64 };
-typedef struct { int kind; uint32_t msg; } reaction_t;
-typedef struct { reaction_t v[4096]; int n; } rlist_t;
-static void rpush(rlist_t *l, int kind, uint32_t msg) { if (l->n < 4096) l->v[l->n++] = (reaction_t){kind, msg}; }
-
 /* Player::heal (player.rs:221-240) */
 static int player_heal(orc_env *e) {
     e->quiet += 1;
@@ -1008,13 +1012,12 @@ static int process_action(orc_env *e, int act, int dir, rlist_t *out) {
         break;
     case ACT_MOVE_UNTIL:
         for (;;) {
-            rlist_t *res = malloc(sizeof(rlist_t)); res->n = 0;
+            rlist_t *res = &e->scratch_b; res->n = 0;
             int done = move_player(e, dir, res);
             int id = IDX(e, e->px, e->py);
             uint8_t tile = (e->fl.attr[id] & A_VISIBLE) ? SURFACE_GLYPH[e->fl.surface[id]] : ' '; /* Cell::tile (field.rs:91-98) */
-            if (done || (tile != '.' && tile != '#')) { for (int i = 0; i < res->n; i++) rpush(out, res->v[i].kind, res->v[i].msg); free(res); break; }
+            if (done || (tile != '.' && tile != '#')) { for (int i = 0; i < res->n; i++) rpush(out, res->v[i].kind, res->v[i].msg); break; }
             else if (out->n == 0) { for (int i = 0; i < res->n; i++) rpush(out, res->v[i].kind, res->v[i].msg); }
-            free(res);
             ui = after_turn(e, out);
         }
         break;
@@ -1140,7 +1143,7 @@ int orc_react(orc_env *e, uint8_t key) {
     int dir = 0, act = key_to_action(key, &dir);
     if (act < 0) return 1;
     if (e->dead) return 2; /* UiState::Mordal + InputCode::Act => IgnoredInput */
-    rlist_t *res = malloc(sizeof(rlist_t)); res->n = 0;
+    rlist_t *res = &e->scratch_a; res->n = 0;
     if (process_action(e, act, dir, res)) e->dead = 1;
     e->message = 0;
     int dead = 0;
@@ -1152,7 +1155,6 @@ int orc_react(orc_env *e, uint8_t key) {
         case RE_NOTIFY: e->message |= res->v[i].msg; break;
         }
     }
-    free(res);
     e->steps += 1;
     e->is_terminal = dead || e->steps >= e->max_steps;
     return 0;

@@ -1,0 +1,1343 @@
+// rg_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the batched Rogue-Gym stepper.
+//
+//   k_build   : GameConfig::build (core/src/lib.rs:193-228) for every env            1 env / lane
+//   k_step    : GameStateImpl::react + ThreadConductor auto-reset                    1 env / lane,
+//               (python/src/state_impls.rs:51-79, thread_impls.rs:61-81)             wave-cooperative BFS
+//   k_render  : RunTime::draw_screen -> PlayerState.map / history mirrors            1 block / env group
+//   k_gray / k_symbol : PlayerState::{gray,symbol}_image[_with_hist] for the batch   16-byte stores
+//
+// No dense contraction anywhere => no MFMA; everything is integer/byte work bounded by HBM traffic
+// (render/encode) or by dependent-load latency and divergence (step/generate).
+// file:line citations are relative to /root/reference.
+#include <hip/hip_runtime.h>
+
+#include "../../include/rogue_gym_hip.h"
+#include "rg_state.h"
+
+#define WAVE 64
+#define DIST_INF 0xFFFFu
+
+// ---------------------------------------------------------------------------------------------
+// static tables
+// ---------------------------------------------------------------------------------------------
+// Direction enum order (dungeon/coord.rs:198-242): Up Down Left Right LeftUp RightUp LeftDown RightDown Stay
+__device__ __constant__ int8_t kDX[9] = {0, 0, -1, 1, -1, 1, -1, 1, 0};
+__device__ __constant__ int8_t kDY[9] = {-1, 1, 0, 0, -1, -1, 1, 1, 0};
+__device__ __constant__ uint8_t kGlyph[8] = {'#', '.', '-', '|', '%', '+', '^', ' '};  // Surface::tile (rogue/mod.rs:149-163)
+
+// BUILTIN_ENEMIES (character/enemies.rs:474-761), index = tile - 'A'
+#define EA_MEAN 1
+#define EA_RANDOM 512
+#define EA_CONFUSED 1024
+__device__ __constant__ uint16_t kMonAttr[26] = {1 | 32, 2 | 512, 0, 1, 1, 1, 2 | 1 | 4, 1, 256, 0, 1, 64, 1, 0, 8, 16, 1, 128 | 1, 1, 1 | 4, 1, 1 | 4, 0, 0, 0, 1};
+__device__ __constant__ int8_t kMonDef[26] = {2 | 8, 3, 4, 3, 7, 3, 2, 5, 9, 6, 7, 8, 2, 9, 6, 3, 3, 3, 5, 4, -2, 1, 4, 7, 6, 8};
+__device__ __constant__ uint16_t kMonExp[26] = {20, 1, 17, 5000, 2, 80, 2000, 3, 5, 3000, 1, 10, 200, 37, 5, 120, 15, 9, 2, 120, 190, 350, 55, 100, 50, 6};
+__device__ __constant__ uint8_t kMonLevel[26] = {5, 1, 4, 10, 1, 8, 13, 1, 1, 15, 1, 3, 8, 3, 1, 8, 3, 2, 1, 6, 7, 8, 5, 7, 4, 2};
+__device__ __constant__ uint8_t kMonNAtt[26] = {1, 1, 3, 3, 1, 0, 2, 1, 1, 2, 1, 1, 3, 1, 1, 1, 2, 1, 1, 3, 3, 1, 1, 1, 2, 1};
+// attack dice (times, max) x3
+__device__ __constant__ uint8_t kMonAtt[26][6] = {
+    {0, 0, 0, 0, 0, 0}, {1, 2, 0, 0, 0, 0}, {1, 2, 1, 5, 1, 5}, {1, 8, 1, 8, 3, 10}, {1, 2, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {4, 3, 3, 5, 0, 0},
+    {1, 8, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {2, 12, 2, 4, 0, 0}, {1, 4, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0}, {3, 4, 3, 4, 2, 5}, {0, 0, 0, 0, 0, 0},
+    {1, 8, 0, 0, 0, 0}, {4, 4, 0, 0, 0, 0}, {1, 5, 1, 5, 0, 0}, {1, 6, 0, 0, 0, 0}, {1, 3, 0, 0, 0, 0}, {1, 8, 1, 8, 2, 6}, {1, 9, 1, 9, 2, 9},
+    {1, 19, 0, 0, 0, 0}, {1, 6, 0, 0, 0, 0}, {4, 4, 0, 0, 0, 0}, {1, 6, 1, 6, 0, 0}, {1, 8, 0, 0, 0, 0}};
+
+// Symbol::from_tile (core/src/symbol.rs:17-40); 255 = not a symbol
+__device__ __forceinline__ uint32_t tile_to_sym(uint32_t t) {
+    switch (t) {
+    case ' ': return 0; case '@': return 1; case '#': return 2; case '.': return 3; case '-': case '|': return 4;
+    case '%': return 5; case '+': return 6; case '^': return 7; case '!': return 8; case '?': return 9; case ']': return 10;
+    case ')': return 11; case '/': return 12; case '*': return 13; case ':': return 14; case '=': return 15; case ',': return 16;
+    default: return (t >= 'A' && t <= 'Z') ? t - 'A' + 17 : 255u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RNG: xorshift128 + rand-0.7 sample_single (core/src/rng.rs:48-98)
+// ---------------------------------------------------------------------------------------------
+struct Rng { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ void rng_seed(Rng &r, uint64_t lo, uint64_t hi) {
+    r.x = (uint32_t)lo; r.y = (uint32_t)(lo >> 32); r.z = (uint32_t)hi; r.w = (uint32_t)(hi >> 32);
+    if ((r.x | r.y | r.z | r.w) == 0) r.x = r.y = r.z = r.w = 0x0BAD5EEDu;
+}
+__device__ __forceinline__ uint32_t rng_u32(Rng &r) {
+    uint32_t t = r.x ^ (r.x << 11);
+    r.x = r.y; r.y = r.z; r.z = r.w;
+    r.w = r.w ^ (r.w >> 19) ^ (t ^ (t >> 8));
+    return r.w;
+}
+// u32 / i32 call sites: one next_u32 per attempt
+__device__ __forceinline__ uint32_t range32(Rng &r, uint32_t low, uint32_t high) {
+    uint32_t range = high - low;
+    uint32_t zone = (range << __clz((int)range)) - 1u;
+    for (;;) {
+        uint32_t v = rng_u32(r);
+        uint32_t lo = v * range;
+        if (lo <= zone) return low + __umulhi(v, range);
+    }
+}
+// usize / i64 call sites: next_u64 = two next_u32 (low word first), 128-bit product
+__device__ __forceinline__ uint64_t range64(Rng &r, uint64_t low, uint64_t high) {
+    uint64_t range = high - low;
+    uint64_t zone = (range << __clzll((long long)range)) - 1ull;
+    for (;;) {
+        uint64_t l = rng_u32(r), h = rng_u32(r);
+        uint64_t v = (h << 32) | l;
+        uint64_t lo = v * range;
+        if (lo <= zone) return low + __umul64hi(v, range);
+    }
+}
+__device__ __forceinline__ bool does_happen(Rng &r, uint32_t p_inv) { return range32(r, 0, p_inv) == 0; }
+__device__ __forceinline__ bool parcent(Rng &r, uint32_t p) { return range32(r, 1, 101) <= p; }
+
+// ---------------------------------------------------------------------------------------------
+// per-lane environment view
+// ---------------------------------------------------------------------------------------------
+struct Env {
+    int e;              // env index
+    int n;              // env count (SoA stride)
+    uint16_t *cell;     // this env's grid
+    Rng rd, ri, re;     // dungeon / item / enemy streams
+    int px, py;
+    int hp, hpmax, plvl;
+    uint32_t exp, food, quiet, gold, dlevel;
+    uint32_t mon_alive, mon_active;
+};
+
+#define POS(x, y) ((uint32_t)(((x) << 8) | (y)))
+#define POS_X(p) ((int)(((p) >> 8) & 0xff))
+#define POS_Y(p) ((int)((p) & 0xff))
+
+__device__ __forceinline__ bool can_walk(uint32_t c) {
+    uint32_t s = c & C_SURF_MASK;
+    return !(s == S_WALLX || s == S_WALLY || s == S_NONE);
+}
+__device__ __forceinline__ bool in_bounds(const RgConfig &c, int x, int y) { return x >= 0 && y >= 0 && x < c.width && y < c.height; }
+
+// Room::assigned_area of room id i (rooms.rs:192-209), half-open
+__device__ __forceinline__ void assigned_area(const RgConfig &c, int i, int &x0, int &y0, int &x1, int &y1) {
+    int rsx = c.width / c.room_num_x, rsy = c.height / c.room_num_y;
+    int cx = i % c.room_num_x, cy = i / c.room_num_x;
+    x0 = cx * rsx; x1 = x0 + rsx;
+    y0 = cy == 0 ? 1 : cy * rsy;
+    y1 = (cy + 1) * rsy;
+    if (y1 == c.height) y1 -= 1;
+}
+// Floor::cd_to_room_id (floor.rs:194-200): areas are disjoint, so arithmetic replaces the scan
+__device__ __forceinline__ int room_id_of(const RgConfig &c, int x, int y) {
+    int rsx = c.width / c.room_num_x, rsy = c.height / c.room_num_y;
+    if (y < 1 || x < 0) return -1;
+    int cx = x / rsx, cy = y / rsy;
+    if (cx >= c.room_num_x || cy >= c.room_num_y) return -1;
+    if ((cy + 1) * rsy == c.height && y == c.height - 1) return -1;
+    return cy * c.room_num_x + cx;
+}
+__device__ __forceinline__ void unpack_rect(uint32_t r, int &x0, int &y0, int &x1, int &y1) {
+    x0 = r & 0xff; y0 = (r >> 8) & 0xff; x1 = (r >> 16) & 0xff; y1 = r >> 24;
+}
+
+// Floor::can_move_impl (floor.rs:169-182)
+__device__ __forceinline__ bool can_move(const RgConfig &c, const uint16_t *cell, int x, int y, int d, bool is_enemy) {
+    int dx = kDX[d], dy = kDY[d];
+    int nx = x + dx, ny = y + dy;
+    if (!in_bounds(c, nx, ny)) return false;
+    uint32_t nc = cell[ny * c.width + nx];
+    bool res = can_walk(nc);
+    if (!is_enemy) res = res && !(nc & (C_HIDDEN | C_LOCKED));
+    if (dx != 0 && dy != 0) {
+        res = res && can_walk(cell[y * c.width + nx]);
+        res = res && can_walk(cell[ny * c.width + x]);
+    }
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// monsters table helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mon_find(const RgState &S, const Env &E, int nrooms, uint32_t pos) {
+    if (E.mon_alive == 0) return -1;
+    int found = -1;
+    for (int s = 0; s < nrooms; s++) {
+        uint32_t w = S.mon_w0[s * E.n + E.e];
+        uint32_t fl = w >> 24;
+        if ((fl & MF_ALIVE) && (w & 0xffff) == pos) found = s;
+    }
+    return found;
+}
+// skip() of EnemyHandler::move_actives (enemies.rs:386-387) seen from monster `self`: a cell is blocked by any
+// asleep monster or any active monster that already moved this turn; `self` is in neither map while it moves
+__device__ __forceinline__ bool blocked_for(const RgState &S, const Env &E, int nrooms, uint32_t pos, int self) {
+    bool blk = false;
+    for (int s = 0; s < nrooms; s++) {
+        uint32_t w = S.mon_w0[s * E.n + E.e];
+        uint32_t fl = w >> 24;
+        if (s != self && (fl & MF_ALIVE) && !(fl & MF_PENDING) && (w & 0xffff) == pos) blk = true;
+    }
+    return blk;
+}
+__device__ __forceinline__ uint32_t lev_add_of(const RgConfig &c, uint32_t level) { return c.amulet_level < level ? level - c.amulet_level : 0; }
+
+// EnemyHandler::activate_area (enemies.rs:342-362): wake MEAN sleepers inside room `rid`'s assigned area
+__device__ void activate_room(const RgState &S, const RgConfig &c, Env &E, int rid) {
+    if (E.mon_alive == E.mon_active) return;
+    int nrooms = c.room_num_x * c.room_num_y;
+    for (int s = 0; s < nrooms; s++) {
+        uint32_t w = S.mon_w0[s * E.n + E.e];
+        uint32_t fl = w >> 24;
+        if (!(fl & MF_ALIVE) || (fl & MF_ACTIVE)) continue;
+        if (!(kMonAttr[(w >> 16) & 0xff] & EA_MEAN)) continue;
+        if (room_id_of(c, POS_X(w), POS_Y(w)) != rid) continue;
+        S.mon_w0[s * E.n + E.e] = w | (MF_ACTIVE << 24);
+        E.mon_active++;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// field-of-view (floor.rs:201-312)
+// ---------------------------------------------------------------------------------------------
+__device__ void player_in(const RgState &S, const RgConfig &c, Env &E, int x, int y, bool init) {
+    uint16_t *cell = E.cell;
+    int W = c.width;
+    uint32_t here = cell[y * W + x];
+    if (init || (here & C_DOOR)) {
+        int rid = room_id_of(c, x, y);
+        if (rid >= 0) {
+            uint8_t meta = S.room_meta[rid * E.n + E.e];
+            if (!(meta & RM_VISITED)) {  // Floor::enters_room (floor.rs:231-247)
+                S.room_meta[rid * E.n + E.e] = meta | RM_VISITED;
+                if ((meta & RM_KIND_MASK) == RK_NORMAL && !(meta & RM_DARK)) {
+                    int x0, y0, x1, y1;
+                    unpack_rect(S.room_rect[rid * E.n + E.e], x0, y0, x1, y1);
+                    for (int yy = y0; yy < y1; yy++)
+                        for (int xx = x0; xx < x1; xx++) cell[yy * W + xx] |= C_DRAWN | C_VISIBLE;
+                }
+            }
+            activate_room(S, c, E, rid);
+        }
+    }
+    cell[y * W + x] |= C_VISITED;
+    for (int d = 0; d < 9; d++) {
+        int cx = x + kDX[d], cy = y + kDY[d];
+        if (!in_bounds(c, cx, cy)) continue;
+        uint32_t v = cell[cy * W + cx];
+        bool diag = d >= 4 && d < 8;
+        if (diag && (v & C_SURF_MASK) == S_PASSAGE) continue;
+        if (v & C_HIDDEN) continue;  // Cell::approached (field.rs:20-26)
+        cell[cy * W + cx] = v | C_DRAWN | C_VISIBLE;
+    }
+}
+__device__ void player_out(const RgState &S, const RgConfig &c, Env &E, int x, int y) {
+    uint16_t *cell = E.cell;
+    int W = c.width;
+    if (cell[y * W + x] & C_DOOR) {  // Floor::leaves_room (floor.rs:249-261)
+        int rid = room_id_of(c, x, y);
+        if (rid >= 0) {
+            uint8_t meta = S.room_meta[rid * E.n + E.e];
+            if ((meta & RM_VISITED) && (meta & RM_DARK)) {
+                int x0, y0, x1, y1;
+                if ((meta & RM_KIND_MASK) == RK_EMPTY) assigned_area(c, rid, x0, y0, x1, y1);
+                else unpack_rect(S.room_rect[rid * E.n + E.e], x0, y0, x1, y1);
+                for (int yy = y0 + 1; yy < y1 - 1; yy++)
+                    for (int xx = x0 + 1; xx < x1 - 1; xx++) cell[yy * W + xx] &= ~C_VISIBLE;
+            }
+        }
+    }
+    for (int d = 0; d < 9; d++) {
+        int cx = x + kDX[d], cy = y + kDY[d];
+        if (!in_bounds(c, cx, cy)) continue;
+        uint32_t v = cell[cy * W + cx];
+        if ((v & C_SURF_MASK) == S_FLOOR && (v & C_DARK)) cell[cy * W + cx] = v & ~C_VISIBLE;  // Cell::left
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generator (rogue/rooms.rs, maze.rs, passages.rs, floor.rs, rogue/mod.rs:434-481)
+// ---------------------------------------------------------------------------------------------
+// free-cell selection.  The reference keeps a FenwickSet per room; only `nth` over "members minus a
+// handful of filled cells" is ever observed during level creation, so the set is
+// implicit: interior cells (Normal) or C_MAZE cells (Maze) in row-major order, minus `excl`.
+__device__ bool room_select(const RgState &S, const RgConfig &c, Env &E, int rid, uint32_t excl /* pos or ~0u */, uint32_t &out) {
+    uint8_t meta = S.room_meta[rid * E.n + E.e];
+    int kind = meta & RM_KIND_MASK;
+    if (kind == RK_EMPTY) return false;
+    int x0, y0, x1, y1;
+    unpack_rect(S.room_rect[rid * E.n + E.e], x0, y0, x1, y1);
+    if (kind == RK_NORMAL) {
+        int iw = x1 - x0 - 2, ih = y1 - y0 - 2;
+        int count = iw * ih;
+        int eo = -1;
+        if (excl != ~0u) { eo = (POS_Y(excl) - y0 - 1) * iw + (POS_X(excl) - x0 - 1); count--; }
+        if (count <= 0) return false;
+        int nth = (int)range64(E.rd, 0, (uint64_t)count);
+        if (eo >= 0 && eo <= nth) nth++;
+        out = POS(x0 + 1 + nth % iw, y0 + 1 + nth / iw);
+        return true;
+    }
+    int count = 0;
+    for (int yy = y0; yy < y1; yy++)
+        for (int xx = x0; xx < x1; xx++)
+            if ((E.cell[yy * c.width + xx] & C_MAZE) && POS(xx, yy) != excl) count++;
+    if (count == 0) return false;
+    int nth = (int)range64(E.rd, 0, (uint64_t)count);
+    for (int yy = y0; yy < y1; yy++)
+        for (int xx = x0; xx < x1; xx++)
+            if ((E.cell[yy * c.width + xx] & C_MAZE) && POS(xx, yy) != excl) {
+                if (nth == 0) { out = POS(xx, yy); return true; }
+                nth--;
+            }
+    return false;
+}
+// nth set bit of a small mask
+__device__ __forceinline__ int nth_bit(uint32_t m, int nth) {
+    for (int i = 0; i < nth; i++) m &= m - 1;
+    return __ffs((int)m) - 1;
+}
+// Floor::select_cell (floor.rs:333-346)
+__device__ bool floor_select(const RgState &S, const RgConfig &c, Env &E, uint32_t non_empty, int mode /*0 stair, 1 player*/, uint32_t &out) {
+    uint32_t cand = non_empty;
+    while (cand) {
+        int idx = nth_bit(cand, (int)range64(E.rd, 0, (uint64_t)__popc(cand)));
+        uint32_t excl = ~0u;
+        if (mode == 0) { uint32_t g = S.gold_pos[idx * E.n + E.e]; if (g & 0x10000u) excl = g & 0xffff; }
+        else { uint32_t w = S.mon_w0[idx * E.n + E.e]; if ((w >> 24) & MF_ALIVE) excl = w & 0xffff; }
+        if (room_select(S, c, E, idx, excl, out)) return true;
+        cand &= ~(1u << idx);
+    }
+    return false;
+}
+
+// gen_attr (floor.rs:420-451) for Passage / Door cells; returns C_HIDDEN / C_LOCKED / 0
+__device__ __forceinline__ uint32_t gen_attr_corridor(const RgConfig &c, Env &E, int kind, uint32_t level) {
+    if (range32(E.rd, 0, c.dark_level) < level) {
+        if (kind == S_PASSAGE) { if (does_happen(E.rd, c.hidden_passage_rate_inv)) return C_HIDDEN; }
+        else { if (does_happen(E.rd, c.locked_door_rate_inv)) return C_LOCKED; }
+    }
+    return 0;
+}
+// one registered corridor cell (floor.rs:87-101)
+__device__ __forceinline__ void register_cell(const RgConfig &c, Env &E, int x, int y, int kind, uint32_t level) {
+    uint32_t a = gen_attr_corridor(c, E, kind, level);
+    uint32_t v = E.cell[y * c.width + x];
+    v = (v & ~C_ATTR_MASK) | a;
+    if (kind == S_DOOR) v |= C_DOOR;
+    if (!a) v = (v & ~C_SURF_MASK) | (uint32_t)kind;
+    E.cell[y * c.width + x] = (uint16_t)v;
+}
+
+// select_start_or_end (passages.rs:143-179).  dir: 0 Up 1 Down 2 Left 3 Right
+__device__ uint32_t select_door(const RgState &S, const RgConfig &c, Env &E, int rid, int dir) {
+    uint8_t meta = S.room_meta[rid * E.n + E.e];
+    int kind = meta & RM_KIND_MASK;
+    int x0, y0, x1, y1;
+    unpack_rect(S.room_rect[rid * E.n + E.e], x0, y0, x1, y1);
+    if (kind == RK_EMPTY) return POS(x0, y0);
+    if (kind == RK_NORMAL) {  // edges(range, dir, inclusive): the wall without its corners; SliceRandom::choose = 64-bit draw
+        if (dir < 2) {
+            int k = (int)range64(E.rd, 0, (uint64_t)(x1 - x0 - 2));
+            return POS(x0 + 1 + k, dir == 1 ? y1 - 1 : y0);
+        }
+        int k = (int)range64(E.rd, 0, (uint64_t)(y1 - y0 - 2));
+        return POS(dir == 2 ? x0 : x1 - 1, y0 + 1 + k);
+    }
+    // Maze: shrink the probe rectangle from the facing side until its edge holds maze cells
+    int rx0 = x0, ry0 = y0, rx1 = x1, ry1 = y1;
+    for (int guard = 0; guard < 256 && rx0 < rx1 && ry0 < ry1; guard++) {
+        int cnt = 0;
+        if (dir < 2) {
+            int yy = dir == 1 ? ry1 - 1 : ry0;
+            for (int xx = rx0; xx < rx1; xx++)
+                if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.cell[yy * c.width + xx] & C_MAZE)) cnt++;
+            if (cnt) {
+                int k = (int)range64(E.rd, 0, (uint64_t)cnt);
+                for (int xx = rx0; xx < rx1; xx++)
+                    if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.cell[yy * c.width + xx] & C_MAZE)) { if (k == 0) return POS(xx, yy); k--; }
+            }
+        } else {
+            int xx = dir == 2 ? rx0 : rx1 - 1;
+            for (int yy = ry0; yy < ry1; yy++)
+                if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.cell[yy * c.width + xx] & C_MAZE)) cnt++;
+            if (cnt) {
+                int k = (int)range64(E.rd, 0, (uint64_t)cnt);
+                for (int yy = ry0; yy < ry1; yy++)
+                    if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.cell[yy * c.width + xx] & C_MAZE)) { if (k == 0) return POS(xx, yy); k--; }
+            }
+        }
+        if (dir == 1) ry1--; else if (dir == 2) rx0--; else if (dir == 3) rx1--; else ry0--;
+    }
+    return POS(x0, y0);
+}
+
+// connect_2rooms (passages.rs:84-133): draws the two doors and the bend now, records the corridor for
+// the deferred gen_attr pass (the reference collects Positioned<Surface> in a Vec, floor.rs:73-86)
+__device__ void connect_rooms(const RgState &S, const RgConfig &c, Env &E, int r1, int r2, int dir, int &n_edges) {
+    if (dir == 0 || dir == 2) { int t = r1; r1 = r2; r2 = t; dir ^= 1; }
+    uint32_t s = select_door(S, c, E, r1, dir);
+    uint32_t t = select_door(S, c, E, r2, dir ^ 1);
+    int k1 = (S.room_meta[r1 * E.n + E.e] & RM_KIND_MASK) == RK_NORMAL;
+    int k2 = (S.room_meta[r2 * E.n + E.e] & RM_KIND_MASK) == RK_NORMAL;
+    int bend;
+    if (dir == 1) bend = (int)range32(E.rd, (uint32_t)(POS_Y(s) + 1), (uint32_t)POS_Y(t));
+    else bend = (int)range32(E.rd, (uint32_t)(POS_X(s) + 1), (uint32_t)POS_X(t));
+    if (n_edges < RG_MAX_EDGES) {
+        S.edge_a[n_edges * E.n + E.e] = s | (t << 16);
+        S.edge_b[n_edges * E.n + E.e] = (uint32_t)bend | ((uint32_t)(dir == 1) << 8) | ((uint32_t)k1 << 9) | ((uint32_t)k2 << 10);
+        n_edges++;
+    }
+}
+// replay one recorded corridor in registration order (passages.rs:98-132 + floor.rs:87-101)
+__device__ void paint_corridor(const RgConfig &c, Env &E, uint32_t a, uint32_t b, uint32_t level) {
+    int sx = POS_X(a), sy = POS_Y(a), ex = POS_X(a >> 16), ey = POS_Y(a >> 16);
+    int bend = b & 0xff;
+    bool down = (b >> 8) & 1;
+    register_cell(c, E, sx, sy, ((b >> 9) & 1) ? S_DOOR : S_PASSAGE, level);
+    register_cell(c, E, ex, ey, ((b >> 10) & 1) ? S_DOOR : S_PASSAGE, level);
+    int dx = down ? 0 : 1, dy = down ? 1 : 0;
+    int tsx = down ? sx : bend, tsy = down ? bend : sy;
+    int tex = down ? ex : bend, tey = down ? bend : ey;
+    int tdx = down ? (sx < ex ? 1 : -1) : 0, tdy = down ? 0 : (sy < ey ? 1 : -1);
+    int x = sx + dx, y = sy + dy;
+    while (!(x == tsx && y == tsy)) { register_cell(c, E, x, y, S_PASSAGE, level); x += dx; y += dy; }
+    x = tsx; y = tsy;
+    while (!(x == tex && y == tey)) { register_cell(c, E, x, y, S_PASSAGE, level); x += tdx; y += tdy; }
+    x = tex; y = tey;
+    while (!(x == ex && y == ey)) { register_cell(c, E, x, y, S_PASSAGE, level); x += dx; y += dy; }
+}
+
+// select_candidate (passages.rs:69-82): reservoir over grid-neighbour rooms in ascending id
+__device__ int select_candidate(const RgConfig &c, Env &E, int nrooms, int node, uint32_t excl_mask, int &dir_out) {
+    int rnx = c.room_num_x, rny = c.room_num_y;
+    int nx0 = node % rnx, ny0 = node / rnx, res = -1, i = 0;
+    for (int id = 0; id < nrooms; id++) {
+        if ((excl_mask >> id) & 1) continue;
+        int ox = id % rnx, oy = id / rnx, d;
+        if (ox == nx0 && oy == ny0 - 1) d = 0;
+        else if (ox == nx0 && oy == ny0 + 1) d = 1;
+        else if (oy == ny0 && ox == nx0 - 1) d = 2;
+        else if (oy == ny0 && ox == nx0 + 1) d = 3;
+        else continue;
+        (void)rny;
+        if (does_happen(E.rd, (uint32_t)i + 1)) { res = id; dir_out = d; }
+        i++;
+    }
+    return res;
+}
+
+// dig_maze (maze.rs:38-89) with an explicit stack (the reference recurses; same visiting and draw order)
+__device__ void dig_maze(const RgState &S, const RgConfig &c, Env &E, int x0, int y0, int x1, int y1) {
+    uint16_t *stk = S.maze_stack + (size_t)E.e * RG_MAZE_STACK;
+    int W = c.width, sp = 0;
+    E.cell[y0 * W + x0] |= C_MAZE;
+    stk[sp++] = (uint16_t)POS(x0, y0);
+    while (sp > 0) {
+        int cx = POS_X(stk[sp - 1]), cy = POS_Y(stk[sp - 1]);
+        int dig = -1, i = 0;
+        for (int d = 0; d < 4; d++) {
+            int nx = cx + 2 * kDX[d], ny = cy + 2 * kDY[d];
+            if (nx < x0 || nx >= x1 || ny < y0 || ny >= y1) continue;
+            if (E.cell[ny * W + nx] & C_MAZE) continue;
+            if (does_happen(E.rd, (uint32_t)i + 1)) dig = d;
+            i++;
+        }
+        if (dig < 0) { sp--; continue; }
+        for (int k = 1; k <= 2; k++) E.cell[(cy + k * kDY[dig]) * W + cx + k * kDX[dig]] |= C_MAZE;
+        if (sp < RG_MAZE_STACK) stk[sp++] = (uint16_t)POS(cx + 2 * kDX[dig], cy + 2 * kDY[dig]);
+    }
+}
+
+// Dungeon::new_level_ (rogue/mod.rs:434-481).  Returns the bitmask of non-empty rooms.
+__device__ __noinline__ uint32_t gen_level(const RgState &S, const RgConfig &c, Env &E) {
+    const int W = c.width, H = c.height, HW = W * H, n = E.n, e = E.e;
+    const int rnx = c.room_num_x, nrooms = rnx * c.room_num_y;
+    uint16_t *cell = E.cell;
+    const uint32_t level = ++E.dlevel;
+
+    // fresh Field: Surface::None, no attributes (16-byte stores; the grid is 16-byte aligned)
+    {
+        uint4 v; v.x = v.y = v.z = v.w = (S_NONE | (S_NONE << 16));
+        uint4 *p = reinterpret_cast<uint4 *>(cell);
+        int n16 = HW / 8;
+        for (int i = 0; i < n16; i++) p[i] = v;
+        for (int i = n16 * 8; i < HW; i++) cell[i] = S_NONE;
+    }
+    for (int s = 0; s < nrooms; s++) {  // remove_enemies + fresh Floor::items
+        S.mon_w0[s * n + e] = 0;
+        S.gold_pos[s * n + e] = 0;
+    }
+    E.mon_alive = E.mon_active = 0;
+
+    // ---- gen_rooms (rooms.rs:165-211) ----
+    uint32_t empty_num = range32(E.rd, 0, c.max_empty_rooms + 1);
+    if (empty_num >= (uint32_t)nrooms) empty_num = nrooms - 1;
+    uint32_t empty_mask = 0;
+    {
+        uint32_t sel = nrooms >= 32 ? 0xffffffffu : ((1u << nrooms) - 1u);
+        for (uint32_t k = 0; k < empty_num; k++) {  // rng.select(0..room_num).take(empty_num): 64-bit nth
+            int id = nth_bit(sel, (int)range64(E.rd, 0, (uint64_t)__popc(sel)));
+            sel &= ~(1u << id);
+            empty_mask |= 1u << id;
+        }
+    }
+    for (int i = 0; i < nrooms; i++) {  // make_room (rooms.rs:214-269)
+        int ax0, ay0, ax1, ay1;
+        assigned_area(c, i, ax0, ay0, ax1, ay1);
+        int rsx = ax1 - ax0, rsy = ay1 - ay0;
+        uint32_t rect; uint8_t meta;
+        if ((empty_mask >> i) & 1) {
+            int x = (int)range32(E.rd, 1, (uint32_t)(rsx - 1)) + ax0;
+            int y = (int)range32(E.rd, 1, (uint32_t)(rsy - 1)) + ay0;
+            rect = (uint32_t)x | ((uint32_t)y << 8);
+            meta = RK_EMPTY | RM_DARK;
+        } else {
+            bool dark = range32(E.rd, 0, c.dark_level) < level;
+            if (dark && does_happen(E.rd, c.maze_rate_inv)) {
+                int mx1 = ax0 + rsx - 1, my1 = ay0 + rsy - 1;
+                rect = (uint32_t)ax0 | ((uint32_t)ay0 << 8) | ((uint32_t)mx1 << 16) | ((uint32_t)my1 << 24);
+                meta = RK_MAZE | RM_DARK;
+                dig_maze(S, c, E, ax0, ay0, mx1, my1);
+            } else {
+                int sx = (int)range32(E.rd, (uint32_t)c.min_room_x, (uint32_t)rsx);
+                int sy = (int)range32(E.rd, (uint32_t)c.min_room_y, (uint32_t)rsy);
+                int ox = (int)range32(E.rd, 0, (uint32_t)(rsx - sx)) + ax0;
+                int oy = (int)range32(E.rd, 0, (uint32_t)(rsy - sy)) + ay0;
+                rect = (uint32_t)ox | ((uint32_t)oy << 8) | ((uint32_t)(ox + sx) << 16) | ((uint32_t)(oy + sy) << 24);
+                meta = RK_NORMAL | (dark ? RM_DARK : 0);
+            }
+        }
+        S.room_rect[i * n + e] = rect;
+        S.room_meta[i * n + e] = meta;
+    }
+    // ---- paint rooms in id order (floor.rs:61-71; Room::draw rooms.rs:58-82) ----
+    for (int i = 0; i < nrooms; i++) {
+        uint8_t meta = S.room_meta[i * n + e];
+        int kind = meta & RM_KIND_MASK;
+        if (kind == RK_EMPTY) continue;
+        int x0, y0, x1, y1;
+        unpack_rect(S.room_rect[i * n + e], x0, y0, x1, y1);
+        if (kind == RK_NORMAL) {
+            uint16_t fl = (uint16_t)(S_FLOOR | ((meta & RM_DARK) ? C_DARK : 0));
+            for (int x = x0; x < x1; x++) { cell[y0 * W + x] = S_WALLX; cell[(y1 - 1) * W + x] = S_WALLX; }
+            for (int y = y0 + 1; y < y1 - 1; y++) {
+                cell[y * W + x0] = S_WALLY; cell[y * W + x1 - 1] = S_WALLY;
+                for (int x = x0 + 1; x < x1 - 1; x++) cell[y * W + x] = fl;
+            }
+        } else {  // maze cells in ascending range index; each draws gen_attr (Passage)
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++) {
+                    uint32_t v = cell[y * W + x];
+                    if (!(v & C_MAZE)) continue;
+                    uint32_t a = gen_attr_corridor(c, E, S_PASSAGE, level);
+                    cell[y * W + x] = (uint16_t)(C_MAZE | S_PASSAGE | a);
+                }
+        }
+    }
+    // ---- dig_passges (passages.rs:16-67) ----
+    int n_edges = 0;
+    {
+        uint32_t conn[RG_MAX_ROOMS];
+        for (int i = 0; i < RG_MAX_ROOMS; i++) conn[i] = 0;
+        uint32_t selected = 0;
+        int cur = (int)range64(E.rd, 0, (uint64_t)nrooms), n_sel = 1;
+        selected |= 1u << cur;
+        while (n_sel < nrooms) {
+            int dir = 0;
+            int nxt = select_candidate(c, E, nrooms, cur, selected, dir);
+            if (nxt >= 0) {
+                selected |= 1u << nxt; n_sel++;
+                conn[cur] |= 1u << nxt; conn[nxt] |= 1u << cur;
+                connect_rooms(S, c, E, cur, nxt, dir, n_edges);
+            } else {
+                cur = nth_bit(selected, (int)range64(E.rd, 0, (uint64_t)n_sel));
+            }
+        }
+        uint32_t try_num = range32(E.rd, 0, c.max_extra_edges);
+        for (uint32_t t = 0; t < try_num; t++) {
+            int room1 = (int)range64(E.rd, 0, (uint64_t)nrooms), dir = 0;
+            int room2 = select_candidate(c, E, nrooms, room1, conn[room1], dir);
+            if (room2 >= 0) {
+                conn[room1] |= 1u << room2; conn[room2] |= 1u << room1;
+                connect_rooms(S, c, E, room1, room2, dir, n_edges);
+            }
+        }
+    }
+    for (int k = 0; k < n_edges; k++) paint_corridor(c, E, S.edge_a[k * n + e], S.edge_b[k * n + e], level);
+
+    const uint32_t non_empty = (nrooms >= 32 ? 0xffffffffu : ((1u << nrooms) - 1u)) & ~empty_mask;
+    // ---- gold (floor.rs:132-153, item/gold.rs:18-24) ----
+    for (int i = 0; i < nrooms; i++) {
+        uint32_t pos;
+        if (!room_select(S, c, E, i, ~0u, pos)) continue;
+        if (!does_happen(E.ri, c.gold_rate_inv)) continue;
+        uint32_t num = range32(E.ri, 0, c.gold_base + c.gold_per_level * level) + c.gold_minimum;
+        S.gold_pos[i * n + e] = pos | 0x10000u;
+        S.gold_amt[i * n + e] = num;
+        S.room_meta[i * n + e] |= RM_HAS_GOLD;
+        cell[POS_Y(pos) * W + POS_X(pos)] |= C_GOLD;
+    }
+    // ---- stair (floor.rs:156-167) ----
+    {
+        uint32_t pos;
+        if (floor_select(S, c, E, non_empty, 0, pos)) {
+            uint32_t v = cell[POS_Y(pos) * W + POS_X(pos)];
+            cell[POS_Y(pos) * W + POS_X(pos)] = (uint16_t)((v & ~C_SURF_MASK) | S_STAIR);
+        }
+    }
+    // ---- monsters (floor.rs:106-130, enemies.rs:265-320) ----
+    if (c.n_enemies > 0) {
+        uint32_t mn = level >= 4 ? level - 4 : 0, mx = level + 6;
+        uint32_t lev_add = lev_add_of(c, level);
+        for (int i = 0; i < nrooms; i++) {
+            uint32_t pos;
+            if (!room_select(S, c, E, i, ~0u, pos)) continue;
+            bool has_gold = S.room_meta[i * n + e] & RM_HAS_GOLD;
+            if (!parcent(E.re, has_gold ? c.appear_rate_gold : c.appear_rate_nogold)) continue;
+            uint32_t len = (uint32_t)c.n_enemies;
+            uint32_t idx = range32(E.re, mn, mx);
+            if (idx > len) { uint32_t rg = len < 5 ? len : 5; idx = (uint32_t)range64(E.re, len - rg, len); }
+            if (idx >= len) continue;
+            uint32_t type = c.enemy_sorted[idx];
+            int64_t mlevel = (int64_t)kMonLevel[type] + lev_add, hp = 0;
+            for (int k = 0; k < 8; k++) hp += (int64_t)range64(E.re, 1, (uint64_t)mlevel + 1);
+            int64_t base = mlevel == 1 ? hp / 8 : hp / 6;
+            uint32_t exp_add = mlevel >= 10 ? (uint32_t)base * 20u : (uint32_t)base * 4u;
+            S.mon_w0[i * n + e] = pos | (type << 16) | ((uint32_t)MF_ALIVE << 24);
+            S.mon_hp[i * n + e] = (int32_t)hp;
+            S.mon_exp[i * n + e] = (uint32_t)kMonExp[type] + lev_add * 10u + exp_add;
+            E.mon_alive++;
+        }
+    }
+    if (!c.hide_dungeon)
+        for (int y = 1; y < H - 1; y++)
+            for (int x = 0; x < W; x++) cell[y * W + x] |= C_VISIBLE;
+    return non_empty;
+}
+
+// actions::new_level's tail (actions.rs:130-137): place the player and enter the room
+__device__ void place_player(const RgState &S, const RgConfig &c, Env &E, uint32_t non_empty) {
+    uint32_t pos = 0;
+    floor_select(S, c, E, non_empty, 1, pos);
+    E.px = POS_X(pos); E.py = POS_Y(pos);
+    player_in(S, c, E, E.px, E.py, true);
+}
+
+// GameConfig::build (core/src/lib.rs:193-228) + PlayerState::reset's status (python/src/lib.rs:52-58)
+__device__ void build_env(const RgState &S, const RgConfig &c, Env &E) {
+    uint64_t lo = S.seed_lo[E.e], hi = S.seed_hi[E.e];
+    if (S.reseed[E.e]) {  // `seed: None` => a new random seed per build; not parity-relevant, splitmix64 chain
+        uint64_t z = lo + 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        uint64_t y = (hi ^ z) + 0x9E3779B97F4A7C15ull; y = (y ^ (y >> 30)) * 0xBF58476D1CE4E5B9ull; y = (y ^ (y >> 27)) * 0x94D049BB133111EBull; y ^= y >> 31;
+        S.seed_lo[E.e] = z; S.seed_hi[E.e] = y;
+    }
+    rng_seed(E.ri, lo, hi); rng_seed(E.re, lo, hi); rng_seed(E.rd, lo, hi);
+    E.dlevel = 0;
+    uint32_t non_empty = gen_level(S, c, E);
+    // Player::init_items: mace 1..2, bow 1..2, arrow 8..17 on the item stream (weapon.rs:159,179-188)
+    (void)range32(E.ri, 1, 2); (void)range32(E.ri, 1, 2); (void)range32(E.ri, 8, 17);
+    E.hp = E.hpmax = c.init_hp; E.plvl = 1; E.exp = 0;
+    E.food = c.hunger_time; E.quiet = 0; E.gold = 0;
+    place_player(S, c, E, non_empty);
+    S.dc_len[E.e] = 0; S.dc_head[E.e] = 0;  // a rebuilt RunTime owns a fresh DistCache
+}
+
+// RunTime::player_status (core/src/lib.rs:345-356, player.rs:107-118) -> mirror
+__device__ __forceinline__ void write_status(const RgState &S, const RgConfig &c, const Env &E) {
+    int32_t *st = S.status + (size_t)E.e * 10;
+    uint32_t hunger = c.hunger_time / 10;
+    st[0] = (int32_t)E.dlevel; st[1] = (int32_t)E.gold; st[2] = E.hp; st[3] = E.hpmax; st[4] = 16; st[5] = 16; st[6] = 0;
+    st[7] = E.plvl; st[8] = (int32_t)E.exp;
+    st[9] = E.food <= hunger ? 2 : (E.food <= hunger * 2 ? 1 : 0);
+}
+
+__device__ __forceinline__ void load_env(const RgState &S, Env &E, int e) {
+    int n = S.n;
+    E.e = e; E.n = n;
+    E.cell = S.cell + (size_t)e * S.hw;
+    E.rd = {S.rng[0 * n + e], S.rng[1 * n + e], S.rng[2 * n + e], S.rng[3 * n + e]};
+    E.ri = {S.rng[4 * n + e], S.rng[5 * n + e], S.rng[6 * n + e], S.rng[7 * n + e]};
+    E.re = {S.rng[8 * n + e], S.rng[9 * n + e], S.rng[10 * n + e], S.rng[11 * n + e]};
+    uint32_t p = S.p_pos[e];
+    E.px = POS_X(p); E.py = POS_Y(p);
+    E.hp = S.p_hp[e]; E.hpmax = S.p_hpmax[e]; E.plvl = S.p_lvl[e];
+    E.exp = S.p_exp[e]; E.food = S.food[e]; E.quiet = S.quiet[e]; E.gold = S.pack_gold[e]; E.dlevel = S.dlevel[e];
+    uint32_t mc = S.mon_cnt[e];
+    E.mon_alive = mc & 0xff; E.mon_active = (mc >> 8) & 0xff;
+}
+__device__ __forceinline__ void store_env(const RgState &S, const Env &E) {
+    int n = S.n, e = E.e;
+    S.rng[0 * n + e] = E.rd.x; S.rng[1 * n + e] = E.rd.y; S.rng[2 * n + e] = E.rd.z; S.rng[3 * n + e] = E.rd.w;
+    S.rng[4 * n + e] = E.ri.x; S.rng[5 * n + e] = E.ri.y; S.rng[6 * n + e] = E.ri.z; S.rng[7 * n + e] = E.ri.w;
+    S.rng[8 * n + e] = E.re.x; S.rng[9 * n + e] = E.re.y; S.rng[10 * n + e] = E.re.z; S.rng[11 * n + e] = E.re.w;
+    S.p_pos[e] = (uint16_t)POS(E.px, E.py);
+    S.p_hp[e] = E.hp; S.p_hpmax[e] = E.hpmax; S.p_lvl[e] = E.plvl;
+    S.p_exp[e] = E.exp; S.food[e] = E.food; S.quiet[e] = E.quiet; S.pack_gold[e] = E.gold; S.dlevel[e] = E.dlevel;
+    S.mon_cnt[e] = E.mon_alive | (E.mon_active << 8);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_build: (re)build every env from its seed
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
+    int e = blockIdx.x * WAVE + threadIdx.x;
+    if (e >= S.n) return;
+    Env E;
+    E.e = e; E.n = S.n; E.cell = S.cell + (size_t)e * S.hw;
+    build_env(S, c, E);
+    store_env(S, E);
+    write_status(S, c, E);
+    S.steps[e] = 0;
+    S.flags[e] = RG_FLAG_REDRAW;
+    S.reward[e] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-cooperative bit-parallel BFS (Floor::make_dist_map, floor.rs:395-416)
+// ---------------------------------------------------------------------------------------------
+// The reference runs a FIFO BFS over 8 directions; the result is the exact unit-weight shortest
+// distance, so any level-synchronous formulation gives identical maps.  Here every grid row is a
+// bitmask (u64 words) in LDS; one level of the frontier expansion is a handful of shifts/ANDs per
+// row-word, with the diagonal rule of can_move_impl (both orthogonal neighbours walkable, floor.rs:
+// 177-180) expressed on the masks.  The 64 lanes of the wave serve one requesting env at a time.
+#define BFS_MAXWW 3                    // ceil(160 / 64)
+#define BFS_MAXT (RG_MAX_H * BFS_MAXWW)
+struct BfsShared {
+    uint64_t walk[BFS_MAXT], vis[BFS_MAXT], fr[2][BFS_MAXT];
+    uint16_t dist[RG_MAX_W * RG_MAX_H];
+};
+
+__device__ __forceinline__ uint64_t row_word(const uint64_t *a, int y, int k, int H, int WW) {
+    return (y < 0 || y >= H || k < 0 || k >= WW) ? 0ull : a[y * WW + k];
+}
+// (a & b) of row y shifted one cell toward +x (shl) or -x (shr), with carries across 64-bit words
+__device__ __forceinline__ uint64_t and_shl(const uint64_t *a, int ya, const uint64_t *b, int yb, int k, int H, int WW) {
+    uint64_t cur = row_word(a, ya, k, H, WW) & row_word(b, yb, k, H, WW);
+    uint64_t prev = row_word(a, ya, k - 1, H, WW) & row_word(b, yb, k - 1, H, WW);
+    return (cur << 1) | (prev >> 63);
+}
+__device__ __forceinline__ uint64_t and_shr(const uint64_t *a, int ya, const uint64_t *b, int yb, int k, int H, int WW) {
+    uint64_t cur = row_word(a, ya, k, H, WW) & row_word(b, yb, k, H, WW);
+    uint64_t next = row_word(a, ya, k + 1, H, WW) & row_word(b, yb, k + 1, H, WW);
+    return (cur >> 1) | (next << 63);
+}
+
+__device__ void bfs_service(const RgState &S, const RgConfig &c, BfsShared &sh, int env, int tx, int ty, int slot, int lane) {
+    const int W = c.width, H = c.height, HW = W * H, WW = (W + 63) >> 6, T = H * WW;
+    const uint16_t *cell = S.cell + (size_t)env * HW;
+    for (int y = 0; y < H; y++)
+        for (int k = 0; k < WW; k++) {
+            int x = k * 64 + lane;
+            bool wk = x < W && can_walk(cell[y * W + x]);
+            uint64_t m = __ballot(wk);
+            if (lane == 0) sh.walk[y * WW + k] = m;
+        }
+    for (int i = lane; i < HW; i += WAVE) sh.dist[i] = DIST_INF;
+    for (int t = lane; t < T; t += WAVE) { sh.vis[t] = 0; sh.fr[0][t] = 0; }
+    __syncthreads();
+    if (lane == 0) {
+        int t = ty * WW + (tx >> 6);
+        sh.vis[t] = 1ull << (tx & 63);
+        sh.fr[0][t] = 1ull << (tx & 63);
+        sh.dist[ty * W + tx] = 0;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t level = 1; level < (uint32_t)HW; level++) {
+        const uint64_t *F = sh.fr[cur];
+        uint64_t *NF = sh.fr[cur ^ 1];
+        bool any = false;
+        for (int t = lane; t < T; t += WAVE) {
+            int y = t / WW, k = t - y * WW;
+            uint64_t wk = sh.walk[t];
+            // same row: Left / Right
+            uint64_t tgt = and_shl(F, y, F, y, k, H, WW) | and_shr(F, y, F, y, k, H, WW);
+            // from the row above (moving Down) and below (moving Up): straight, then the two diagonals.
+            // source (x-+1, y') -> target (x, y) needs walk(x, y') and walk(x-+1, y) besides walk(x, y).
+            tgt |= row_word(F, y - 1, k, H, WW) | row_word(F, y + 1, k, H, WW);
+            tgt |= (and_shl(F, y - 1, sh.walk, y, k, H, WW) | and_shr(F, y - 1, sh.walk, y, k, H, WW)) & row_word(sh.walk, y - 1, k, H, WW);
+            tgt |= (and_shl(F, y + 1, sh.walk, y, k, H, WW) | and_shr(F, y + 1, sh.walk, y, k, H, WW)) & row_word(sh.walk, y + 1, k, H, WW);
+            uint64_t nw = tgt & wk & ~sh.vis[t];
+            NF[t] = nw;
+            if (nw) {
+                sh.vis[t] |= nw;
+                any = true;
+                uint64_t b = nw;
+                while (b) {
+                    int bit = __ffsll((long long)b) - 1;
+                    b &= b - 1;
+                    sh.dist[y * W + k * 64 + bit] = (uint16_t)level;
+                }
+            }
+        }
+        __syncthreads();
+        if (!__any(any)) break;
+        cur ^= 1;
+    }
+    uint16_t *out = S.dc_map + ((size_t)env * RG_DIST_SLOTS + slot) * HW;
+    for (int i = lane; i < HW; i += WAVE) out[i] = sh.dist[i];
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// the turn (core/src/actions.rs, character/{player,fight,enemies}.rs)
+// ---------------------------------------------------------------------------------------------
+#define R_REDRAW 1u
+#define R_STATUS 2u
+#define R_GRAVE 4u
+#define R_HIST_STALE 8u
+#define MSG_HIT_FROM (1u << 8)
+#define MSG_HIT_TO (2u << 8)
+#define MSG_MISS_TO (4u << 8)
+#define MSG_MISS_FROM (8u << 8)
+#define MSG_KILLED (16u << 8)
+#define MSG_SECRET_DOOR (32u << 8)
+#define MSG_NO_DOWNSTAIR (64u << 8)
+
+enum { ACT_INVALID = -1, ACT_MOVE = 0, ACT_MOVE_UNTIL, ACT_DOWNSTAIR, ACT_SEARCH, ACT_NOOP };
+
+// KeyMap::ai (input.rs:73-100)
+__device__ __forceinline__ int decode_key(uint32_t key, int &dir) {
+    uint32_t lower = key | 0x20u;
+    int d = -1;
+    switch (lower) {
+    case 'k': d = 0; break; case 'j': d = 1; break; case 'h': d = 2; break; case 'l': d = 3; break;
+    case 'y': d = 4; break; case 'u': d = 5; break; case 'b': d = 6; break; case 'n': d = 7; break;
+    }
+    if (d >= 0 && ((key >= 'a' && key <= 'z') || (key >= 'A' && key <= 'Z'))) { dir = d; return (key & 0x20u) ? ACT_MOVE : ACT_MOVE_UNTIL; }
+    if (key == '.') return ACT_NOOP;
+    if (key == 's') return ACT_SEARCH;
+    if (key == '>') return ACT_DOWNSTAIR;
+    return ACT_INVALID;
+}
+
+// fight::attack_rate (fight.rs:84-87) + Parcent::truncate
+__device__ __forceinline__ uint32_t attack_rate(int64_t level, int64_t armor, int64_t revision) {
+    int64_t v = (level + armor + revision + 1) * 5;
+    return (uint32_t)(v < 0 ? 0 : (v > 100 ? 100 : v));
+}
+
+// Player::level_up (player.rs:185-197, 345-352)
+__device__ bool level_up(const RgConfig &c, Env &E, uint32_t exp) {
+    E.exp += exp;
+    int cur = E.plvl - 1, diff = 0;
+    if (cur >= c.n_level_exps) return false;
+    while (cur + diff < c.n_level_exps && !(E.exp < c.level_exps[cur + diff])) diff++;
+    if (diff == 0) return false;
+    E.plvl += diff;
+    int add = 0;
+    for (int i = 0; i < diff; i++) add += (int)range64(E.re, 1, 11);
+    E.hpmax += add; E.hp += add;
+    return true;
+}
+
+// actions::player_attack + fight::player_attack (actions.rs:140-166, fight.rs:6-39):
+// mace 2d4 hit+1 dam+1, strength 16 => +0/+0; the monster is always `running` by the time of the roll
+__device__ void player_attack(const RgState &S, const RgConfig &c, Env &E, int slot, uint32_t &react) {
+    int idx = slot * E.n + E.e;
+    uint32_t w = S.mon_w0[idx];
+    E.quiet = 0;
+    if (!((w >> 24) & MF_ACTIVE)) { w |= (uint32_t)MF_ACTIVE << 24; E.mon_active++; S.mon_w0[idx] = w; }
+    uint32_t type = (w >> 16) & 0xff;
+    int64_t def = (int64_t)kMonDef[type] - (int64_t)lev_add_of(c, E.dlevel);
+    uint32_t rate = attack_rate(E.plvl, def, 1);
+    if (parcent(E.re, rate)) {
+        int dmg = (int)range64(E.re, 1, 5);
+        dmg += (int)range64(E.re, 1, 5);
+        dmg += 1;
+        react |= MSG_HIT_TO;
+        int hp = S.mon_hp[idx];
+        if (hp <= dmg) {  // Enemy::get_damage (enemies.rs:205-213)
+            S.mon_w0[idx] = 0;
+            E.mon_alive--; E.mon_active--;
+            if (level_up(c, E, S.mon_exp[idx])) react |= R_STATUS;
+            react |= MSG_KILLED | R_REDRAW;
+        } else S.mon_hp[idx] = dmg - hp;  // reference quirk: stores damage - cur
+    } else react |= MSG_MISS_TO;
+}
+
+// actions::move_player + get_item (actions.rs:168-231); returns `done`
+__device__ bool move_player(const RgState &S, const RgConfig &c, Env &E, int d, uint32_t &react) {
+    const int nrooms = c.room_num_x * c.room_num_y;
+    if (!can_move(c, E.cell, E.px, E.py, d, false)) return true;  // Notify(CantMove): no mirror effect
+    int nx = E.px + kDX[d], ny = E.py + kDY[d];
+    int ms = mon_find(S, E, nrooms, POS(nx, ny));
+    if (ms >= 0) { player_attack(S, c, E, ms, react); return true; }
+    player_out(S, c, E, E.px, E.py);
+    player_in(S, c, E, nx, ny, false);
+    E.px = nx; E.py = ny;
+    react |= R_REDRAW;
+    uint32_t v = E.cell[ny * c.width + nx];
+    if (v & C_GOLD) {  // ItemBox::entry -> Merge into the pack's gold (itembox.rs:30-40)
+        for (int s = 0; s < nrooms; s++) {
+            uint32_t g = S.gold_pos[s * E.n + E.e];
+            if (g == (POS(nx, ny) | 0x10000u)) { E.gold += S.gold_amt[s * E.n + E.e]; S.gold_pos[s * E.n + E.e] = 0; }
+        }
+        E.cell[ny * c.width + nx] = (uint16_t)(v & ~C_GOLD);
+        react |= R_STATUS;
+        return true;
+    }
+    return false;
+}
+
+// Floor::search (floor.rs:349-370)
+__device__ void do_search(const RgConfig &c, Env &E, uint32_t &react) {
+    for (int d = 0; d < 8; d++) {
+        int x = E.px + kDX[d], y = E.py + kDY[d];
+        if (!in_bounds(c, x, y)) continue;
+        uint32_t v = E.cell[y * c.width + x];
+        if ((v & C_HIDDEN) && does_happen(E.rd, c.passage_unlock_rate_inv))
+            v = (v & ~(C_LOCKED | C_HIDDEN | C_SURF_MASK)) | C_VISIBLE | S_PASSAGE;
+        if ((v & C_LOCKED) && does_happen(E.rd, c.door_unlock_rate_inv)) {
+            v = (v & ~(C_LOCKED | C_HIDDEN | C_SURF_MASK)) | C_VISIBLE | S_DOOR;
+            react |= MSG_SECRET_DOOR;
+        }
+        E.cell[y * c.width + x] = (uint16_t)v;
+    }
+    react |= R_REDRAW;
+}
+
+// Player::turn_passed + heal (player.rs:163-176,221-240)
+__device__ void turn_passed(const RgConfig &c, Env &E, uint32_t &react) {
+    E.food -= 1;  // u32: wraps in release builds
+    if (E.food == 0) return;  // [PlayerEvent::Dead], ignored by after_turn (actions.rs:75)
+    uint32_t hunger = c.hunger_time / 10;
+    if (E.food == hunger || E.food == hunger * 2) react |= R_STATUS;
+    E.quiet += 1;
+    int64_t quiet = E.quiet, level = E.plvl, heal;
+    if (level < 8) { heal = quiet + (level << 1) - 20; heal = heal < 0 ? 0 : (heal > 1 ? 1 : heal); }
+    else if (quiet >= 3) heal = (int64_t)range64(E.re, 1, (uint64_t)(level - 6));
+    else heal = 0;
+    if (heal > 0) {
+        E.hp += (int)heal;
+        if (E.hp > E.hpmax) E.hp = E.hpmax;
+        E.quiet = 0;
+        react |= R_STATUS;
+    }
+}
+
+// smallest PENDING monster key strictly greater than `last` (BTreeMap iteration order); -1 if none
+__device__ __forceinline__ int next_pending(const RgState &S, const Env &E, int nrooms, int last, int &slot_out) {
+    int best = 0x7fffffff, bs = -1;
+    for (int s = 0; s < nrooms; s++) {
+        uint32_t w = S.mon_w0[s * E.n + E.e];
+        if (!((w >> 24) & MF_PENDING)) continue;
+        int key = (int)(w & 0xffff);
+        if (key > last && key < best) { best = key; bs = s; }
+    }
+    slot_out = bs;
+    return bs < 0 ? -1 : best;
+}
+
+// EnemyHandler::move_actives, RNG part (enemies.rs:399-404, rogue/mod.rs:383): the per-monster draws do not
+// depend on positions, so they are taken first (same per-stream order) to learn whether a dist map is needed.
+__device__ bool monsters_prepass(const RgState &S, const RgConfig &c, Env &E, uint32_t &rand_mask, uint64_t &rand_dir) {
+    const int nrooms = c.room_num_x * c.room_num_y;
+    rand_mask = 0; rand_dir = 0;
+    for (int s = 0; s < nrooms; s++) {  // the taken map: every active monster is pending
+        uint32_t w = S.mon_w0[s * E.n + E.e];
+        if (((w >> 24) & (MF_ALIVE | MF_ACTIVE)) == (MF_ALIVE | MF_ACTIVE)) S.mon_w0[s * E.n + E.e] = w | ((uint32_t)MF_PENDING << 24);
+    }
+    bool need_map = false;
+    int last = -1, slot;
+    while ((last = next_pending(S, E, nrooms, last, slot)) >= 0) {
+        uint32_t attr = kMonAttr[(S.mon_w0[slot * E.n + E.e] >> 16) & 0xff];
+        bool rnd = false;
+        if (does_happen(E.re, 2) && (attr & EA_RANDOM)) rnd = true;
+        else if (!does_happen(E.re, 5) && (attr & EA_CONFUSED)) rnd = true;
+        if (rnd) {
+            rand_mask |= 1u << slot;
+            rand_dir |= range64(E.rd, 0, 8) << (slot * 4);
+        } else need_map = true;
+    }
+    return need_map;
+}
+
+// DistCache::make_dist_map lookup (rogue/mod.rs:504-517): FIFO ring of 9 maps keyed by target coord only
+__device__ bool dist_cache_lookup(const RgState &S, const Env &E, uint32_t key, int &slot) {
+    int len = S.dc_len[E.e], head = S.dc_head[E.e];
+    for (int i = 0; i < len; i++) {
+        int idx = head + i; if (idx >= RG_DIST_SLOTS) idx -= RG_DIST_SLOTS;
+        if (S.dc_key[idx * E.n + E.e] == key) { slot = idx; return true; }
+    }
+    if (len < RG_DIST_SLOTS) { slot = head + len; if (slot >= RG_DIST_SLOTS) slot -= RG_DIST_SLOTS; S.dc_len[E.e] = (uint8_t)(len + 1); }
+    else { slot = head; S.dc_head[E.e] = (uint8_t)(head + 1 >= RG_DIST_SLOTS ? 0 : head + 1); }
+    S.dc_key[slot * E.n + E.e] = (uint16_t)key;
+    return false;
+}
+
+// EnemyHandler::move_actives moves + actions::move_active_enemies attacks
+// (enemies.rs:366-424, rogue/mod.rs:339-397, actions.rs:82-119, fight.rs:41-72)
+__device__ bool monsters_move(const RgState &S, const RgConfig &c, Env &E, uint32_t rand_mask, uint64_t rand_dir, int map_slot, uint32_t &react) {
+    const int nrooms = c.room_num_x * c.room_num_y, W = c.width, n = E.n, e = E.e;
+    const uint16_t *dist = S.dc_map + ((size_t)e * RG_DIST_SLOTS + (map_slot < 0 ? 0 : map_slot)) * S.hw;
+    const uint32_t ppos = POS(E.px, E.py);
+    uint64_t att_list = 0; int n_att = 0;
+    int last = -1, slot;
+    while ((last = next_pending(S, E, nrooms, last, slot)) >= 0) {
+        uint32_t w = S.mon_w0[slot * n + e] & ~((uint32_t)MF_PENDING << 24);
+        S.mon_w0[slot * n + e] = w;  // leaves the taken map; not yet in the new one, so it never blocks itself
+        int cx = POS_X(w), cy = POS_Y(w);
+        uint32_t fin = w & 0xffff;
+        bool reach = false;
+        if ((rand_mask >> slot) & 1) {  // Dungeon::move_enemy_randomly
+            int d = (int)((rand_dir >> (slot * 4)) & 7);
+            uint32_t np = POS(cx + kDX[d], cy + kDY[d]);
+            if (!blocked_for(S, E, nrooms, np, slot) && can_move(c, E.cell, cx, cy, d, true)) {
+                if (np == ppos) reach = true; else fin = np;
+            }
+        } else {  // Dungeon::move_enemy: greedy step on the (possibly stale) dist map, 9 directions incl. Stay
+            uint32_t best = DIST_INF; bool found = false; uint32_t bp = fin;
+            for (int d = 0; d < 9; d++) {
+                int nx = cx + kDX[d], ny = cy + kDY[d];
+                uint32_t np = POS(nx, ny);
+                if (blocked_for(S, E, nrooms, np, slot)) continue;
+                uint32_t nd = in_bounds(c, nx, ny) ? dist[ny * W + nx] : DIST_INF;
+                if (nd == 0 && can_move(c, E.cell, cx, cy, d, true)) { reach = true; break; }
+                if (nd != DIST_INF && nd > 0 && (!found || nd < best)) { best = nd; bp = np; found = true; }
+            }
+            if (!reach && found) fin = bp;
+        }
+        if (reach) { att_list |= (uint64_t)slot << (4 * n_att); n_att++; }
+        if (fin == (w & 0xffff)) {
+            // BTreeMap::insert on its own key replaces a monster that already moved onto this cell
+            for (int s = 0; s < nrooms; s++) {
+                if (s == slot) continue;
+                uint32_t o = S.mon_w0[s * n + e];
+                uint32_t fl = o >> 24;
+                if ((fl & MF_ALIVE) && (fl & MF_ACTIVE) && !(fl & MF_PENDING) && (o & 0xffff) == fin) { S.mon_w0[s * n + e] = 0; E.mon_alive--; E.mon_active--; }
+            }
+        } else S.mon_w0[slot * n + e] = (w & 0xffff0000u) | fin;
+    }
+    if (n_att > 0) E.quiet = 0;  // player.buttle()
+    bool did_hit = false;
+    uint32_t lev_add = lev_add_of(c, E.dlevel);
+    for (int i = 0; i < n_att; i++) {
+        int s = (int)((att_list >> (4 * i)) & 15);
+        uint32_t type = (S.mon_w0[s * n + e] >> 16) & 0xff;
+        uint32_t rate = attack_rate((int64_t)kMonLevel[type] + lev_add, 4 /* ring mail 3 + 1 */, 0 /* hit_prob_plus(10) */);
+        int sum = 0; bool hit = false;
+        for (int k = 0; k < kMonNAtt[type]; k++) {
+            if (!parcent(E.re, rate)) continue;
+            hit = true;
+            int times = kMonAtt[type][2 * k], mx = kMonAtt[type][2 * k + 1];
+            for (int t = 0; t < times; t++) sum += (int)range64(E.re, 1, (uint64_t)mx + 1);
+        }
+        if (hit) {
+            react |= MSG_HIT_FROM;
+            did_hit = true;
+            E.hp = E.hp - sum > 0 ? E.hp - sum : 0;  // Player::get_damage (player.rs:177-184)
+            if (E.hp == 0) { react |= R_GRAVE; return true; }
+        } else react |= MSG_MISS_FROM;
+    }
+    if (did_hit) react |= R_STATUS;
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_step: one key for every env
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WAVE) k_step(RgState S, RgConfig c, const uint8_t *__restrict__ keys, uint32_t *__restrict__ err_any) {
+    __shared__ BfsShared sh;
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x * WAVE + lane;
+    const bool valid = e < S.n;
+    Env E;
+    uint32_t react = 0, err = 0, old_flags = 0, steps = 0;
+    int act = ACT_NOOP, dir = 0;
+    int gold_before = 0;
+    bool live = false;   // this lane processes a key this call
+    bool ui_dead = false;
+    if (valid) {
+        old_flags = S.flags[e];
+        steps = S.steps[e];
+        gold_before = S.status[(size_t)e * 10 + 1];
+        if (!(steps > c.max_steps)) {  // state_impls.rs:52-54
+            act = decode_key(keys[e], dir);
+            if (act == ACT_INVALID) err = RG_FLAG_ERR_KEY;            // ErrorKind::InvalidInput
+            else if (old_flags & RG_FLAG_DEAD) err = RG_FLAG_ERR_DEAD; // Grave modal + InputCode::Act => IgnoredInput
+            else live = true;
+        }
+        if (live) load_env(S, E, e);
+    }
+    bool running = live && act != ACT_NOOP;
+    int iter = 0;
+    while (__any(running)) {
+        bool do_turn = false, need_bfs = false;
+        uint32_t rand_mask = 0; uint64_t rand_dir = 0; int map_slot = -1;
+        if (running) {
+            switch (act) {  // actions::process_action (actions.rs:16-65)
+            case ACT_DOWNSTAIR:
+                if ((E.cell[E.py * c.width + E.px] & C_SURF_MASK) == S_STAIR) {
+                    uint32_t non_empty = gen_level(S, c, E);
+                    place_player(S, c, E, non_empty);
+                    react |= R_REDRAW | R_STATUS | R_HIST_STALE;  // Redraw precedes StatusUpdated: history keeps the old level
+                } else react |= MSG_NO_DOWNSTAIR;
+                do_turn = true; running = false;
+                break;
+            case ACT_MOVE:
+                move_player(S, c, E, dir, react);
+                do_turn = true; running = false;
+                break;
+            case ACT_MOVE_UNTIL: {
+                bool done = move_player(S, c, E, dir, react);
+                uint32_t v = E.cell[E.py * c.width + E.px];
+                uint32_t tile = (v & C_VISIBLE) ? kGlyph[v & C_SURF_MASK] : ' ';
+                if (done || (tile != '.' && tile != '#')) running = false;  // stops without after_turn
+                else do_turn = true;
+                break;
+            }
+            case ACT_SEARCH:
+                do_search(c, E, react);
+                do_turn = true; running = false;
+                break;
+            }
+            if (do_turn) {  // actions::after_turn (actions.rs:67-80)
+                turn_passed(c, E, react);
+                if (E.mon_active > 0 && monsters_prepass(S, c, E, rand_mask, rand_dir))
+                    need_bfs = !dist_cache_lookup(S, E, POS(E.px, E.py), map_slot);
+            }
+        }
+        uint64_t m = __ballot(need_bfs);
+        while (m) {  // serve the requesting lanes one at a time with the whole wave
+            int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            int env_s = __shfl(e, src), tx = __shfl(E.px, src), ty = __shfl(E.py, src), sl = __shfl(map_slot, src);
+            bfs_service(S, c, sh, env_s, tx, ty, sl, lane);
+        }
+        if (do_turn && E.mon_active > 0) {
+            ui_dead = monsters_move(S, c, E, rand_mask, rand_dir, map_slot, react);  // `ui` of the LAST after_turn wins (actions.rs:44-57)
+        } else if (do_turn) ui_dead = false;
+        if (++iter > RG_MAX_W + RG_MAX_H) running = false;
+    }
+    if (!valid) return;
+    if (err) {
+        S.flags[e] = (old_flags & ~RG_FLAG_ERR_MASK) | err;
+        S.reward[e] = 0.f;
+        atomicOr(err_any, err);
+        return;
+    }
+    if (!live) { S.reward[e] = 0.f; return; }  // steps > max_steps: silent no-op
+
+    // GameStateImpl::react's reaction loop (state_impls.rs:56-78)
+    uint32_t flags = (react & 0x7f00u);                       // message flags of this key only
+    if (react & R_REDRAW) flags |= RG_FLAG_REDRAW | ((react & R_HIST_STALE) ? RG_FLAG_HIST_STALE : 0);
+    else flags |= old_flags & (RG_FLAG_REDRAW | RG_FLAG_HIST_STALE);
+    if (react & R_STATUS) write_status(S, c, E);
+    if (ui_dead) flags |= RG_FLAG_DEAD;
+    steps += 1;
+    bool terminal = (react & R_GRAVE) || steps >= c.max_steps;
+    if (terminal && c.auto_reset) {  // ThreadConductor::step (thread_impls.rs:69-79)
+        build_env(S, c, E);
+        write_status(S, c, E);
+        steps = 0;
+        flags = RG_FLAG_REDRAW;
+    }
+    if (terminal) flags |= RG_FLAG_TERMINAL;
+    store_env(S, E);
+    S.steps[e] = steps;
+    S.flags[e] = flags;
+    int gold_after = S.status[(size_t)e * 10 + 1];
+    S.reward[e] = (float)(gold_after - gold_before > 0 ? gold_after - gold_before : 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_render: RunTime::draw_screen (core/src/lib.rs:264-285; rogue/mod.rs:278-300,398-404) into the
+// PlayerState mirrors, only for envs whose last key produced Reaction::Redraw
+// ---------------------------------------------------------------------------------------------
+#define RENDER_THREADS 256
+__device__ __forceinline__ bool in_same_room(const RgState &S, const RgConfig &c, int e, int ax, int ay, int bx, int by) {
+    int id = room_id_of(c, ax, ay);  // Floor::in_same_room (floor.rs:381-393)
+    if (id < 0 || room_id_of(c, bx, by) != id) return false;
+    uint8_t meta = S.room_meta[id * S.n + e];
+    if ((meta & RM_KIND_MASK) == RK_EMPTY) return true;
+    int x0, y0, x1, y1;
+    unpack_rect(S.room_rect[id * S.n + e], x0, y0, x1, y1);
+    bool ina = ax >= x0 && ax < x1 && ay >= y0 && ay < y1, inb = bx >= x0 && bx < x1 && by >= y0 && by < y1;
+    return ina == inb;
+}
+
+__global__ void __launch_bounds__(RENDER_THREADS) k_render(RgState S, RgConfig c) {
+    __shared__ uint8_t s_scr[RG_MAX_W * RG_MAX_H];
+    __shared__ uint16_t s_cell_at[2 * RG_MAX_ROOMS];  // cell words under gold / monster overlays
+    const int tid = threadIdx.x, W = c.width, H = c.height, HW = W * H, n = S.n;
+    const int nrooms = c.room_num_x * c.room_num_y;
+    for (int e = blockIdx.x; e < n; e += gridDim.x) {
+        const uint32_t fl = S.flags[e];
+        if (!(fl & RG_FLAG_REDRAW)) continue;
+        const uint16_t *cell = S.cell + (size_t)e * HW;
+        const bool upd_hist = !(fl & RG_FLAG_HIST_STALE);
+        uint8_t *hist = S.hist + (size_t)e * HW;
+        for (int i = tid; i < HW; i += RENDER_THREADS) {
+            uint32_t v = cell[i];
+            int y = i / W;
+            uint8_t g = ' ';
+            if (y >= 1 && y < H - 1 && (v & C_VISIBLE)) g = kGlyph[v & C_SURF_MASK];
+            s_scr[i] = g;
+            if (upd_hist) hist[i] = (v & C_VISITED) ? 1 : 0;
+        }
+        __syncthreads();
+        const uint32_t ppos = S.p_pos[e];
+        const int px = POS_X(ppos), py = POS_Y(ppos);
+        // draw priority: player > gold > monster (core/src/lib.rs:271-283): lowest priority first
+        if (tid < nrooms) {
+            uint32_t w = S.mon_w0[tid * n + e];
+            if ((w >> 24) & MF_ALIVE) {
+                int x = POS_X(w), y = POS_Y(w);
+                uint32_t v = cell[y * W + x];
+                int dx = px - x, dy = py - y;
+                if ((v & (C_VISIBLE | C_DRAWN)) && y >= 1 && y < H - 1 && (dx * dx + dy * dy <= 2 || in_same_room(S, c, e, px, py, x, y)))
+                    s_scr[y * W + x] = (uint8_t)('A' + ((w >> 16) & 0xff));
+            }
+        }
+        __syncthreads();
+        if (tid < nrooms) {
+            uint32_t g = S.gold_pos[tid * n + e];
+            if (g & 0x10000u) {
+                int x = POS_X(g), y = POS_Y(g);
+                if ((cell[y * W + x] & (C_VISIBLE | C_DRAWN)) && y >= 1 && y < H - 1) s_scr[y * W + x] = '*';
+            }
+        }
+        __syncthreads();
+        if (tid == 0 && (cell[py * W + px] & (C_VISIBLE | C_DRAWN)) && py >= 1 && py < H - 1) s_scr[py * W + px] = '@';
+        __syncthreads();
+        uint8_t *scr = S.screen + (size_t)e * HW;
+        if ((HW & 3) == 0) {
+            uint32_t *d4 = reinterpret_cast<uint32_t *>(scr);
+            const uint32_t *s4 = reinterpret_cast<const uint32_t *>(s_scr);
+            for (int i = tid; i < HW / 4; i += RENDER_THREADS) d4[i] = s4[i];
+        } else
+            for (int i = tid; i < HW; i += RENDER_THREADS) scr[i] = s_scr[i];
+        if (tid == 0) S.flags[e] = fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE);
+        __syncthreads();
+    }
+    (void)s_cell_at;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gray / k_symbol: observation encode (python/src/lib.rs:72-111,162-205; flags.rs:88-115)
+// one thread = 4 consecutive cells of one env, all planes; float4 (16-byte) stores
+// ---------------------------------------------------------------------------------------------
+// StatusFlagInner bit b -> index into Status::to_vec
+__device__ __constant__ uint8_t kStatusIdx[9] = {0, 2, 3, 4, 5, 6, 7, 8, 9};
+
+__global__ void __launch_bounds__(256) k_gray(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status,
+                                              int n, int hw, int symbols, uint32_t sflag, int with_hist, float *__restrict__ out) {
+    const int q = hw >> 2;  // quads per env (hw % 4 == 0 checked on the host)
+    const size_t total = (size_t)n * q;
+    const int nplanes = 1 + __popc(sflag) + (with_hist ? 1 : 0);
+    const float fsym = (float)(uint8_t)symbols;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        int e = (int)(g / q), i = (int)(g - (size_t)e * q);
+        uint32_t s4 = reinterpret_cast<const uint32_t *>(screen + (size_t)e * hw)[i];
+        float4 v;
+        v.x = (float)(uint8_t)tile_to_sym(s4 & 0xff) / fsym;
+        v.y = (float)(uint8_t)tile_to_sym((s4 >> 8) & 0xff) / fsym;
+        v.z = (float)(uint8_t)tile_to_sym((s4 >> 16) & 0xff) / fsym;
+        v.w = (float)(uint8_t)tile_to_sym(s4 >> 24) / fsym;
+        float4 *o = reinterpret_cast<float4 *>(out + (size_t)e * nplanes * hw) + i;
+        o[0] = v;
+        int p = 1;
+        for (int b = 0; b < 9; b++)
+            if (sflag & (1u << b)) {
+                float f = (float)status[(size_t)e * 10 + kStatusIdx[b]];
+                float4 sv; sv.x = sv.y = sv.z = sv.w = f;
+                o[(size_t)p * q] = sv;
+                p++;
+            }
+        if (with_hist) {
+            uint32_t h4 = reinterpret_cast<const uint32_t *>(hist + (size_t)e * hw)[i];
+            float4 hv;
+            hv.x = (h4 & 0xff) ? 1.f : 0.f; hv.y = (h4 & 0xff00) ? 1.f : 0.f; hv.z = (h4 & 0xff0000) ? 1.f : 0.f; hv.w = (h4 >> 24) ? 1.f : 0.f;
+            o[(size_t)p * q] = hv;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_symbol(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status,
+                                                uint32_t *__restrict__ flags, uint32_t *__restrict__ err_any,
+                                                int n, int hw, int symbols, uint32_t sflag, int with_hist, float *__restrict__ out) {
+    const int q = hw >> 2;
+    const size_t total = (size_t)n * q;
+    const int nplanes = symbols + __popc(sflag) + (with_hist ? 1 : 0);
+    const uint32_t symbol_max = (uint32_t)symbols - 1;  // construct_symbol_map fills channels 0..symbols-2 (symbol.rs:51-71)
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        int e = (int)(g / q), i = (int)(g - (size_t)e * q);
+        uint32_t s4 = reinterpret_cast<const uint32_t *>(screen + (size_t)e * hw)[i];
+        uint32_t a = tile_to_sym(s4 & 0xff), b = tile_to_sym((s4 >> 8) & 0xff), cc = tile_to_sym((s4 >> 16) & 0xff), d = tile_to_sym(s4 >> 24);
+        if (a >= symbol_max || b >= symbol_max || cc >= symbol_max || d >= symbol_max) {  // InvalidTileError (e.g. 'Z')
+            if (flags) atomicOr(&flags[e], RG_FLAG_ERR_TILE);
+            atomicOr(err_any, RG_FLAG_ERR_TILE);
+        }
+        float4 *o = reinterpret_cast<float4 *>(out + (size_t)e * nplanes * hw) + i;
+        for (uint32_t ch = 0; ch < (uint32_t)symbols; ch++) {
+            float4 v;
+            v.x = a == ch ? 1.f : 0.f; v.y = b == ch ? 1.f : 0.f; v.z = cc == ch ? 1.f : 0.f; v.w = d == ch ? 1.f : 0.f;
+            if (ch >= symbol_max) v.x = v.y = v.z = v.w = 0.f;
+            o[(size_t)ch * q] = v;
+        }
+        int p = symbols;
+        for (int bb = 0; bb < 9; bb++)
+            if (sflag & (1u << bb)) {
+                float f = (float)status[(size_t)e * 10 + kStatusIdx[bb]];
+                float4 sv; sv.x = sv.y = sv.z = sv.w = f;
+                o[(size_t)p * q] = sv;
+                p++;
+            }
+        if (with_hist) {
+            uint32_t h4 = reinterpret_cast<const uint32_t *>(hist + (size_t)e * hw)[i];
+            float4 hv;
+            hv.x = (h4 & 0xff) ? 1.f : 0.f; hv.y = (h4 & 0xff00) ? 1.f : 0.f; hv.z = (h4 & 0xff0000) ? 1.f : 0.f; hv.w = (h4 >> 24) ? 1.f : 0.f;
+            o[(size_t)p * q] = hv;
+        }
+    }
+}
+
+// scalar fallbacks for H*W not divisible by 4 (never the case for the benchmark sizes)
+__global__ void __launch_bounds__(256) k_encode_scalar(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status,
+                                                       uint32_t *__restrict__ flags, uint32_t *__restrict__ err_any, int n, int hw, int symbols,
+                                                       uint32_t sflag, int with_hist, int kind, float *__restrict__ out) {
+    const size_t total = (size_t)n * hw;
+    const int base = kind ? symbols : 1;
+    const int nplanes = base + __popc(sflag) + (with_hist ? 1 : 0);
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        int e = (int)(g / hw), i = (int)(g - (size_t)e * hw);
+        uint32_t sym = tile_to_sym(screen[g]);
+        float *o = out + (size_t)e * nplanes * hw + i;
+        if (!kind) o[0] = (float)(uint8_t)sym / (float)(uint8_t)symbols;
+        else {
+            if (sym >= (uint32_t)symbols - 1) { if (flags) atomicOr(&flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
+            for (int ch = 0; ch < symbols; ch++) o[(size_t)ch * hw] = (sym == (uint32_t)ch && ch < symbols - 1) ? 1.f : 0.f;
+        }
+        int p = base;
+        for (int b = 0; b < 9; b++)
+            if (sflag & (1u << b)) { o[(size_t)p * hw] = (float)status[(size_t)e * 10 + kStatusIdx[b]]; p++; }
+        if (with_hist) o[(size_t)p * hw] = hist[g] ? 1.f : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-callable launchers (used by rg_api.cpp)
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
+    hipLaunchKernelGGL(k_build, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), 0, st, *S, *c);
+}
+void rgk_step(const RgState *S, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, hipStream_t st) {
+    hipLaunchKernelGGL(k_step, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), 0, st, *S, *c, keys, err_any);
+}
+void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st) {
+    int blocks = S->n < 8192 ? S->n : 8192;
+    hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RENDER_THREADS), 0, st, *S, *c);
+}
+void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, int symbols,
+                uint32_t sflag, int with_hist, int kind, float *out, hipStream_t st) {
+    if ((hw & 3) == 0) {
+        size_t total = (size_t)n * (hw >> 2);
+        int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+        if (blocks < 1) blocks = 1;
+        if (!kind) hipLaunchKernelGGL(k_gray, dim3(blocks), dim3(256), 0, st, screen, hist, status, n, hw, symbols, sflag, with_hist, out);
+        else hipLaunchKernelGGL(k_symbol, dim3(blocks), dim3(256), 0, st, screen, hist, status, flags, err_any, n, hw, symbols, sflag, with_hist, out);
+    } else {
+        size_t total = (size_t)n * hw;
+        int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+        hipLaunchKernelGGL(k_encode_scalar, dim3(blocks), dim3(256), 0, st, screen, hist, status, flags, err_any, n, hw, symbols, sflag, with_hist, kind, out);
+    }
+}
+}

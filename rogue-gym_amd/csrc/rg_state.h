@@ -1,0 +1,78 @@
+// rg_state.h -- HBM layout of the batched Rogue-Gym state (shared by kernels and the C-ABI host).
+//
+// One environment per lane; 64 environments share a wavefront.  Scalars and entity tables are
+// struct-of-arrays `[field][slot][env]` so a wavefront's loads of one field are one coalesced
+// transaction; tile grids are `[env][cell]` (u16 per cell) so an env's 3x3 neighbourhood sits in
+// <= 3 cache lines and the render / encode kernels stream rows with 16-byte accesses.
+#pragma once
+#include <cstdint>
+
+#include "rg_config.h"
+
+// ---- cell word (u16): surface | door | CellAttr | generator marks ----
+#define C_SURF_MASK 0x0007u   // Surface enum order, rogue/mod.rs:137-147
+#define C_DOOR      0x0008u   // member of Floor::doors (floor.rs:18)
+#define C_ATTR_SHIFT 4        // CellAttr bits (field.rs:107-124) live in bits 4..9
+#define C_VISITED   0x0010u
+#define C_HIDDEN    0x0020u
+#define C_VISIBLE   0x0040u
+#define C_DRAWN     0x0080u
+#define C_LOCKED    0x0100u
+#define C_DARK      0x0200u
+#define C_ATTR_MASK 0x03f0u
+#define C_MAZE      0x0400u   // maze.passages membership (maze.rs:12-15)
+#define C_GOLD      0x0800u   // Floor::items has an entry here (floor.rs:25)
+
+enum { S_PASSAGE = 0, S_FLOOR, S_WALLX, S_WALLY, S_STAIR, S_DOOR, S_TRAP, S_NONE };
+
+// room_meta bits
+#define RM_KIND_MASK 0x03u    // 0 normal, 1 maze, 2 empty (rooms.rs:11-19)
+#define RM_DARK      0x04u
+#define RM_VISITED   0x08u
+#define RM_HAS_GOLD  0x10u
+enum { RK_NORMAL = 0, RK_MAZE = 1, RK_EMPTY = 2 };
+
+// monster word 0: pos (x<<8|y, so the numeric order is the BTreeMap<[level,x,y]> order) | type<<16 | flags<<24
+#define MF_ALIVE   0x01u
+#define MF_ACTIVE  0x02u      // in active_enemies (and `running`)
+#define MF_PENDING 0x04u      // active and not yet moved this turn (still in the taken map, enemies.rs:376-380)
+
+#define RG_MAX_EDGES (RG_MAX_ROOMS + 16)
+#define RG_MAZE_STACK 512
+
+struct RgState {
+    int32_t n;          // environments on this device
+    int32_t hw;         // H*W
+    // grids
+    uint16_t *cell;     // [n][hw]
+    uint8_t *screen;    // [n][hw]   PlayerState.map mirror
+    uint8_t *hist;      // [n][hw]   PlayerState.history mirror
+    // player + runtime scalars [n]
+    uint16_t *p_pos;    // x<<8|y
+    int32_t *p_hp, *p_hpmax, *p_lvl;
+    uint32_t *p_exp, *food, *quiet, *pack_gold, *dlevel;
+    uint32_t *steps, *flags;
+    float *reward;
+    uint32_t *rng;      // [12][n]  dungeon{x,y,z,w}, item{..}, enemy{..}
+    uint64_t *seed_lo, *seed_hi;  // [n] seed used by the next build
+    uint8_t *reseed;    // [n] 1 = config has no seed: draw a fresh one for every build (core/src/lib.rs:157-165)
+    // rooms [RG_MAX_ROOMS][n]
+    uint32_t *room_rect;  // x0 | y0<<8 | x1<<16 | y1<<24 (half-open; Empty: x0,y0 = up_left)
+    uint8_t *room_meta;
+    // monsters [RG_MAX_ROOMS][n] (at most one spawn per room per level, floor.rs:106-130)
+    uint32_t *mon_w0;
+    int32_t *mon_hp;
+    uint32_t *mon_exp;
+    uint32_t *mon_cnt;  // [n] alive | active<<8
+    // gold [RG_MAX_ROOMS][n]: pos | 0x10000 when present; amounts
+    uint32_t *gold_pos, *gold_amt;
+    // generator scratch
+    uint32_t *edge_a, *edge_b;  // [RG_MAX_EDGES][n] corridor records, replayed for gen_attr (floor.rs:73-102)
+    uint16_t *maze_stack;       // [n][RG_MAZE_STACK]
+    // DistCache (rogue/mod.rs:492-518)
+    uint16_t *dc_map;   // [n][RG_DIST_SLOTS][hw], 0xFFFF = unreachable
+    uint16_t *dc_key;   // [RG_DIST_SLOTS][n] target pos
+    uint8_t *dc_head, *dc_len;  // [n] FIFO ring
+    // status mirror
+    int32_t *status;    // [n][10]
+};

@@ -1,0 +1,7 @@
+from .parallel import ParallelRogueEnv
+from .rogue_env import DungeonType, ImageSetting, PlayerState, RogueEnv, StatusFlag
+from .wrappers import FirstFloorEnv, StairRewardEnv, StairRewardParallel
+from .device import HipVecRogueEnv
+
+__all__ = ["ParallelRogueEnv", "DungeonType", "ImageSetting", "PlayerState", "RogueEnv", "StatusFlag", "FirstFloorEnv", "StairRewardEnv",
+           "StairRewardParallel", "HipVecRogueEnv"]
