@@ -102,6 +102,14 @@ int rg_fetch_states(rg_t *h, uint8_t *screen, uint8_t *hist, int32_t *status, ui
 int rg_encode_host(int device, const uint8_t *screen, const uint8_t *hist, const int32_t *status, int height, int width,
                    int symbols, uint32_t status_flag, int with_hist, int kind, float *out_host);
 
+/* Per-kernel timing with HIP events recorded on the handle's stream (bench.py's roofline leg).
+ * While enabled, every rg_step / render flush / rg_obs_* launch is bracketed by an event pair (up to
+ * 4096 launches per kernel between reads).  rg_timing_read synchronises, returns the summed elapsed
+ * milliseconds and launch counts per kernel {0: k_step, 1: k_render, 2: k_gray|k_symbol, 3: k_build}
+ * and clears the accumulators. */
+int rg_timing_enable(rg_t *h, int on);
+int rg_timing_read(rg_t *h, double ms[4], uint64_t launches[4]);
+
 /* GameState::dump_config (python/src/lib.rs:252-254): canonical JSON of env i's effective config. */
 int rg_dump_config(const rg_t *h, int env, char *buf, size_t cap);
 

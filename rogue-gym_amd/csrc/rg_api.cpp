@@ -33,6 +33,19 @@ struct rg_handle {
     std::vector<uint64_t> seed_lo, seed_hi;  // host copy of the seeds the next reset will use
     std::vector<uint8_t> reseed;
     std::string err;
+    // per-kernel HIP-event timing (rg_timing_*)
+    bool timing = false;
+    std::vector<hipEvent_t> ev[4];   // start/stop pairs
+    size_t ev_used[4] = {0, 0, 0, 0};
+};
+
+#define RG_TIMING_MAX 4096
+struct TimedLaunch {  // brackets one kernel launch with an event pair when timing is on
+    rg_handle *h; int k; bool on;
+    TimedLaunch(rg_handle *h_, int k_) : h(h_), k(k_), on(false) {
+        if (h->timing && h->ev_used[k] + 2 <= h->ev[k].size()) { on = true; (void)hipEventRecord(h->ev[k][h->ev_used[k]], h->stream); }
+    }
+    ~TimedLaunch() { if (on) { (void)hipEventRecord(h->ev[k][h->ev_used[k] + 1], h->stream); h->ev_used[k] += 2; } }
 };
 
 static thread_local std::string g_create_err;
@@ -65,7 +78,7 @@ static void free_all(rg_handle *h) {
 
 static int flush_render(rg_handle *h) {
     if (h->render_pending) {
-        rgk_render(&h->S, &h->cfg, h->stream);
+        { TimedLaunch t(h, 1); rgk_render(&h->S, &h->cfg, h->stream); }
         HIPCHK(h, hipGetLastError());
         h->render_pending = false;
     }
@@ -158,6 +171,7 @@ void rg_destroy(rg_t *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    for (int k = 0; k < 4; k++) for (auto &e : h->ev[k]) (void)hipEventDestroy(e);
     free_all(h);
     delete h;
 }
@@ -192,7 +206,7 @@ int rg_seed(rg_t *h, const uint64_t *seed_lo, const uint64_t *seed_hi, int n) {
 
 int rg_reset(rg_t *h) {
     HIPCHK(h, hipSetDevice(h->device));
-    rgk_build(&h->S, &h->cfg, h->stream);
+    { TimedLaunch t(h, 3); rgk_build(&h->S, &h->cfg, h->stream); }
     HIPCHK(h, hipGetLastError());
     h->render_pending = true;
     return 0;
@@ -206,7 +220,7 @@ int rg_step(rg_t *h, const uint8_t *keys, int keys_on_device) {
         HIPCHK(h, hipMemcpyAsync(h->d_keys, keys, (size_t)h->S.n, hipMemcpyHostToDevice, h->stream));
         dk = h->d_keys;
     }
-    rgk_step(&h->S, &h->cfg, dk, h->d_err, h->stream);
+    { TimedLaunch t(h, 0); rgk_step(&h->S, &h->cfg, dk, h->d_err, h->stream); }
     HIPCHK(h, hipGetLastError());
     h->render_pending = true;
     return 0;
@@ -240,8 +254,11 @@ int rg_obs_channels(const rg_t *h, int symbol, uint32_t status_flag, int with_hi
 static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, float *out_dev) {
     HIPCHK(h, hipSetDevice(h->device));
     if (flush_render(h)) return 1;
-    rgk_encode(h->S.screen, h->S.hist, h->S.status, h->S.flags, h->d_err, h->S.n, h->S.hw, h->cfg.symbols, status_flag & 0x1ffu, with_hist ? 1 : 0, kind,
-               out_dev, h->stream);
+    {
+        TimedLaunch t(h, 2);
+        rgk_encode(h->S.screen, h->S.hist, h->S.status, h->S.flags, h->d_err, h->S.n, h->S.hw, h->cfg.symbols, status_flag & 0x1ffu, with_hist ? 1 : 0, kind,
+                   out_dev, h->stream);
+    }
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -284,6 +301,35 @@ int rg_encode_host(int device, const uint8_t *screen, const uint8_t *hist, const
 done:
     (void)hipFree(d_scr); (void)hipFree(d_hist); (void)hipFree(d_st); (void)hipFree(d_err); (void)hipFree(d_out);
     return rc;
+}
+
+int rg_timing_enable(rg_t *h, int on) {
+    HIPCHK(h, hipSetDevice(h->device));
+    if (on && h->ev[0].empty())
+        for (int k = 0; k < 4; k++) {
+            h->ev[k].resize(2 * RG_TIMING_MAX);
+            for (auto &e : h->ev[k]) HIPCHK(h, hipEventCreate(&e));
+        }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < 4; k++) h->ev_used[k] = 0;
+    h->timing = on != 0;
+    return 0;
+}
+
+int rg_timing_read(rg_t *h, double ms[4], uint64_t launches[4]) {
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < 4; k++) {
+        double sum = 0;
+        for (size_t i = 0; i + 1 < h->ev_used[k]; i += 2) {
+            float t = 0;
+            HIPCHK(h, hipEventElapsedTime(&t, h->ev[k][i], h->ev[k][i + 1]));
+            sum += t;
+        }
+        ms[k] = sum; launches[k] = h->ev_used[k] / 2;
+        h->ev_used[k] = 0;
+    }
+    return 0;
 }
 
 int rg_dump_config(const rg_t *h, int env, char *buf, size_t cap) {

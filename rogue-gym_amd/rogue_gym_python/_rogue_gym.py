@@ -49,6 +49,13 @@ def load_library():
             "librogue_gym_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or rogue-gym_amd/csrc/build.sh -- there is no CPU fallback." % _SO
         )
+    try:
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same soname, libamdhip64.so.7).
+        # Importing torch first makes the dynamic loader satisfy our NEEDED entry with that copy; loading ours
+        # first would put two runtimes in the process and the second one sees no GPU.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_SO)
     vp, u8p, i32p, u32p, f32p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_float)
     L.rg_create.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(vp)]
@@ -72,10 +79,12 @@ def load_library():
     L.rg_obs_channels.argtypes = [vp, C.c_int, C.c_uint32, C.c_int]
     L.rg_fetch_states.argtypes = [vp, vp, vp, vp, vp]
     L.rg_encode_host.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, vp]
+    L.rg_timing_enable.argtypes = [vp, C.c_int]
+    L.rg_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rg_dump_config.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
     L.rg_debug_fetch.argtypes = [vp, C.c_int, C.POINTER(RgDebugState), vp]
     for f in ("rg_create", "rg_dims", "rg_set_stream", "rg_seed", "rg_reset", "rg_step", "rg_sync", "rg_screen", "rg_hist", "rg_status", "rg_flags",
-              "rg_reward", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_dump_config", "rg_debug_fetch"):
+              "rg_reward", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_dump_config", "rg_debug_fetch", "rg_timing_enable", "rg_timing_read"):
         getattr(L, f).restype = C.c_int
     _ = (u8p, i32p, u32p, f32p)
     _lib = L
