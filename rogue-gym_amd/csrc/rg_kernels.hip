@@ -90,13 +90,26 @@ __device__ __forceinline__ uint64_t range64(Rng &r, uint64_t low, uint64_t high)
 __device__ __forceinline__ bool does_happen(Rng &r, uint32_t p_inv) { return range32(r, 0, p_inv) == 0; }
 __device__ __forceinline__ bool parcent(Rng &r, uint32_t p) { return range32(r, 1, 101) <= p; }
 
+// optional phase profile: lane 0 of every wave folds its elapsed cycles per phase into S.prof (max and sum)
+struct Prof {
+    unsigned long long *p; unsigned long long t;
+    __device__ __forceinline__ void start(unsigned long long *pp) { p = pp; if (p) t = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void mark(int phase) {
+        if (!p) return;
+        unsigned long long now = __builtin_amdgcn_s_memtime();
+        if (threadIdx.x == 0) { atomicMax(&p[phase], now - t); atomicAdd(&p[32 + phase], now - t); }
+        t = now;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // per-lane environment view
 // ---------------------------------------------------------------------------------------------
 struct Env {
     int e;              // env index
     int n;              // env count (SoA stride)
-    uint16_t *cell;     // this env's grid
+    uint16_t *cell;     // this env's grid: global memory, or the LDS staging copy while a level is generated
+    uint16_t *gcell;    // this env's grid in global memory
     Rng rd, ri, re;     // dungeon / item / enemy streams
     int px, py;
     int hp, hpmax, plvl;
@@ -178,7 +191,7 @@ __device__ __forceinline__ bool blocked_for(const RgState &S, const Env &E, int 
 __device__ __forceinline__ uint32_t lev_add_of(const RgConfig &c, uint32_t level) { return c.amulet_level < level ? level - c.amulet_level : 0; }
 
 // EnemyHandler::activate_area (enemies.rs:342-362): wake MEAN sleepers inside room `rid`'s assigned area
-__device__ void activate_room(const RgState &S, const RgConfig &c, Env &E, int rid) {
+__device__ __forceinline__ void activate_room(const RgState &S, const RgConfig &c, Env &E, int rid) {
     if (E.mon_alive == E.mon_active) return;
     int nrooms = c.room_num_x * c.room_num_y;
     for (int s = 0; s < nrooms; s++) {
@@ -195,7 +208,7 @@ __device__ void activate_room(const RgState &S, const RgConfig &c, Env &E, int r
 // ---------------------------------------------------------------------------------------------
 // field-of-view (floor.rs:201-312)
 // ---------------------------------------------------------------------------------------------
-__device__ void player_in(const RgState &S, const RgConfig &c, Env &E, int x, int y, bool init) {
+__device__ __forceinline__ void player_in(const RgState &S, const RgConfig &c, Env &E, int x, int y, bool init) {
     uint16_t *cell = E.cell;
     int W = c.width;
     uint32_t here = cell[y * W + x];
@@ -226,7 +239,7 @@ __device__ void player_in(const RgState &S, const RgConfig &c, Env &E, int x, in
         cell[cy * W + cx] = v | C_DRAWN | C_VISIBLE;
     }
 }
-__device__ void player_out(const RgState &S, const RgConfig &c, Env &E, int x, int y) {
+__device__ __forceinline__ void player_out(const RgState &S, const RgConfig &c, Env &E, int x, int y) {
     uint16_t *cell = E.cell;
     int W = c.width;
     if (cell[y * W + x] & C_DOOR) {  // Floor::leaves_room (floor.rs:249-261)
@@ -256,7 +269,7 @@ __device__ void player_out(const RgState &S, const RgConfig &c, Env &E, int x, i
 // free-cell selection.  The reference keeps a FenwickSet per room; only `nth` over "members minus a
 // handful of filled cells" is ever observed during level creation, so the set is
 // implicit: interior cells (Normal) or C_MAZE cells (Maze) in row-major order, minus `excl`.
-__device__ bool room_select(const RgState &S, const RgConfig &c, Env &E, int rid, uint32_t excl /* pos or ~0u */, uint32_t &out) {
+__device__ __forceinline__ bool room_select(const RgState &S, const RgConfig &c, Env &E, int rid, uint32_t excl /* pos or ~0u */, uint32_t &out) {
     uint8_t meta = S.room_meta[rid * E.n + E.e];
     int kind = meta & RM_KIND_MASK;
     if (kind == RK_EMPTY) return false;
@@ -293,7 +306,7 @@ __device__ __forceinline__ int nth_bit(uint32_t m, int nth) {
     return __ffs((int)m) - 1;
 }
 // Floor::select_cell (floor.rs:333-346)
-__device__ bool floor_select(const RgState &S, const RgConfig &c, Env &E, uint32_t non_empty, int mode /*0 stair, 1 player*/, uint32_t &out) {
+__device__ __forceinline__ bool floor_select(const RgState &S, const RgConfig &c, Env &E, uint32_t non_empty, int mode /*0 stair, 1 player*/, uint32_t &out) {
     uint32_t cand = non_empty;
     while (cand) {
         int idx = nth_bit(cand, (int)range64(E.rd, 0, (uint64_t)__popc(cand)));
@@ -325,7 +338,7 @@ __device__ __forceinline__ void register_cell(const RgConfig &c, Env &E, int x, 
 }
 
 // select_start_or_end (passages.rs:143-179).  dir: 0 Up 1 Down 2 Left 3 Right
-__device__ uint32_t select_door(const RgState &S, const RgConfig &c, Env &E, int rid, int dir) {
+__device__ __forceinline__ uint32_t select_door(const RgState &S, const RgConfig &c, Env &E, int rid, int dir) {
     uint8_t meta = S.room_meta[rid * E.n + E.e];
     int kind = meta & RM_KIND_MASK;
     int x0, y0, x1, y1;
@@ -369,7 +382,7 @@ __device__ uint32_t select_door(const RgState &S, const RgConfig &c, Env &E, int
 
 // connect_2rooms (passages.rs:84-133): draws the two doors and the bend now, records the corridor for
 // the deferred gen_attr pass (the reference collects Positioned<Surface> in a Vec, floor.rs:73-86)
-__device__ void connect_rooms(const RgState &S, const RgConfig &c, Env &E, int r1, int r2, int dir, int &n_edges) {
+__device__ __forceinline__ void connect_rooms(const RgState &S, const RgConfig &c, Env &E, int r1, int r2, int dir, int &n_edges) {
     if (dir == 0 || dir == 2) { int t = r1; r1 = r2; r2 = t; dir ^= 1; }
     uint32_t s = select_door(S, c, E, r1, dir);
     uint32_t t = select_door(S, c, E, r2, dir ^ 1);
@@ -385,7 +398,7 @@ __device__ void connect_rooms(const RgState &S, const RgConfig &c, Env &E, int r
     }
 }
 // replay one recorded corridor in registration order (passages.rs:98-132 + floor.rs:87-101)
-__device__ void paint_corridor(const RgConfig &c, Env &E, uint32_t a, uint32_t b, uint32_t level) {
+__device__ __forceinline__ void paint_corridor(const RgConfig &c, Env &E, uint32_t a, uint32_t b, uint32_t level) {
     int sx = POS_X(a), sy = POS_Y(a), ex = POS_X(a >> 16), ey = POS_Y(a >> 16);
     int bend = b & 0xff;
     bool down = (b >> 8) & 1;
@@ -404,7 +417,7 @@ __device__ void paint_corridor(const RgConfig &c, Env &E, uint32_t a, uint32_t b
 }
 
 // select_candidate (passages.rs:69-82): reservoir over grid-neighbour rooms in ascending id
-__device__ int select_candidate(const RgConfig &c, Env &E, int nrooms, int node, uint32_t excl_mask, int &dir_out) {
+__device__ __forceinline__ int select_candidate(const RgConfig &c, Env &E, int nrooms, int node, uint32_t excl_mask, int &dir_out) {
     int rnx = c.room_num_x, rny = c.room_num_y;
     int nx0 = node % rnx, ny0 = node / rnx, res = -1, i = 0;
     for (int id = 0; id < nrooms; id++) {
@@ -423,7 +436,7 @@ __device__ int select_candidate(const RgConfig &c, Env &E, int nrooms, int node,
 }
 
 // dig_maze (maze.rs:38-89) with an explicit stack (the reference recurses; same visiting and draw order)
-__device__ void dig_maze(const RgState &S, const RgConfig &c, Env &E, int x0, int y0, int x1, int y1) {
+__device__ __forceinline__ void dig_maze(const RgState &S, const RgConfig &c, Env &E, int x0, int y0, int x1, int y1) {
     uint16_t *stk = S.maze_stack + (size_t)E.e * RG_MAZE_STACK;
     int W = c.width, sp = 0;
     E.cell[y0 * W + x0] |= C_MAZE;
@@ -445,7 +458,7 @@ __device__ void dig_maze(const RgState &S, const RgConfig &c, Env &E, int x0, in
 }
 
 // Dungeon::new_level_ (rogue/mod.rs:434-481).  Returns the bitmask of non-empty rooms.
-__device__ __noinline__ uint32_t gen_level(const RgState &S, const RgConfig &c, Env &E) {
+__device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &c, Env &E, Prof &pf) {
     const int W = c.width, H = c.height, HW = W * H, n = E.n, e = E.e;
     const int rnx = c.room_num_x, nrooms = rnx * c.room_num_y;
     uint16_t *cell = E.cell;
@@ -465,6 +478,7 @@ __device__ __noinline__ uint32_t gen_level(const RgState &S, const RgConfig &c, 
     }
     E.mon_alive = E.mon_active = 0;
 
+    pf.mark(8);
     // ---- gen_rooms (rooms.rs:165-211) ----
     uint32_t empty_num = range32(E.rd, 0, c.max_empty_rooms + 1);
     if (empty_num >= (uint32_t)nrooms) empty_num = nrooms - 1;
@@ -506,6 +520,7 @@ __device__ __noinline__ uint32_t gen_level(const RgState &S, const RgConfig &c, 
         S.room_rect[i * n + e] = rect;
         S.room_meta[i * n + e] = meta;
     }
+    pf.mark(9);
     // ---- paint rooms in id order (floor.rs:61-71; Room::draw rooms.rs:58-82) ----
     for (int i = 0; i < nrooms; i++) {
         uint8_t meta = S.room_meta[i * n + e];
@@ -530,6 +545,7 @@ __device__ __noinline__ uint32_t gen_level(const RgState &S, const RgConfig &c, 
                 }
         }
     }
+    pf.mark(10);
     // ---- dig_passges (passages.rs:16-67) ----
     int n_edges = 0;
     {
@@ -559,9 +575,11 @@ __device__ __noinline__ uint32_t gen_level(const RgState &S, const RgConfig &c, 
             }
         }
     }
+    pf.mark(11);
     for (int k = 0; k < n_edges; k++) paint_corridor(c, E, S.edge_a[k * n + e], S.edge_b[k * n + e], level);
 
     const uint32_t non_empty = (nrooms >= 32 ? 0xffffffffu : ((1u << nrooms) - 1u)) & ~empty_mask;
+    pf.mark(12);
     // ---- gold (floor.rs:132-153, item/gold.rs:18-24) ----
     for (int i = 0; i < nrooms; i++) {
         uint32_t pos;
@@ -573,6 +591,7 @@ __device__ __noinline__ uint32_t gen_level(const RgState &S, const RgConfig &c, 
         S.room_meta[i * n + e] |= RM_HAS_GOLD;
         cell[POS_Y(pos) * W + POS_X(pos)] |= C_GOLD;
     }
+    pf.mark(13);
     // ---- stair (floor.rs:156-167) ----
     {
         uint32_t pos;
@@ -581,6 +600,7 @@ __device__ __noinline__ uint32_t gen_level(const RgState &S, const RgConfig &c, 
             cell[POS_Y(pos) * W + POS_X(pos)] = (uint16_t)((v & ~C_SURF_MASK) | S_STAIR);
         }
     }
+    pf.mark(14);
     // ---- monsters (floor.rs:106-130, enemies.rs:265-320) ----
     if (c.n_enemies > 0) {
         uint32_t mn = level >= 4 ? level - 4 : 0, mx = level + 6;
@@ -605,6 +625,7 @@ __device__ __noinline__ uint32_t gen_level(const RgState &S, const RgConfig &c, 
             E.mon_alive++;
         }
     }
+    pf.mark(15);
     if (!c.hide_dungeon)
         for (int y = 1; y < H - 1; y++)
             for (int x = 0; x < W; x++) cell[y * W + x] |= C_VISIBLE;
@@ -612,15 +633,15 @@ __device__ __noinline__ uint32_t gen_level(const RgState &S, const RgConfig &c, 
 }
 
 // actions::new_level's tail (actions.rs:130-137): place the player and enter the room
-__device__ void place_player(const RgState &S, const RgConfig &c, Env &E, uint32_t non_empty) {
+__device__ __forceinline__ void place_player(const RgState &S, const RgConfig &c, Env &E, uint32_t non_empty) {
     uint32_t pos = 0;
     floor_select(S, c, E, non_empty, 1, pos);
     E.px = POS_X(pos); E.py = POS_Y(pos);
     player_in(S, c, E, E.px, E.py, true);
 }
 
-// GameConfig::build (core/src/lib.rs:193-228) + PlayerState::reset's status (python/src/lib.rs:52-58)
-__device__ void build_env(const RgState &S, const RgConfig &c, Env &E) {
+// GameConfig::build (core/src/lib.rs:193-228), split around the level generator
+__device__ __forceinline__ void build_prologue(const RgState &S, Env &E) {
     uint64_t lo = S.seed_lo[E.e], hi = S.seed_hi[E.e];
     if (S.reseed[E.e]) {  // `seed: None` => a new random seed per build; not parity-relevant, splitmix64 chain
         uint64_t z = lo + 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
@@ -629,13 +650,62 @@ __device__ void build_env(const RgState &S, const RgConfig &c, Env &E) {
     }
     rng_seed(E.ri, lo, hi); rng_seed(E.re, lo, hi); rng_seed(E.rd, lo, hi);
     E.dlevel = 0;
-    uint32_t non_empty = gen_level(S, c, E);
+}
+__device__ __forceinline__ void build_epilogue(const RgState &S, const RgConfig &c, Env &E) {
     // Player::init_items: mace 1..2, bow 1..2, arrow 8..17 on the item stream (weapon.rs:159,179-188)
     (void)range32(E.ri, 1, 2); (void)range32(E.ri, 1, 2); (void)range32(E.ri, 8, 17);
     E.hp = E.hpmax = c.init_hp; E.plvl = 1; E.exp = 0;
     E.food = c.hunger_time; E.quiet = 0; E.gold = 0;
-    place_player(S, c, E, non_empty);
     S.dc_len[E.e] = 0; S.dc_head[E.e] = 0;  // a rebuilt RunTime owns a fresh DistCache
+}
+
+// Level generation service.  Generating a level is a long chain of data-dependent, RNG-ordered tile
+// reads/writes; against global memory every one of them costs an HBM/L2 round trip with nothing to
+// hide it (one wave per SIMD).  So the lanes that need a new level (descent, auto-reset, build) stage
+// their grid in LDS: up to `nslots` lanes generate concurrently, each on its own LDS copy, then the whole
+// wave streams the finished grids to HBM with 16-byte stores.  is_build: GameConfig::build, else
+// Dungeon::new_level (rogue/mod.rs:434-481) followed by actions::new_level's player placement.
+__device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c, Env &E, int lane, int e, bool need, bool is_build,
+                                            uint16_t *lds_grid, int nslots, Prof &pf) {
+    const int HW = c.width * c.height;
+    uint64_t m = __ballot(need);
+    while (m) {
+        int rank = __popcll(m & ((1ull << lane) - 1ull));
+        bool mine = need && rank < nslots;
+        unsigned long long tg0 = pf.p ? __builtin_amdgcn_s_memtime() : 0;
+        if (mine) {
+            E.cell = lds_grid + (size_t)rank * HW;
+            if (is_build) build_prologue(S, E);
+            uint32_t non_empty = gen_level(S, c, E, pf);
+            if (is_build) build_epilogue(S, c, E);
+            place_player(S, c, E, non_empty);
+            E.cell = E.gcell;
+            need = false;
+        }
+        if (pf.p && lane == 0) {  // per-round generation time, by number of concurrently generating lanes
+            unsigned long long dt = __builtin_amdgcn_s_memtime() - tg0;
+            int k = __popcll(m) == 1 ? 20 : 22;
+            atomicMax(&pf.p[k], dt); atomicAdd(&pf.p[32 + k], dt); atomicAdd(&pf.p[32 + k + 1], 1ull);
+        }
+        pf.mark(16);
+        __syncthreads();
+        int served = __popcll(m);
+        if (served > nslots) served = nslots;
+        for (int r = 0; r < served; r++) {
+            int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            int env_s = __shfl(e, src);
+            uint16_t *dst = S.cell + (size_t)env_s * HW;
+            const uint16_t *srcp = lds_grid + (size_t)r * HW;
+            if ((HW & 7) == 0) {
+                uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+                const uint4 *s4 = reinterpret_cast<const uint4 *>(srcp);
+                for (int i = lane; i < HW / 8; i += WAVE) d4[i] = s4[i];
+            } else
+                for (int i = lane; i < HW; i += WAVE) dst[i] = srcp[i];
+        }
+        __syncthreads();
+    }
 }
 
 // RunTime::player_status (core/src/lib.rs:345-356, player.rs:107-118) -> mirror
@@ -650,7 +720,7 @@ __device__ __forceinline__ void write_status(const RgState &S, const RgConfig &c
 __device__ __forceinline__ void load_env(const RgState &S, Env &E, int e) {
     int n = S.n;
     E.e = e; E.n = n;
-    E.cell = S.cell + (size_t)e * S.hw;
+    E.cell = E.gcell = S.cell + (size_t)e * S.hw;
     E.rd = {S.rng[0 * n + e], S.rng[1 * n + e], S.rng[2 * n + e], S.rng[3 * n + e]};
     E.ri = {S.rng[4 * n + e], S.rng[5 * n + e], S.rng[6 * n + e], S.rng[7 * n + e]};
     E.re = {S.rng[8 * n + e], S.rng[9 * n + e], S.rng[10 * n + e], S.rng[11 * n + e]};
@@ -675,12 +745,17 @@ __device__ __forceinline__ void store_env(const RgState &S, const Env &E) {
 // ---------------------------------------------------------------------------------------------
 // k_build: (re)build every env from its seed
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
-    int e = blockIdx.x * WAVE + threadIdx.x;
-    if (e >= S.n) return;
+extern __shared__ __align__(16) uint8_t g_smem[];
+
+__global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c, int nslots) {
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x * WAVE + lane;
+    const bool valid = e < S.n;
     Env E;
-    E.e = e; E.n = S.n; E.cell = S.cell + (size_t)e * S.hw;
-    build_env(S, c, E);
+    E.e = valid ? e : 0; E.n = S.n; E.cell = E.gcell = S.cell + (size_t)E.e * S.hw;
+    Prof pf; pf.start(S.prof);
+    gen_service(S, c, E, lane, e, valid, true, reinterpret_cast<uint16_t *>(g_smem), nslots, pf);
+    if (!valid) return;
     store_env(S, E);
     write_status(S, c, E);
     S.steps[e] = 0;
@@ -692,87 +767,121 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
 // wave-cooperative bit-parallel BFS (Floor::make_dist_map, floor.rs:395-416)
 // ---------------------------------------------------------------------------------------------
 // The reference runs a FIFO BFS over 8 directions; the result is the exact unit-weight shortest
-// distance, so any level-synchronous formulation gives identical maps.  Here every grid row is a
-// bitmask (u64 words) in LDS; one level of the frontier expansion is a handful of shifts/ANDs per
-// row-word, with the diagonal rule of can_move_impl (both orthogonal neighbours walkable, floor.rs:
-// 177-180) expressed on the masks.  The 64 lanes of the wave serve one requesting env at a time.
-#define BFS_MAXWW 3                    // ceil(160 / 64)
-#define BFS_MAXT (RG_MAX_H * BFS_MAXWW)
-struct BfsShared {
-    uint64_t walk[BFS_MAXT], vis[BFS_MAXT], fr[2][BFS_MAXT];
-    uint16_t dist[RG_MAX_W * RG_MAX_H];
-};
+// distance, so any level-synchronous formulation gives identical maps.  Here lane y of the wave owns
+// grid row y as bitmasks held in registers (WW 64-bit words per row: walkable, visited, frontier).  One
+// BFS level = two cross-lane shuffles (the frontier of rows y-1 / y+1) plus a handful of shifts/ANDs;
+// the diagonal rule of can_move_impl (both orthogonal neighbours walkable, floor.rs:177-180) is
+// expressed on the masks.  No LDS traffic or barrier inside the level loop; distances are staged in LDS
+// and streamed to the env's DistCache slot with 16-byte stores.
+template <int WW> struct RowBits { uint64_t w[WW]; };
 
-__device__ __forceinline__ uint64_t row_word(const uint64_t *a, int y, int k, int H, int WW) {
-    return (y < 0 || y >= H || k < 0 || k >= WW) ? 0ull : a[y * WW + k];
+template <int WW> __device__ __forceinline__ RowBits<WW> rb_shl1(const RowBits<WW> &a) {  // cell x-1 -> x
+    RowBits<WW> r;
+#pragma unroll
+    for (int k = 0; k < WW; k++) r.w[k] = (a.w[k] << 1) | (k > 0 ? a.w[k - 1] >> 63 : 0ull);
+    return r;
 }
-// (a & b) of row y shifted one cell toward +x (shl) or -x (shr), with carries across 64-bit words
-__device__ __forceinline__ uint64_t and_shl(const uint64_t *a, int ya, const uint64_t *b, int yb, int k, int H, int WW) {
-    uint64_t cur = row_word(a, ya, k, H, WW) & row_word(b, yb, k, H, WW);
-    uint64_t prev = row_word(a, ya, k - 1, H, WW) & row_word(b, yb, k - 1, H, WW);
-    return (cur << 1) | (prev >> 63);
+template <int WW> __device__ __forceinline__ RowBits<WW> rb_shr1(const RowBits<WW> &a) {  // cell x+1 -> x
+    RowBits<WW> r;
+#pragma unroll
+    for (int k = 0; k < WW; k++) r.w[k] = (a.w[k] >> 1) | (k + 1 < WW ? a.w[k + 1] << 63 : 0ull);
+    return r;
 }
-__device__ __forceinline__ uint64_t and_shr(const uint64_t *a, int ya, const uint64_t *b, int yb, int k, int H, int WW) {
-    uint64_t cur = row_word(a, ya, k, H, WW) & row_word(b, yb, k, H, WW);
-    uint64_t next = row_word(a, ya, k + 1, H, WW) & row_word(b, yb, k + 1, H, WW);
-    return (cur >> 1) | (next << 63);
-}
-
-__device__ void bfs_service(const RgState &S, const RgConfig &c, BfsShared &sh, int env, int tx, int ty, int slot, int lane) {
-    const int W = c.width, H = c.height, HW = W * H, WW = (W + 63) >> 6, T = H * WW;
-    const uint16_t *cell = S.cell + (size_t)env * HW;
-    for (int y = 0; y < H; y++)
-        for (int k = 0; k < WW; k++) {
-            int x = k * 64 + lane;
-            bool wk = x < W && can_walk(cell[y * W + x]);
-            uint64_t m = __ballot(wk);
-            if (lane == 0) sh.walk[y * WW + k] = m;
-        }
-    for (int i = lane; i < HW; i += WAVE) sh.dist[i] = DIST_INF;
-    for (int t = lane; t < T; t += WAVE) { sh.vis[t] = 0; sh.fr[0][t] = 0; }
-    __syncthreads();
-    if (lane == 0) {
-        int t = ty * WW + (tx >> 6);
-        sh.vis[t] = 1ull << (tx & 63);
-        sh.fr[0][t] = 1ull << (tx & 63);
-        sh.dist[ty * W + tx] = 0;
+template <int WW> __device__ __forceinline__ RowBits<WW> rb_from_lane(const RowBits<WW> &a, int src_lane, bool ok) {
+    RowBits<WW> r;
+#pragma unroll
+    for (int k = 0; k < WW; k++) {
+        uint32_t lo = (uint32_t)__shfl((int)(uint32_t)a.w[k], src_lane), hi = (uint32_t)__shfl((int)(uint32_t)(a.w[k] >> 32), src_lane);
+        r.w[k] = ok ? (((uint64_t)hi << 32) | lo) : 0ull;
     }
-    __syncthreads();
-    int cur = 0;
-    for (uint32_t level = 1; level < (uint32_t)HW; level++) {
-        const uint64_t *F = sh.fr[cur];
-        uint64_t *NF = sh.fr[cur ^ 1];
-        bool any = false;
-        for (int t = lane; t < T; t += WAVE) {
-            int y = t / WW, k = t - y * WW;
-            uint64_t wk = sh.walk[t];
-            // same row: Left / Right
-            uint64_t tgt = and_shl(F, y, F, y, k, H, WW) | and_shr(F, y, F, y, k, H, WW);
-            // from the row above (moving Down) and below (moving Up): straight, then the two diagonals.
-            // source (x-+1, y') -> target (x, y) needs walk(x, y') and walk(x-+1, y) besides walk(x, y).
-            tgt |= row_word(F, y - 1, k, H, WW) | row_word(F, y + 1, k, H, WW);
-            tgt |= (and_shl(F, y - 1, sh.walk, y, k, H, WW) | and_shr(F, y - 1, sh.walk, y, k, H, WW)) & row_word(sh.walk, y - 1, k, H, WW);
-            tgt |= (and_shl(F, y + 1, sh.walk, y, k, H, WW) | and_shr(F, y + 1, sh.walk, y, k, H, WW)) & row_word(sh.walk, y + 1, k, H, WW);
-            uint64_t nw = tgt & wk & ~sh.vis[t];
-            NF[t] = nw;
-            if (nw) {
-                sh.vis[t] |= nw;
-                any = true;
-                uint64_t b = nw;
-                while (b) {
-                    int bit = __ffsll((long long)b) - 1;
-                    b &= b - 1;
-                    sh.dist[y * W + k * 64 + bit] = (uint16_t)level;
+    return r;
+}
+
+template <int WW>
+__device__ __forceinline__ void bfs_rows(const RgState &S, const RgConfig &c, uint16_t *lds_dist, int env, int tx, int ty, int slot, int lane) {
+    const int W = c.width, H = c.height, HW = W * H;
+    const uint16_t *cell = S.cell + (size_t)env * HW;
+    const bool row_ok = lane < H;
+    RowBits<WW> wk, vis, fr;
+#pragma unroll
+    for (int k = 0; k < WW; k++) wk.w[k] = vis.w[k] = fr.w[k] = 0ull;
+    if (row_ok) {  // walkable mask of my row (Surface::can_walk, rogue/mod.rs:175-182)
+        const uint16_t *row = cell + lane * W;
+        if ((W & 7) == 0) {
+            const uint4 *r4 = reinterpret_cast<const uint4 *>(row);
+            for (int j = 0; j < W / 8; j++) {
+                uint4 v = r4[j];
+                uint32_t q[4] = {v.x, v.y, v.z, v.w};
+                uint32_t bits = 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    bits |= (uint32_t)can_walk(q[t] & 0xffff) << (2 * t);
+                    bits |= (uint32_t)can_walk(q[t] >> 16) << (2 * t + 1);
                 }
+                int x = j * 8;
+#pragma unroll
+                for (int k = 0; k < WW; k++)
+                    if ((x >> 6) == k) wk.w[k] |= (uint64_t)bits << (x & 63);
+            }
+        } else {
+            for (int x = 0; x < W; x++) {
+                uint64_t b = (uint64_t)can_walk(row[x]) << (x & 63);
+#pragma unroll
+                for (int k = 0; k < WW; k++)
+                    if ((x >> 6) == k) wk.w[k] |= b;
             }
         }
-        __syncthreads();
-        if (!__any(any)) break;
-        cur ^= 1;
     }
-    uint16_t *out = S.dc_map + ((size_t)env * RG_DIST_SLOTS + slot) * HW;
-    for (int i = lane; i < HW; i += WAVE) out[i] = sh.dist[i];
+    const RowBits<WW> wu = rb_from_lane<WW>(wk, lane - 1, lane > 0);       // walkable mask of row y-1
+    const RowBits<WW> wd = rb_from_lane<WW>(wk, lane + 1, lane + 1 < H);   // and of row y+1
+    for (int i = lane; i < HW; i += WAVE) lds_dist[i] = DIST_INF;
+    if (lane == ty) {
+#pragma unroll
+        for (int k = 0; k < WW; k++)
+            if ((tx >> 6) == k) { fr.w[k] = 1ull << (tx & 63); vis.w[k] = fr.w[k]; }
+    }
     __syncthreads();
+    if (lane == ty) lds_dist[ty * W + tx] = 0;
+    for (uint32_t level = 1; level < (uint32_t)HW; level++) {
+        const RowBits<WW> fu = rb_from_lane<WW>(fr, lane - 1, lane > 0);
+        const RowBits<WW> fd = rb_from_lane<WW>(fr, lane + 1, lane + 1 < H);
+        RowBits<WW> au, ad;  // frontier of the neighbour row restricted to cells whose vertical step lands on a walkable cell of my row
+#pragma unroll
+        for (int k = 0; k < WW; k++) { au.w[k] = fu.w[k] & wk.w[k]; ad.w[k] = fd.w[k] & wk.w[k]; }
+        const RowBits<WW> sl = rb_shl1<WW>(fr), sr = rb_shr1<WW>(fr);
+        const RowBits<WW> aul = rb_shl1<WW>(au), aur = rb_shr1<WW>(au), adl = rb_shl1<WW>(ad), adr = rb_shr1<WW>(ad);
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < WW; k++) {
+            // Left/Right | Down/Up | diagonals: source (x-+1, y-+1) needs walk(x, y-+1) and walk(x-+1, y)
+            uint64_t tgt = sl.w[k] | sr.w[k] | fu.w[k] | fd.w[k] | ((aul.w[k] | aur.w[k]) & wu.w[k]) | ((adl.w[k] | adr.w[k]) & wd.w[k]);
+            uint64_t nw = tgt & wk.w[k] & ~vis.w[k];
+            vis.w[k] |= nw;
+            fr.w[k] = nw;
+            any = any || nw != 0;
+            while (nw) {
+                int bit = __ffsll((long long)nw) - 1;
+                nw &= nw - 1;
+                lds_dist[lane * W + k * 64 + bit] = (uint16_t)level;
+            }
+        }
+        if (!__any(any)) break;
+    }
+    __syncthreads();
+    uint16_t *out = S.dc_map + ((size_t)env * RG_DIST_SLOTS + slot) * HW;
+    if ((HW & 7) == 0) {
+        uint4 *o4 = reinterpret_cast<uint4 *>(out);
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(lds_dist);
+        for (int i = lane; i < HW / 8; i += WAVE) o4[i] = s4[i];
+    } else
+        for (int i = lane; i < HW; i += WAVE) out[i] = lds_dist[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void bfs_service(const RgState &S, const RgConfig &c, uint16_t *lds_dist, int env, int tx, int ty, int slot, int lane) {
+    if (c.width <= 64) bfs_rows<1>(S, c, lds_dist, env, tx, ty, slot, lane);
+    else if (c.width <= 128) bfs_rows<2>(S, c, lds_dist, env, tx, ty, slot, lane);
+    else bfs_rows<3>(S, c, lds_dist, env, tx, ty, slot, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -814,7 +923,7 @@ __device__ __forceinline__ uint32_t attack_rate(int64_t level, int64_t armor, in
 }
 
 // Player::level_up (player.rs:185-197, 345-352)
-__device__ bool level_up(const RgConfig &c, Env &E, uint32_t exp) {
+__device__ __forceinline__ bool level_up(const RgConfig &c, Env &E, uint32_t exp) {
     E.exp += exp;
     int cur = E.plvl - 1, diff = 0;
     if (cur >= c.n_level_exps) return false;
@@ -829,7 +938,7 @@ __device__ bool level_up(const RgConfig &c, Env &E, uint32_t exp) {
 
 // actions::player_attack + fight::player_attack (actions.rs:140-166, fight.rs:6-39):
 // mace 2d4 hit+1 dam+1, strength 16 => +0/+0; the monster is always `running` by the time of the roll
-__device__ void player_attack(const RgState &S, const RgConfig &c, Env &E, int slot, uint32_t &react) {
+__device__ __forceinline__ void player_attack(const RgState &S, const RgConfig &c, Env &E, int slot, uint32_t &react) {
     int idx = slot * E.n + E.e;
     uint32_t w = S.mon_w0[idx];
     E.quiet = 0;
@@ -853,7 +962,7 @@ __device__ void player_attack(const RgState &S, const RgConfig &c, Env &E, int s
 }
 
 // actions::move_player + get_item (actions.rs:168-231); returns `done`
-__device__ bool move_player(const RgState &S, const RgConfig &c, Env &E, int d, uint32_t &react) {
+__device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c, Env &E, int d, uint32_t &react) {
     const int nrooms = c.room_num_x * c.room_num_y;
     if (!can_move(c, E.cell, E.px, E.py, d, false)) return true;  // Notify(CantMove): no mirror effect
     int nx = E.px + kDX[d], ny = E.py + kDY[d];
@@ -877,7 +986,7 @@ __device__ bool move_player(const RgState &S, const RgConfig &c, Env &E, int d, 
 }
 
 // Floor::search (floor.rs:349-370)
-__device__ void do_search(const RgConfig &c, Env &E, uint32_t &react) {
+__device__ __forceinline__ void do_search(const RgConfig &c, Env &E, uint32_t &react) {
     for (int d = 0; d < 8; d++) {
         int x = E.px + kDX[d], y = E.py + kDY[d];
         if (!in_bounds(c, x, y)) continue;
@@ -894,7 +1003,7 @@ __device__ void do_search(const RgConfig &c, Env &E, uint32_t &react) {
 }
 
 // Player::turn_passed + heal (player.rs:163-176,221-240)
-__device__ void turn_passed(const RgConfig &c, Env &E, uint32_t &react) {
+__device__ __forceinline__ void turn_passed(const RgConfig &c, Env &E, uint32_t &react) {
     E.food -= 1;  // u32: wraps in release builds
     if (E.food == 0) return;  // [PlayerEvent::Dead], ignored by after_turn (actions.rs:75)
     uint32_t hunger = c.hunger_time / 10;
@@ -927,7 +1036,7 @@ __device__ __forceinline__ int next_pending(const RgState &S, const Env &E, int 
 
 // EnemyHandler::move_actives, RNG part (enemies.rs:399-404, rogue/mod.rs:383): the per-monster draws do not
 // depend on positions, so they are taken first (same per-stream order) to learn whether a dist map is needed.
-__device__ bool monsters_prepass(const RgState &S, const RgConfig &c, Env &E, uint32_t &rand_mask, uint64_t &rand_dir) {
+__device__ __forceinline__ bool monsters_prepass(const RgState &S, const RgConfig &c, Env &E, uint32_t &rand_mask, uint64_t &rand_dir) {
     const int nrooms = c.room_num_x * c.room_num_y;
     rand_mask = 0; rand_dir = 0;
     for (int s = 0; s < nrooms; s++) {  // the taken map: every active monster is pending
@@ -950,7 +1059,7 @@ __device__ bool monsters_prepass(const RgState &S, const RgConfig &c, Env &E, ui
 }
 
 // DistCache::make_dist_map lookup (rogue/mod.rs:504-517): FIFO ring of 9 maps keyed by target coord only
-__device__ bool dist_cache_lookup(const RgState &S, const Env &E, uint32_t key, int &slot) {
+__device__ __forceinline__ bool dist_cache_lookup(const RgState &S, const Env &E, uint32_t key, int &slot) {
     int len = S.dc_len[E.e], head = S.dc_head[E.e];
     for (int i = 0; i < len; i++) {
         int idx = head + i; if (idx >= RG_DIST_SLOTS) idx -= RG_DIST_SLOTS;
@@ -964,7 +1073,7 @@ __device__ bool dist_cache_lookup(const RgState &S, const Env &E, uint32_t key, 
 
 // EnemyHandler::move_actives moves + actions::move_active_enemies attacks
 // (enemies.rs:366-424, rogue/mod.rs:339-397, actions.rs:82-119, fight.rs:41-72)
-__device__ bool monsters_move(const RgState &S, const RgConfig &c, Env &E, uint32_t rand_mask, uint64_t rand_dir, int map_slot, uint32_t &react) {
+__device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &c, Env &E, uint32_t rand_mask, uint64_t rand_dir, int map_slot, uint32_t &react) {
     const int nrooms = c.room_num_x * c.room_num_y, W = c.width, n = E.n, e = E.e;
     const uint16_t *dist = S.dc_map + ((size_t)e * RG_DIST_SLOTS + (map_slot < 0 ? 0 : map_slot)) * S.hw;
     const uint32_t ppos = POS(E.px, E.py);
@@ -1033,17 +1142,18 @@ __device__ bool monsters_move(const RgState &S, const RgConfig &c, Env &E, uint3
 // ---------------------------------------------------------------------------------------------
 // k_step: one key for every env
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WAVE) k_step(RgState S, RgConfig c, const uint8_t *__restrict__ keys, uint32_t *__restrict__ err_any) {
-    __shared__ BfsShared sh;
+__global__ void __launch_bounds__(WAVE) k_step(RgState S, RgConfig c, const uint8_t *__restrict__ keys, uint32_t *__restrict__ err_any, int nslots) {
+    uint16_t *lds_grid = reinterpret_cast<uint16_t *>(g_smem);
     const int lane = threadIdx.x;
     const int e = blockIdx.x * WAVE + lane;
     const bool valid = e < S.n;
+    Prof pf0; pf0.start(S.prof);
     Env E;
-    uint32_t react = 0, err = 0, old_flags = 0, steps = 0;
+    uint32_t react = 0, err = 0, old_flags = 0, steps = 0, flags = 0;
     int act = ACT_NOOP, dir = 0;
     int gold_before = 0;
     bool live = false;   // this lane processes a key this call
-    bool ui_dead = false;
+    bool ui_dead = false, terminal = false;
     if (valid) {
         old_flags = S.flags[e];
         steps = S.steps[e];
@@ -1056,56 +1166,85 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgConfig c, const uint
         }
         if (live) load_env(S, E, e);
     }
-    bool running = live && act != ACT_NOOP;
-    int iter = 0;
-    while (__any(running)) {
-        bool do_turn = false, need_bfs = false;
-        uint32_t rand_mask = 0; uint64_t rand_dir = 0; int map_slot = -1;
-        if (running) {
-            switch (act) {  // actions::process_action (actions.rs:16-65)
-            case ACT_DOWNSTAIR:
-                if ((E.cell[E.py * c.width + E.px] & C_SURF_MASK) == S_STAIR) {
-                    uint32_t non_empty = gen_level(S, c, E);
-                    place_player(S, c, E, non_empty);
-                    react |= R_REDRAW | R_STATUS | R_HIST_STALE;  // Redraw precedes StatusUpdated: history keeps the old level
-                } else react |= MSG_NO_DOWNSTAIR;
-                do_turn = true; running = false;
-                break;
-            case ACT_MOVE:
-                move_player(S, c, E, dir, react);
-                do_turn = true; running = false;
-                break;
-            case ACT_MOVE_UNTIL: {
-                bool done = move_player(S, c, E, dir, react);
-                uint32_t v = E.cell[E.py * c.width + E.px];
-                uint32_t tile = (v & C_VISIBLE) ? kGlyph[v & C_SURF_MASK] : ' ';
-                if (done || (tile != '.' && tile != '#')) running = false;  // stops without after_turn
-                else do_turn = true;
-                break;
-            }
-            case ACT_SEARCH:
-                do_search(c, E, react);
-                do_turn = true; running = false;
-                break;
-            }
-            if (do_turn) {  // actions::after_turn (actions.rs:67-80)
-                turn_passed(c, E, react);
-                if (E.mon_active > 0 && monsters_prepass(S, c, E, rand_mask, rand_dir))
-                    need_bfs = !dist_cache_lookup(S, E, POS(E.px, E.py), map_slot);
-            }
-        }
-        uint64_t m = __ballot(need_bfs);
-        while (m) {  // serve the requesting lanes one at a time with the whole wave
-            int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            int env_s = __shfl(e, src), tx = __shfl(E.px, src), ty = __shfl(E.py, src), sl = __shfl(map_slot, src);
-            bfs_service(S, c, sh, env_s, tx, ty, sl, lane);
-        }
-        if (do_turn && E.mon_active > 0) {
-            ui_dead = monsters_move(S, c, E, rand_mask, rand_dir, map_slot, react);  // `ui` of the LAST after_turn wins (actions.rs:44-57)
-        } else if (do_turn) ui_dead = false;
-        if (++iter > RG_MAX_W + RG_MAX_H) running = false;
+    // Action::DownStair (actions.rs:27-36): the new level is produced by the generation service below
+    pf0.mark(0);
+    Prof pf; pf.start(S.prof);
+    bool need_gen = false;
+    if (live && act == ACT_DOWNSTAIR) {
+        if ((E.cell[E.py * c.width + E.px] & C_SURF_MASK) == S_STAIR) {
+            need_gen = true;
+            react |= R_REDRAW | R_STATUS | R_HIST_STALE;  // Redraw precedes StatusUpdated: history keeps the old level
+        } else react |= MSG_NO_DOWNSTAIR;
     }
+#pragma nounroll
+    for (int pass = 0; pass < 2; ++pass) {
+        // pass 0: levels for descending lanes; pass 1: rebuilds for terminal lanes (ThreadConductor auto-reset)
+        pf.mark(1);
+        gen_service(S, c, E, lane, e, need_gen, pass == 1, lds_grid, nslots, pf);
+        pf.mark(2);
+        need_gen = false;
+        if (pass == 1) break;
+
+        bool running = live && act != ACT_NOOP;
+        int iter = 0;
+        while (__any(running)) {
+            bool do_turn = false, need_bfs = false;
+            uint32_t rand_mask = 0; uint64_t rand_dir = 0; int map_slot = -1;
+            if (running) {
+                switch (act) {  // actions::process_action (actions.rs:16-65)
+                case ACT_DOWNSTAIR:
+                    do_turn = true; running = false;
+                    break;
+                case ACT_MOVE:
+                case ACT_MOVE_UNTIL: {
+                    bool done = move_player(S, c, E, dir, react);
+                    if (act == ACT_MOVE) { do_turn = true; running = false; break; }
+                    uint32_t v = E.cell[E.py * c.width + E.px];
+                    uint32_t tile = (v & C_VISIBLE) ? kGlyph[v & C_SURF_MASK] : ' ';
+                    if (done || (tile != '.' && tile != '#')) running = false;  // MoveUntil stops without after_turn
+                    else do_turn = true;
+                    break;
+                }
+                case ACT_SEARCH:
+                    do_search(c, E, react);
+                    do_turn = true; running = false;
+                    break;
+                }
+                if (do_turn) {  // actions::after_turn (actions.rs:67-80)
+                    turn_passed(c, E, react);
+                    if (E.mon_active > 0 && monsters_prepass(S, c, E, rand_mask, rand_dir))
+                        need_bfs = !dist_cache_lookup(S, E, POS(E.px, E.py), map_slot);
+                }
+            }
+            pf.mark(3);
+            uint64_t m = __ballot(need_bfs);
+            while (m) {  // serve the requesting lanes one at a time with the whole wave
+                int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                int env_s = __shfl(e, src), tx = __shfl(E.px, src), ty = __shfl(E.py, src), sl = __shfl(map_slot, src);
+                unsigned long long tb0 = pf.p ? __builtin_amdgcn_s_memtime() : 0;
+                bfs_service(S, c, lds_grid, env_s, tx, ty, sl, lane);
+                if (pf.p && lane == 0) { unsigned long long dt = __builtin_amdgcn_s_memtime() - tb0; atomicMax(&pf.p[24], dt); atomicAdd(&pf.p[32 + 24], dt); atomicAdd(&pf.p[32 + 25], 1ull); }
+            }
+            pf.mark(4);
+            if (do_turn && E.mon_active > 0) ui_dead = monsters_move(S, c, E, rand_mask, rand_dir, map_slot, react);  // `ui` of the LAST after_turn wins
+            else if (do_turn) ui_dead = false;
+            pf.mark(5);
+            if (++iter > RG_MAX_W + RG_MAX_H) running = false;
+        }
+        if (live) {
+            // GameStateImpl::react's reaction loop (state_impls.rs:56-78)
+            flags = (react & 0x7f00u);                       // message flags of this key only
+            if (react & R_REDRAW) flags |= RG_FLAG_REDRAW | ((react & R_HIST_STALE) ? RG_FLAG_HIST_STALE : 0);
+            else flags |= old_flags & (RG_FLAG_REDRAW | RG_FLAG_HIST_STALE);
+            if (react & R_STATUS) write_status(S, c, E);
+            if (ui_dead) flags |= RG_FLAG_DEAD;
+            steps += 1;
+            terminal = (react & R_GRAVE) || steps >= c.max_steps;
+            need_gen = terminal && c.auto_reset;  // ThreadConductor::step (thread_impls.rs:69-79)
+        }
+    }
+    pf.mark(6);
     if (!valid) return;
     if (err) {
         S.flags[e] = (old_flags & ~RG_FLAG_ERR_MASK) | err;
@@ -1114,17 +1253,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgConfig c, const uint
         return;
     }
     if (!live) { S.reward[e] = 0.f; return; }  // steps > max_steps: silent no-op
-
-    // GameStateImpl::react's reaction loop (state_impls.rs:56-78)
-    uint32_t flags = (react & 0x7f00u);                       // message flags of this key only
-    if (react & R_REDRAW) flags |= RG_FLAG_REDRAW | ((react & R_HIST_STALE) ? RG_FLAG_HIST_STALE : 0);
-    else flags |= old_flags & (RG_FLAG_REDRAW | RG_FLAG_HIST_STALE);
-    if (react & R_STATUS) write_status(S, c, E);
-    if (ui_dead) flags |= RG_FLAG_DEAD;
-    steps += 1;
-    bool terminal = (react & R_GRAVE) || steps >= c.max_steps;
-    if (terminal && c.auto_reset) {  // ThreadConductor::step (thread_impls.rs:69-79)
-        build_env(S, c, E);
+    if (terminal && c.auto_reset) {
         write_status(S, c, E);
         steps = 0;
         flags = RG_FLAG_REDRAW;
@@ -1316,11 +1445,23 @@ __global__ void __launch_bounds__(256) k_encode_scalar(const uint8_t *__restrict
 // host-callable launchers (used by rg_api.cpp)
 // ---------------------------------------------------------------------------------------------
 extern "C" {
+static int gen_slots(int hw, int budget_bytes) {
+    int n = budget_bytes / (hw * 2);
+    return n < 1 ? 1 : (n > WAVE ? WAVE : n);
+}
+static size_t bfs_bytes(const RgConfig *c) { return (size_t)c->width * c->height * 2; }
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
-    hipLaunchKernelGGL(k_build, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), 0, st, *S, *c);
+    int hw = c->width * c->height;
+    int ns = gen_slots(hw, 64 * 1024);
+    size_t smem = (size_t)ns * hw * 2;
+    hipLaunchKernelGGL(k_build, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *c, ns);
 }
 void rgk_step(const RgState *S, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, hipStream_t st) {
-    hipLaunchKernelGGL(k_step, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), 0, st, *S, *c, keys, err_any);
+    int hw = c->width * c->height;
+    int ns = gen_slots(hw, 32 * 1024);
+    size_t smem = (size_t)ns * hw * 2;
+    if (bfs_bytes(c) > smem) smem = bfs_bytes(c);
+    hipLaunchKernelGGL(k_step, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *c, keys, err_any, ns);
 }
 void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st) {
     int blocks = S->n < 8192 ? S->n : 8192;

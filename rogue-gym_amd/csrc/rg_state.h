@@ -73,6 +73,8 @@ struct RgState {
     uint16_t *dc_map;   // [n][RG_DIST_SLOTS][hw], 0xFFFF = unreachable
     uint16_t *dc_key;   // [RG_DIST_SLOTS][n] target pos
     uint8_t *dc_head, *dc_len;  // [n] FIFO ring
+    // optional in-kernel phase profile (development aid): [2][32] u64 = {max cycles, sum cycles} per phase, NULL = off
+    unsigned long long *prof;
     // status mirror
     int32_t *status;    // [n][10]
 };

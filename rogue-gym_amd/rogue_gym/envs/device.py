@@ -100,11 +100,10 @@ class HipVecRogueEnv:
             out = torch.empty((ws * self.num_envs,) + tuple(self.obs.shape[1:]), dtype=self.obs.dtype, device=self.device)
             dist.all_gather_into_tensor(out, self.obs)
             return out
-        scr = torch.empty((ws * self.num_envs, self.height, self.width), dtype=torch.uint8, device=self.device)
-        st = torch.empty((ws * self.num_envs, 10), dtype=torch.int32, device=self.device)
-        dist.all_gather_into_tensor(scr, self.screen)
-        dist.all_gather_into_tensor(st, self.status)
-        return scr, st
+        from .sharding import all_gather_compact
+
+        _ = ws
+        return all_gather_compact(self.screen, self.status)
 
     def close(self):
         self._h.close()

@@ -1,0 +1,90 @@
+"""World-size-2 gloo test of the N>1 path on CPU: env sharding arithmetic + the compact observation
+all-gather + consumer-side gray expansion.  Each rank steps its shard with the CPU oracle (stand-in for the
+per-rank HIP stepper, which needs a GPU); rank 0 checks the gathered batch against a single-process run."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_total, steps, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "rogue-gym_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.pyoracle import OracleEnv
+    from rogue_gym.envs.sharding import all_gather_compact, expand_gray, shard_range
+
+    cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_goldens.json")))["configs"]["mini"]
+    first, last = shard_range(n_total, rank, world)
+    envs = [OracleEnv(cfg, seed=i, max_steps=20) for i in range(first, last)]
+    acts = np.frombuffer(b".hjklnbuy>s", np.uint8)
+    rng = np.random.RandomState(0)
+    for _ in range(steps):
+        keys = acts[rng.randint(0, 11, n_total)]  # same global action tensor on every rank
+        for j, e in enumerate(envs):
+            e.step_autoreset(int(keys[first + j]))
+    screen = torch.from_numpy(np.stack([e.screen() for e in envs]))
+    status = torch.from_numpy(np.stack([e.status_arr().astype(np.int32) for e in envs]))
+    scr, st = all_gather_compact(screen, status)
+    gray = expand_gray(scr, 43)
+    if rank == 0:
+        q.put((scr.numpy(), st.numpy(), gray.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_ranges_partition():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "rogue-gym_amd"))
+    from rogue_gym.envs.sharding import shard_range
+    for n, w in [(65536, 8), (262144, 8), (10000, 8), (7, 2), (64, 1)]:
+        r = [shard_range(n, i, w) for i in range(w)]
+        assert r[0][0] == 0 and r[-1][1] == n
+        assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+    assert shard_range(10000, 3, 8) == (3750, 5000)  # BASELINE config 5: 1 250 envs per GPU
+
+
+@pytest.mark.timeout(120)
+def test_world2_gloo_gather_matches_single_process():
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle.pyoracle import OracleEnv
+    n_total, steps, world = 24, 30, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    scr, st, gray = q.get(timeout=100)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_goldens.json")))["configs"]["mini"]
+    envs = [OracleEnv(cfg, seed=i, max_steps=20) for i in range(n_total)]
+    acts = np.frombuffer(b".hjklnbuy>s", np.uint8)
+    rng = np.random.RandomState(0)
+    for _ in range(steps):
+        keys = acts[rng.randint(0, 11, n_total)]
+        for i, e in enumerate(envs):
+            e.step_autoreset(int(keys[i]))
+    for i, e in enumerate(envs):
+        assert np.array_equal(scr[i], e.screen())
+        assert np.array_equal(st[i], e.status_arr().astype(np.int32))
+        assert np.array_equal(gray[i], e.gray_image(0))

@@ -144,8 +144,8 @@ def test_dead_single_env_raises(goldens):
     for seed in range(40):
         env = e.RogueEnv(config_dict=dict(goldens["configs"]["mini"]), seed=seed, max_steps=100000)
         done = False
-        for _ in range(400):
-            _, _, done, _ = env.step("hjklyubn"[rng.randint(8)] * 8)
+        for _ in range(3000):
+            _, _, done, _ = env.step("hjklyubn"[rng.randint(8)])
             if done:
                 break
         if done:
