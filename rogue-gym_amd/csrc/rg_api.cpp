@@ -18,6 +18,7 @@ void rgk_step(const RgState *S, const RgConfig *c, const uint8_t *keys, uint32_t
 void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st);
 void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, int symbols,
                 uint32_t sflag, int with_hist, int kind, float *out, hipStream_t st);
+int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, hipStream_t st);
 }
 
 struct rg_handle {
@@ -253,6 +254,15 @@ int rg_obs_channels(const rg_t *h, int symbol, uint32_t status_flag, int with_hi
 
 static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, float *out_dev) {
     HIPCHK(h, hipSetDevice(h->device));
+    {   // steady state: one fused pass refreshes the mirrors of Redraw envs and encodes every env
+        TimedLaunch t(h, 2);
+        if (rgk_obs(&h->S, &h->cfg, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->d_err, h->stream)) {
+            HIPCHK(h, hipGetLastError());
+            h->render_pending = false;
+            return 0;
+        }
+        t.on = false;
+    }
     if (flush_render(h)) return 1;
     {
         TimedLaunch t(h, 2);

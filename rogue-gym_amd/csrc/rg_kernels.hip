@@ -1418,6 +1418,143 @@ __global__ void __launch_bounds__(256) k_symbol(const uint8_t *__restrict__ scre
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_obs: fused mirror refresh + observation encode (the steady-state path: one pass per step)
+// ---------------------------------------------------------------------------------------------
+// For every env: if the last key produced a Redraw, draw the screen from the tile words (+ entity
+// overlays) and refresh the screen / history mirrors; otherwise re-read the 1-byte-per-cell mirror.  The
+// screen is staged in LDS, then encoded straight into the caller's f32 tensor with float4 stores.
+// HBM traffic per env-step (mini gray): 1 KB tiles (Redraw envs) or 0.5 KB mirror read, 0.5 KB mirror
+// write (Redraw envs), 2 KB observation write.  A block of 256 threads serves `epb` envs, `tpe` threads each;
+// a thread owns 8 consecutive cells (one 16-byte tile load, two float4 stores per plane).
+#define OBS_THREADS 256
+template <int KIND>
+__global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint32_t sflag, int with_hist, float *__restrict__ out,
+                                                    uint32_t *__restrict__ err_any, int tpe, int epb) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    float *lutf = reinterpret_cast<float *>(smem);        // glyph -> gray value (KIND 0)
+    uint8_t *luts = smem + 512;                            // glyph -> symbol id
+    uint8_t *screens = smem + 512 + 128;                   // epb x HW staged screens
+    const int tid = threadIdx.x, W = c.width, H = c.height, HW = W * H, n = S.n, Q8 = HW >> 3;
+    const int nrooms = c.room_num_x * c.room_num_y;
+    const int symbols = c.symbols;
+    if (tid < 128) {
+        uint32_t sy = tile_to_sym((uint32_t)tid);
+        luts[tid] = (uint8_t)sy;
+        lutf[tid] = (float)(uint8_t)sy / (float)(uint8_t)symbols;  // python/src/lib.rs:84 (same single division)
+    }
+    const int le = tid / tpe, lt = tid - le * tpe;
+    const int base_planes = KIND ? symbols : 1;
+    const int nplanes = base_planes + __popc(sflag) + (with_hist ? 1 : 0);
+    uint8_t *scr = screens + (size_t)le * HW;
+    for (int base = blockIdx.x * epb; base < n; base += gridDim.x * epb) {
+        const int e = base + le;
+        const bool valid = le < epb && e < n;
+        uint32_t fl = 0;
+        bool redraw = false;
+        if (valid) { fl = S.flags[e]; redraw = fl & RG_FLAG_REDRAW; }
+        __syncthreads();  // LUTs ready / previous iteration's LDS reads done
+        if (valid) {
+            if (redraw) {
+                const uint4 *cell4 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW);
+                const bool upd_hist = !(fl & RG_FLAG_HIST_STALE);
+                uint2 *hist8 = reinterpret_cast<uint2 *>(S.hist + (size_t)e * HW);
+                for (int i = lt; i < Q8; i += tpe) {
+                    uint4 v = cell4[i];
+                    uint32_t q[4] = {v.x, v.y, v.z, v.w};
+                    uint32_t g[2] = {0, 0}, hb[2] = {0, 0};
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        uint32_t cw = (q[t >> 1] >> ((t & 1) * 16)) & 0xffff;
+                        int idx = i * 8 + t;
+                        uint32_t gl = ' ';
+                        if (idx >= W && idx < HW - W && (cw & C_VISIBLE)) gl = kGlyph[cw & C_SURF_MASK];  // rows 1..H-2 only (rogue/mod.rs:278-290)
+                        g[t >> 2] |= gl << ((t & 3) * 8);
+                        hb[t >> 2] |= ((cw & C_VISITED) ? 1u : 0u) << ((t & 3) * 8);
+                    }
+                    reinterpret_cast<uint2 *>(scr)[i] = make_uint2(g[0], g[1]);
+                    if (upd_hist) hist8[i] = make_uint2(hb[0], hb[1]);
+                }
+            } else {
+                const uint2 *m8 = reinterpret_cast<const uint2 *>(S.screen + (size_t)e * HW);
+                for (int i = lt; i < Q8; i += tpe) reinterpret_cast<uint2 *>(scr)[i] = m8[i];
+            }
+        }
+        __syncthreads();
+        // entity overlays, lowest draw priority first: monster < gold < player (core/src/lib.rs:271-283)
+        uint32_t ppos = 0;
+        if (valid && redraw) ppos = S.p_pos[e];
+        const int px = POS_X(ppos), py = POS_Y(ppos);
+        if (valid && redraw && lt < nrooms) {
+            uint32_t w = S.mon_w0[lt * n + e];
+            if ((w >> 24) & MF_ALIVE) {
+                int x = POS_X(w), y = POS_Y(w);
+                uint32_t v = S.cell[(size_t)e * HW + y * W + x];
+                int dx = px - x, dy = py - y;
+                if ((v & (C_VISIBLE | C_DRAWN)) && y >= 1 && y < H - 1 && (dx * dx + dy * dy <= 2 || in_same_room(S, c, e, px, py, x, y)))
+                    scr[y * W + x] = (uint8_t)('A' + ((w >> 16) & 0xff));
+            }
+        }
+        __syncthreads();
+        if (valid && redraw && lt < nrooms) {
+            uint32_t g = S.gold_pos[lt * n + e];
+            if (g & 0x10000u) {
+                int x = POS_X(g), y = POS_Y(g);
+                if ((S.cell[(size_t)e * HW + y * W + x] & (C_VISIBLE | C_DRAWN)) && y >= 1 && y < H - 1) scr[y * W + x] = '*';
+            }
+        }
+        __syncthreads();
+        if (valid && redraw && lt == 0 && (S.cell[(size_t)e * HW + py * W + px] & (C_VISIBLE | C_DRAWN)) && py >= 1 && py < H - 1) scr[py * W + px] = '@';
+        __syncthreads();
+        if (valid) {
+            uint2 *m8 = reinterpret_cast<uint2 *>(S.screen + (size_t)e * HW);
+            float4 *o = reinterpret_cast<float4 *>(out + (size_t)e * nplanes * HW);
+            const int q4 = HW >> 2;
+            bool bad = false;
+            for (int i = lt; i < Q8; i += tpe) {
+                uint2 g = reinterpret_cast<const uint2 *>(scr)[i];
+                if (redraw) m8[i] = g;
+                uint32_t gg[2] = {g.x, g.y};
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    uint32_t b0 = gg[half] & 0x7f, b1 = (gg[half] >> 8) & 0x7f, b2 = (gg[half] >> 16) & 0x7f, b3 = (gg[half] >> 24) & 0x7f;
+                    if (KIND == 0) {
+                        float4 v; v.x = lutf[b0]; v.y = lutf[b1]; v.z = lutf[b2]; v.w = lutf[b3];
+                        o[2 * i + half] = v;
+                    } else {
+                        uint32_t s0 = luts[b0], s1 = luts[b1], s2 = luts[b2], s3 = luts[b3];
+                        uint32_t smax = (uint32_t)symbols - 1;  // construct_symbol_map fills channels 0..symbols-2 (symbol.rs:51-71)
+                        bad = bad || s0 >= smax || s1 >= smax || s2 >= smax || s3 >= smax;
+                        for (uint32_t ch = 0; ch < (uint32_t)symbols; ch++) {
+                            float4 v;
+                            v.x = s0 == ch ? 1.f : 0.f; v.y = s1 == ch ? 1.f : 0.f; v.z = s2 == ch ? 1.f : 0.f; v.w = s3 == ch ? 1.f : 0.f;
+                            if (ch >= smax) v.x = v.y = v.z = v.w = 0.f;
+                            o[(size_t)ch * q4 + 2 * i + half] = v;
+                        }
+                    }
+                }
+                int p = base_planes;
+                for (int b = 0; b < 9; b++)
+                    if (sflag & (1u << b)) {
+                        float f = (float)S.status[(size_t)e * 10 + kStatusIdx[b]];
+                        float4 sv; sv.x = sv.y = sv.z = sv.w = f;
+                        o[(size_t)p * q4 + 2 * i] = sv; o[(size_t)p * q4 + 2 * i + 1] = sv;
+                        p++;
+                    }
+                if (with_hist) {
+                    uint2 h8 = reinterpret_cast<const uint2 *>(S.hist + (size_t)e * HW)[i];
+                    float4 a, b2;
+                    a.x = (h8.x & 0xff) ? 1.f : 0.f; a.y = (h8.x & 0xff00) ? 1.f : 0.f; a.z = (h8.x & 0xff0000) ? 1.f : 0.f; a.w = (h8.x >> 24) ? 1.f : 0.f;
+                    b2.x = (h8.y & 0xff) ? 1.f : 0.f; b2.y = (h8.y & 0xff00) ? 1.f : 0.f; b2.z = (h8.y & 0xff0000) ? 1.f : 0.f; b2.w = (h8.y >> 24) ? 1.f : 0.f;
+                    o[(size_t)p * q4 + 2 * i] = a; o[(size_t)p * q4 + 2 * i + 1] = b2;
+                }
+            }
+            if (KIND == 1 && bad) { atomicOr(&S.flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
+            if (redraw && lt == 0) S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE)) | (KIND == 1 && bad ? RG_FLAG_ERR_TILE : 0);
+        }
+    }
+}
+
 // scalar fallbacks for H*W not divisible by 4 (never the case for the benchmark sizes)
 __global__ void __launch_bounds__(256) k_encode_scalar(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status,
                                                        uint32_t *__restrict__ flags, uint32_t *__restrict__ err_any, int n, int hw, int symbols,
@@ -1466,6 +1603,21 @@ void rgk_step(const RgState *S, const RgConfig *c, const uint8_t *keys, uint32_t
 void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st) {
     int blocks = S->n < 8192 ? S->n : 8192;
     hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RENDER_THREADS), 0, st, *S, *c);
+}
+// fused mirror refresh + encode; returns 0 if the geometry is not supported (caller falls back to k_render + encode)
+int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, hipStream_t st) {
+    int hw = c->width * c->height;
+    if (hw & 7) return 0;
+    int q8 = hw / 8;
+    int tpe = q8 >= OBS_THREADS ? OBS_THREADS : ((q8 + 63) / 64) * 64;  // threads per env: a whole number of waves
+    if (tpe > OBS_THREADS) tpe = OBS_THREADS;
+    int epb = OBS_THREADS / tpe;
+    size_t smem = 512 + 128 + (size_t)epb * hw;
+    int blocks = (S->n + epb - 1) / epb;
+    if (blocks > 32768) blocks = 32768;
+    if (!kind) hipLaunchKernelGGL(k_obs<0>, dim3(blocks), dim3(OBS_THREADS), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb);
+    else hipLaunchKernelGGL(k_obs<1>, dim3(blocks), dim3(OBS_THREADS), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb);
+    return 1;
 }
 void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, int symbols,
                 uint32_t sflag, int with_hist, int kind, float *out, hipStream_t st) {
