@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <string>
@@ -14,7 +15,8 @@
 
 extern "C" {
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st);
-void rgk_step(const RgState *S, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, hipStream_t st);
+void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, int use_spares, hipStream_t st);
+void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st);
 void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st);
 void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, int symbols,
                 uint32_t sflag, int with_hist, int kind, float *out, hipStream_t st);
@@ -25,6 +27,11 @@ struct rg_handle {
     RgParsed parsed;             // config of env 0 (all envs agree except for the seed)
     RgConfig cfg;
     RgState S;
+    RgState SP;                  // spare view: core pointers address the pre-generated next level-1 state (k_regen)
+    bool spares = false;
+    uint64_t step_count = 0;
+    hipStream_t side = nullptr;  // stream of the background generator (high priority: a low-priority queue starves behind the back-to-back step kernels)
+    hipEvent_t ev_step = nullptr, ev_regen = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
@@ -155,6 +162,24 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
               dev_alloc(h, &S.dc_map, h->cfg.n_enemies > 0 ? n * RG_DIST_SLOTS * hw : 16) && dev_alloc(h, &S.dc_key, RG_DIST_SLOTS * n) &&
               dev_alloc(h, &S.dc_head, n) && dev_alloc(h, &S.dc_len, n) && dev_alloc(h, &S.status, n * 10) &&
               dev_alloc(h, &h->d_err, 4) && dev_alloc(h, &h->d_keys, n);
+    ok = ok && dev_alloc(h, &S.sp_ready, n);
+    h->SP = S;
+    h->spares = auto_reset != 0 && getenv("ROGUE_GYM_HIP_NO_SPARES") == nullptr;
+    if (ok && h->spares) {
+        RgState &P = h->SP;
+        ok = dev_alloc(h, &P.cell, n * hw) && dev_alloc(h, &P.p_pos, n) && dev_alloc(h, &P.p_hp, n) && dev_alloc(h, &P.p_hpmax, n) && dev_alloc(h, &P.p_lvl, n) &&
+             dev_alloc(h, &P.p_exp, n) && dev_alloc(h, &P.food, n) && dev_alloc(h, &P.quiet, n) && dev_alloc(h, &P.pack_gold, n) && dev_alloc(h, &P.dlevel, n) &&
+             dev_alloc(h, &P.rng, 12 * n) && dev_alloc(h, &P.room_rect, RG_MAX_ROOMS * n) && dev_alloc(h, &P.room_meta, RG_MAX_ROOMS * n) &&
+             dev_alloc(h, &P.mon_w0, RG_MAX_ROOMS * n) && dev_alloc(h, &P.mon_hp, RG_MAX_ROOMS * n) && dev_alloc(h, &P.mon_exp, RG_MAX_ROOMS * n) &&
+             dev_alloc(h, &P.mon_cnt, n) && dev_alloc(h, &P.gold_pos, RG_MAX_ROOMS * n) && dev_alloc(h, &P.gold_amt, RG_MAX_ROOMS * n) &&
+             dev_alloc(h, &P.edge_a, RG_MAX_EDGES * n) && dev_alloc(h, &P.edge_b, RG_MAX_EDGES * n) && dev_alloc(h, &P.maze_stack, RG_MAZE_STACK * n);
+        P.prof = nullptr;
+        int lo = 0, hi = 0;
+        if (ok && (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, getenv("ROGUE_GYM_HIP_SIDE_LOWPRIO") ? lo : hi) != hipSuccess ||
+                   hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_regen, hipEventDisableTiming) != hipSuccess)) {
+            h->err = "failed to create the background generation stream"; ok = false;
+        }
+    }
     if (!ok) { g_create_err = h->err; free_all(h); delete h; return 1; }
     // screen rows 0 and H-1 are never drawn: PlayerState::new fills the map with b' ' (python/src/lib.rs:41-50)
     if (hipMemset(S.screen, ' ', n * hw) != hipSuccess) { g_create_err = "hipMemset failed"; free_all(h); delete h; return 1; }
@@ -164,6 +189,10 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { g_create_err = std::string("k_build: ") + hipGetErrorString(e); free_all(h); delete h; return 1; }
     h->render_pending = true;
+    if (h->spares) {  // first spares: generated in the background right away
+        rgk_regen(&h->SP, &h->cfg, h->side);
+        (void)hipEventRecord(h->ev_regen, h->side);
+    }
     *out = h;
     return 0;
 }
@@ -172,6 +201,9 @@ void rg_destroy(rg_t *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+    if (h->ev_step) (void)hipEventDestroy(h->ev_step);
+    if (h->ev_regen) (void)hipEventDestroy(h->ev_regen);
     for (int k = 0; k < 4; k++) for (auto &e : h->ev[k]) (void)hipEventDestroy(e);
     free_all(h);
     delete h;
@@ -187,6 +219,7 @@ int rg_dims(const rg_t *h, int *height, int *width, int *symbols, int *n_env) {
 
 int rg_set_stream(rg_t *h, void *hip_stream) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
     h->stream = (hipStream_t)hip_stream;
     return 0;
 }
@@ -195,6 +228,7 @@ int rg_seed(rg_t *h, const uint64_t *seed_lo, const uint64_t *seed_hi, int n) {
     if (n > h->S.n) n = h->S.n;
     HIPCHK(h, hipSetDevice(h->device));
     // envs without a configured seed advance their seed on the device at every build: keep those values
+    if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
     std::vector<uint64_t> lo(h->S.n), hi(h->S.n);
     HIPCHK(h, hipMemcpyAsync(lo.data(), h->S.seed_lo, (size_t)h->S.n * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(hi.data(), h->S.seed_hi, (size_t)h->S.n * 8, hipMemcpyDeviceToHost, h->stream));
@@ -202,6 +236,10 @@ int rg_seed(rg_t *h, const uint64_t *seed_lo, const uint64_t *seed_hi, int n) {
     for (int i = 0; i < h->S.n; i++)
         if (h->reseed[i]) { h->seed_lo[i] = lo[i]; h->seed_hi[i] = hi[i]; }
     for (int i = 0; i < n; i++) { h->seed_lo[i] = seed_lo[i]; h->seed_hi[i] = seed_hi ? seed_hi[i] : 0; h->reseed[i] = 0; }
+    if (h->spares) {  // spares were generated from the old seeds: drop them (k_step falls back to inline generation until refilled)
+        HIPCHK(h, hipStreamSynchronize(h->side));
+        HIPCHK(h, hipMemsetAsync(h->S.sp_ready, 0, (size_t)h->S.n * 4, h->stream));
+    }
     return upload_seeds(h);
 }
 
@@ -221,8 +259,17 @@ int rg_step(rg_t *h, const uint8_t *keys, int keys_on_device) {
         HIPCHK(h, hipMemcpyAsync(h->d_keys, keys, (size_t)h->S.n, hipMemcpyHostToDevice, h->stream));
         dk = h->d_keys;
     }
-    { TimedLaunch t(h, 0); rgk_step(&h->S, &h->cfg, dk, h->d_err, h->stream); }
+    { TimedLaunch t(h, 0); rgk_step(&h->S, &h->SP, &h->cfg, dk, h->d_err, h->spares ? 1 : 0, h->stream); }
     HIPCHK(h, hipGetLastError());
+    if (h->spares && (++h->step_count & 1) == 0) {
+        // refill the consumed spares behind this step on the side stream.  Purely stream-ordered (the host runs far ahead of
+        // the GPU, so polling an event here would be meaningless); a launch that finds nothing to do costs ~10 us, concurrently.
+        HIPCHK(h, hipEventRecord(h->ev_step, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_step, 0));
+        rgk_regen(&h->SP, &h->cfg, h->side);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipEventRecord(h->ev_regen, h->side));
+    }
     h->render_pending = true;
     return 0;
 }
@@ -232,6 +279,7 @@ int rg_sync(rg_t *h) {
     uint32_t err = 0;
     HIPCHK(h, hipMemcpyAsync(&err, h->d_err, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
     if (err) {
         HIPCHK(h, hipMemsetAsync(h->d_err, 0, 4, h->stream));
         if (err & RG_FLAG_ERR_KEY) h->err = "Invalid input (key is not in the ai keymap)";

@@ -656,7 +656,6 @@ __device__ __forceinline__ void build_epilogue(const RgState &S, const RgConfig 
     (void)range32(E.ri, 1, 2); (void)range32(E.ri, 1, 2); (void)range32(E.ri, 8, 17);
     E.hp = E.hpmax = c.init_hp; E.plvl = 1; E.exp = 0;
     E.food = c.hunger_time; E.quiet = 0; E.gold = 0;
-    S.dc_len[E.e] = 0; S.dc_head[E.e] = 0;  // a rebuilt RunTime owns a fresh DistCache
 }
 
 // Level generation service.  Generating a level is a long chain of data-dependent, RNG-ordered tile
@@ -758,9 +757,37 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c, int nslot
     if (!valid) return;
     store_env(S, E);
     write_status(S, c, E);
+    S.dc_len[e] = 0; S.dc_head[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
     S.steps[e] = 0;
     S.flags[e] = RG_FLAG_REDRAW;
     S.reward[e] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_regen: background producer of the spare level-1 states (runs on a low-priority side stream)
+// ---------------------------------------------------------------------------------------------
+// Every auto-reset rebuilds the env from its (config, seed) -- a ~130-300 us single-lane dependency chain
+// that would otherwise sit on k_step's critical path ~450 times per 65 536-env step.  The rebuild only
+// depends on the seed, so it is produced AHEAD of time into a second ("spare") copy of the env state,
+// one generation per consumed spare, overlapped with the following steps; k_step's reset then is a copy.
+// SP is an RgState whose core pointers address the spare arrays.  Hand-off per env through sp_ready with
+// agent-scope release/acquire (the consumer kernel runs concurrently on another stream).
+__global__ void __launch_bounds__(WAVE) k_regen(RgState SP, RgConfig c, int nslots) {
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x * WAVE + lane;
+    const bool valid = e < SP.n;
+    bool claim = false;
+    if (valid && __hip_atomic_load(&SP.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+        claim = atomicCAS(&SP.sp_ready[e], 0u, 2u) == 0u;
+    if (!__any(claim)) return;
+    Env E;
+    E.e = valid ? e : 0; E.n = SP.n; E.cell = E.gcell = SP.cell + (size_t)E.e * SP.hw;
+    Prof pf; pf.start(nullptr);
+    gen_service(SP, c, E, lane, e, claim, true, reinterpret_cast<uint16_t *>(g_smem), nslots, pf);
+    if (claim) store_env(SP, E);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (claim) __hip_atomic_store(&SP.sp_ready[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -773,7 +800,12 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c, int nslot
 // the diagonal rule of can_move_impl (both orthogonal neighbours walkable, floor.rs:177-180) is
 // expressed on the masks.  No LDS traffic or barrier inside the level loop; distances are staged in LDS
 // and streamed to the env's DistCache slot with 16-byte stores.
+// Up to G = 64 / pow2ceil(H) requests are served at once: the wave is split into G groups of rows
+// (mini: 4 groups of 16 lanes), and the neighbour rows come from DPP whole-wave shifts (1 VALU op each).
 template <int WW> struct RowBits { uint64_t w[WW]; };
+
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }  // lane i <- lane i-1
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }  // lane i <- lane i+1
 
 template <int WW> __device__ __forceinline__ RowBits<WW> rb_shl1(const RowBits<WW> &a) {  // cell x-1 -> x
     RowBits<WW> r;
@@ -787,28 +819,34 @@ template <int WW> __device__ __forceinline__ RowBits<WW> rb_shr1(const RowBits<W
     for (int k = 0; k < WW; k++) r.w[k] = (a.w[k] >> 1) | (k + 1 < WW ? a.w[k + 1] << 63 : 0ull);
     return r;
 }
-template <int WW> __device__ __forceinline__ RowBits<WW> rb_from_lane(const RowBits<WW> &a, int src_lane, bool ok) {
+// the row above (UP = true: lane-1) or below (lane+1) of the same group; `ok` masks group boundaries.
+// NARROW: rows fit 32 bits, so only the low halves travel.
+template <int WW, bool NARROW, bool UP> __device__ __forceinline__ RowBits<WW> rb_neighbour(const RowBits<WW> &a, bool ok) {
     RowBits<WW> r;
 #pragma unroll
     for (int k = 0; k < WW; k++) {
-        uint32_t lo = (uint32_t)__shfl((int)(uint32_t)a.w[k], src_lane), hi = (uint32_t)__shfl((int)(uint32_t)(a.w[k] >> 32), src_lane);
+        uint32_t lo = UP ? wave_shr1((uint32_t)a.w[k]) : wave_shl1((uint32_t)a.w[k]);
+        uint32_t hi = 0;
+        if (!NARROW) hi = UP ? wave_shr1((uint32_t)(a.w[k] >> 32)) : wave_shl1((uint32_t)(a.w[k] >> 32));
         r.w[k] = ok ? (((uint64_t)hi << 32) | lo) : 0ull;
     }
     return r;
 }
 
-template <int WW>
-__device__ __forceinline__ void bfs_rows(const RgState &S, const RgConfig &c, uint16_t *lds_dist, int env, int tx, int ty, int slot, int lane) {
+// one round: group g of the wave computes the dist map of request (env, tx, ty, slot) given per lane (uniform per group)
+template <int WW, bool NARROW>
+__device__ __forceinline__ void bfs_rows(const RgState &S, const RgConfig &c, uint16_t *lds_dist /* this group's HW u16 */, bool active, int env, int tx, int ty,
+                                         int slot, int row, int grp_lane0, int rows_pow2) {
     const int W = c.width, H = c.height, HW = W * H;
     const uint16_t *cell = S.cell + (size_t)env * HW;
-    const bool row_ok = lane < H;
+    const bool row_ok = active && row < H;
     RowBits<WW> wk, vis, fr;
 #pragma unroll
     for (int k = 0; k < WW; k++) wk.w[k] = vis.w[k] = fr.w[k] = 0ull;
     if (row_ok) {  // walkable mask of my row (Surface::can_walk, rogue/mod.rs:175-182)
-        const uint16_t *row = cell + lane * W;
+        const uint16_t *rowp = cell + row * W;
         if ((W & 7) == 0) {
-            const uint4 *r4 = reinterpret_cast<const uint4 *>(row);
+            const uint4 *r4 = reinterpret_cast<const uint4 *>(rowp);
             for (int j = 0; j < W / 8; j++) {
                 uint4 v = r4[j];
                 uint32_t q[4] = {v.x, v.y, v.z, v.w};
@@ -825,27 +863,28 @@ __device__ __forceinline__ void bfs_rows(const RgState &S, const RgConfig &c, ui
             }
         } else {
             for (int x = 0; x < W; x++) {
-                uint64_t b = (uint64_t)can_walk(row[x]) << (x & 63);
+                uint64_t b = (uint64_t)can_walk(rowp[x]) << (x & 63);
 #pragma unroll
                 for (int k = 0; k < WW; k++)
                     if ((x >> 6) == k) wk.w[k] |= b;
             }
         }
     }
-    const RowBits<WW> wu = rb_from_lane<WW>(wk, lane - 1, lane > 0);       // walkable mask of row y-1
-    const RowBits<WW> wd = rb_from_lane<WW>(wk, lane + 1, lane + 1 < H);   // and of row y+1
-    for (int i = lane; i < HW; i += WAVE) lds_dist[i] = DIST_INF;
-    if (lane == ty) {
+    const bool up_ok = row > 0, dn_ok = row + 1 < H;
+    const RowBits<WW> wu = rb_neighbour<WW, NARROW, true>(wk, up_ok);    // walkable mask of row y-1
+    const RowBits<WW> wd = rb_neighbour<WW, NARROW, false>(wk, dn_ok);   // and of row y+1
+    if (active) for (int i = row; i < HW; i += rows_pow2) lds_dist[i] = DIST_INF;
+    if (row_ok && row == ty) {
 #pragma unroll
         for (int k = 0; k < WW; k++)
             if ((tx >> 6) == k) { fr.w[k] = 1ull << (tx & 63); vis.w[k] = fr.w[k]; }
     }
     __syncthreads();
-    if (lane == ty) lds_dist[ty * W + tx] = 0;
+    if (row_ok && row == ty) lds_dist[ty * W + tx] = 0;
     for (uint32_t level = 1; level < (uint32_t)HW; level++) {
-        const RowBits<WW> fu = rb_from_lane<WW>(fr, lane - 1, lane > 0);
-        const RowBits<WW> fd = rb_from_lane<WW>(fr, lane + 1, lane + 1 < H);
-        RowBits<WW> au, ad;  // frontier of the neighbour row restricted to cells whose vertical step lands on a walkable cell of my row
+        const RowBits<WW> fu = rb_neighbour<WW, NARROW, true>(fr, up_ok);
+        const RowBits<WW> fd = rb_neighbour<WW, NARROW, false>(fr, dn_ok);
+        RowBits<WW> au, ad;  // neighbour-row frontier restricted to cells whose vertical step lands on a walkable cell of my row
 #pragma unroll
         for (int k = 0; k < WW; k++) { au.w[k] = fu.w[k] & wk.w[k]; ad.w[k] = fd.w[k] & wk.w[k]; }
         const RowBits<WW> sl = rb_shl1<WW>(fr), sr = rb_shr1<WW>(fr);
@@ -862,26 +901,47 @@ __device__ __forceinline__ void bfs_rows(const RgState &S, const RgConfig &c, ui
             while (nw) {
                 int bit = __ffsll((long long)nw) - 1;
                 nw &= nw - 1;
-                lds_dist[lane * W + k * 64 + bit] = (uint16_t)level;
+                lds_dist[row * W + k * 64 + bit] = (uint16_t)level;
             }
         }
         if (!__any(any)) break;
     }
     __syncthreads();
-    uint16_t *out = S.dc_map + ((size_t)env * RG_DIST_SLOTS + slot) * HW;
-    if ((HW & 7) == 0) {
-        uint4 *o4 = reinterpret_cast<uint4 *>(out);
-        const uint4 *s4 = reinterpret_cast<const uint4 *>(lds_dist);
-        for (int i = lane; i < HW / 8; i += WAVE) o4[i] = s4[i];
-    } else
-        for (int i = lane; i < HW; i += WAVE) out[i] = lds_dist[i];
+    if (active) {
+        uint16_t *out = S.dc_map + ((size_t)env * RG_DIST_SLOTS + slot) * HW;
+        if ((HW & 7) == 0) {
+            uint4 *o4 = reinterpret_cast<uint4 *>(out);
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(lds_dist);
+            for (int i = row; i < HW / 8; i += rows_pow2) o4[i] = s4[i];
+        } else
+            for (int i = row; i < HW; i += rows_pow2) out[i] = lds_dist[i];
+    }
     __syncthreads();
+    (void)grp_lane0;
 }
 
-__device__ __forceinline__ void bfs_service(const RgState &S, const RgConfig &c, uint16_t *lds_dist, int env, int tx, int ty, int slot, int lane) {
-    if (c.width <= 64) bfs_rows<1>(S, c, lds_dist, env, tx, ty, slot, lane);
-    else if (c.width <= 128) bfs_rows<2>(S, c, lds_dist, env, tx, ty, slot, lane);
-    else bfs_rows<3>(S, c, lds_dist, env, tx, ty, slot, lane);
+// serve every lane of `need` (ballot mask): G requests per round
+__device__ __forceinline__ void bfs_service(const RgState &S, const RgConfig &c, uint16_t *lds, uint64_t need, int e, int px, int py, int map_slot, int lane) {
+    const int H = c.height, HW = c.width * H;
+    const int rows_pow2 = H <= 16 ? 16 : (H <= 32 ? 32 : 64);
+    const int G = WAVE / rows_pow2;
+    const int grp = lane / rows_pow2, row = lane - grp * rows_pow2;
+    while (need) {
+        int src = -1;
+        for (int g = 0; g < G; g++) {
+            int sg = need ? __ffsll((long long)need) - 1 : -1;
+            if (need) need &= need - 1;
+            if (g == grp) src = sg;
+        }
+        const bool active = src >= 0;
+        const int s = active ? src : 0;
+        int env_s = __shfl(e, s), tx = __shfl(px, s), ty = __shfl(py, s), sl = __shfl(map_slot, s);
+        uint16_t *ld = lds + (size_t)grp * HW;
+        if (c.width <= 32) bfs_rows<1, true>(S, c, ld, active, env_s, tx, ty, sl, row, grp * rows_pow2, rows_pow2);
+        else if (c.width <= 64) bfs_rows<1, false>(S, c, ld, active, env_s, tx, ty, sl, row, grp * rows_pow2, rows_pow2);
+        else if (c.width <= 128) bfs_rows<2, false>(S, c, ld, active, env_s, tx, ty, sl, row, grp * rows_pow2, rows_pow2);
+        else bfs_rows<3, false>(S, c, ld, active, env_s, tx, ty, sl, row, grp * rows_pow2, rows_pow2);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1142,7 +1202,8 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
 // ---------------------------------------------------------------------------------------------
 // k_step: one key for every env
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WAVE) k_step(RgState S, RgConfig c, const uint8_t *__restrict__ keys, uint32_t *__restrict__ err_any, int nslots) {
+__global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c, const uint8_t *__restrict__ keys, uint32_t *__restrict__ err_any, int nslots,
+                                               int use_spares) {
     uint16_t *lds_grid = reinterpret_cast<uint16_t *>(g_smem);
     const int lane = threadIdx.x;
     const int e = blockIdx.x * WAVE + lane;
@@ -1180,6 +1241,41 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgConfig c, const uint
     for (int pass = 0; pass < 2; ++pass) {
         // pass 0: levels for descending lanes; pass 1: rebuilds for terminal lanes (ThreadConductor auto-reset)
         pf.mark(1);
+        if (pass == 1 && use_spares) {
+            // take the pre-generated spare level when it is ready (k_regen); otherwise generate inline below
+            bool take = false;
+            if (need_gen && __hip_atomic_load(&S.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) take = true;
+            uint64_t tm = __ballot(take);
+            if (tm) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const int HW = S.hw, n = S.n, nrooms = c.room_num_x * c.room_num_y;
+                if (take) {
+                    uint16_t *gc = E.gcell;
+                    load_env(SP, E, e);
+                    E.cell = E.gcell = gc;
+                    for (int sl = 0; sl < nrooms; sl++) {
+                        S.room_rect[sl * n + e] = SP.room_rect[sl * n + e]; S.room_meta[sl * n + e] = SP.room_meta[sl * n + e];
+                        S.mon_w0[sl * n + e] = SP.mon_w0[sl * n + e]; S.mon_hp[sl * n + e] = SP.mon_hp[sl * n + e]; S.mon_exp[sl * n + e] = SP.mon_exp[sl * n + e];
+                        S.gold_pos[sl * n + e] = SP.gold_pos[sl * n + e]; S.gold_amt[sl * n + e] = SP.gold_amt[sl * n + e];
+                    }
+                    need_gen = false;
+                }
+                uint64_t mm = tm;
+                while (mm) {  // the wave streams each taken grid spare -> live with 16-byte accesses
+                    int src = __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    int env_s = __shfl(e, src);
+                    const uint16_t *sp = SP.cell + (size_t)env_s * HW;
+                    uint16_t *dp = S.cell + (size_t)env_s * HW;
+                    if ((HW & 7) == 0) {
+                        for (int i = lane; i < HW / 8; i += WAVE) reinterpret_cast<uint4 *>(dp)[i] = reinterpret_cast<const uint4 *>(sp)[i];
+                    } else
+                        for (int i = lane; i < HW; i += WAVE) dp[i] = sp[i];
+                }
+                __syncthreads();
+                if (take) __hip_atomic_store(&S.sp_ready[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // consumed: k_regen refills it
+            }
+        }
         gen_service(S, c, E, lane, e, need_gen, pass == 1, lds_grid, nslots, pf);
         pf.mark(2);
         need_gen = false;
@@ -1218,13 +1314,10 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgConfig c, const uint
             }
             pf.mark(3);
             uint64_t m = __ballot(need_bfs);
-            while (m) {  // serve the requesting lanes one at a time with the whole wave
-                int src = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                int env_s = __shfl(e, src), tx = __shfl(E.px, src), ty = __shfl(E.py, src), sl = __shfl(map_slot, src);
+            if (m) {  // serve the requesting lanes with the whole wave, several maps per round
                 unsigned long long tb0 = pf.p ? __builtin_amdgcn_s_memtime() : 0;
-                bfs_service(S, c, lds_grid, env_s, tx, ty, sl, lane);
-                if (pf.p && lane == 0) { unsigned long long dt = __builtin_amdgcn_s_memtime() - tb0; atomicMax(&pf.p[24], dt); atomicAdd(&pf.p[32 + 24], dt); atomicAdd(&pf.p[32 + 25], 1ull); }
+                bfs_service(S, c, lds_grid, m, e, E.px, E.py, map_slot, lane);
+                if (pf.p && lane == 0) { unsigned long long dt = __builtin_amdgcn_s_memtime() - tb0; atomicMax(&pf.p[24], dt); atomicAdd(&pf.p[32 + 24], dt); atomicAdd(&pf.p[32 + 25], (unsigned long long)__popcll(m)); }
             }
             pf.mark(4);
             if (do_turn && E.mon_active > 0) ui_dead = monsters_move(S, c, E, rand_mask, rand_dir, map_slot, react);  // `ui` of the LAST after_turn wins
@@ -1255,6 +1348,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgConfig c, const uint
     if (!live) { S.reward[e] = 0.f; return; }  // steps > max_steps: silent no-op
     if (terminal && c.auto_reset) {
         write_status(S, c, E);
+        S.dc_len[e] = 0; S.dc_head[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
         steps = 0;
         flags = RG_FLAG_REDRAW;
     }
@@ -1586,19 +1680,28 @@ static int gen_slots(int hw, int budget_bytes) {
     int n = budget_bytes / (hw * 2);
     return n < 1 ? 1 : (n > WAVE ? WAVE : n);
 }
-static size_t bfs_bytes(const RgConfig *c) { return (size_t)c->width * c->height * 2; }
+static size_t bfs_bytes(const RgConfig *c) {
+    int rows = c->height <= 16 ? 16 : (c->height <= 32 ? 32 : 64);
+    return (size_t)(WAVE / rows) * c->width * c->height * 2;
+}
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
     int ns = gen_slots(hw, 64 * 1024);
     size_t smem = (size_t)ns * hw * 2;
     hipLaunchKernelGGL(k_build, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *c, ns);
 }
-void rgk_step(const RgState *S, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, hipStream_t st) {
+void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, int use_spares, hipStream_t st) {
     int hw = c->width * c->height;
     int ns = gen_slots(hw, 32 * 1024);
     size_t smem = (size_t)ns * hw * 2;
     if (bfs_bytes(c) > smem) smem = bfs_bytes(c);
-    hipLaunchKernelGGL(k_step, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *c, keys, err_any, ns);
+    hipLaunchKernelGGL(k_step, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *SP, *c, keys, err_any, ns, use_spares);
+}
+void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
+    int hw = c->width * c->height;
+    int ns = gen_slots(hw, 32 * 1024);
+    size_t smem = (size_t)ns * hw * 2;
+    hipLaunchKernelGGL(k_regen, dim3((SP->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *SP, *c, ns);
 }
 void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st) {
     int blocks = S->n < 8192 ? S->n : 8192;

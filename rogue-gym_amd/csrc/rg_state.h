@@ -75,6 +75,8 @@ struct RgState {
     uint8_t *dc_head, *dc_len;  // [n] FIFO ring
     // optional in-kernel phase profile (development aid): [2][32] u64 = {max cycles, sum cycles} per phase, NULL = off
     unsigned long long *prof;
+    // spare-level pipeline: 0 = spare must be (re)generated, 1 = ready, 2 = generation in progress
+    uint32_t *sp_ready; // [n] (shared by the live and the spare view)
     // status mirror
     int32_t *status;    // [n][10]
 };

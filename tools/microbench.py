@@ -80,7 +80,10 @@ def prof(name, cfg, keys_table, n=65536, steps=200, max_steps=1000, do_reset=Fal
     for i in sorted(names):
         if out[32 + i]:
             print("   %-16s max %8.1f us (over all launches)   avg/wave/launch %8.2f us" % (names[i], out[i] / 100.0, out[32 + i] / 100.0 / nw / steps))
-    CLK = 100.0  # s_memtime ticks per us (constant 100 MHz counter)
+    ngen = out[32 + 21] + out[32 + 23]
+    if ngen:
+        print("   per-generation averages (us, ticks/2400): " + "  ".join("%s %.1f" % (names[i][2:], out[32 + i] / ngen / 2400.0) for i in range(8, 16))
+              + "  | place+copy %.1f" % ((out[32 + 20] + out[32 + 22]) / ngen / 2400.0 - sum(out[32 + i] for i in range(9, 16)) / ngen / 2400.0))
     for nm, k in (("gen (1 lane)", 20), ("gen (>1 lanes)", 22), ("bfs", 24)):
         if out[32 + k + 1]:
             print("   %-16s count/launch %.1f  avg %.1f ticks  max %.1f ticks" % (nm, out[32 + k + 1] / steps, out[32 + k] / out[32 + k + 1], out[k]))
