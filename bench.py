@@ -5,8 +5,9 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one lock-step pass of the hot path over every env of this rank: action fetch ->
-k_step (player turn, monster AI, combat, FoV, auto-reset incl. dungeon generation) -> k_render
-(mirror refresh) -> k_gray (f32 observation written into a PyTorch-ROCm tensor in HBM).
+k_step (player turn, monster AI, combat, FoV, descents, auto-reset) -> k_obs (mirror refresh fused with the
+f32 observation encode into a PyTorch-ROCm tensor in HBM); k_regen refills the consumed spare levels on a side stream
+(one dungeon generation per reset, overlapped; torch.cuda.synchronize() at the end of the timed region waits for it too).
 Workload = BASELINE.json configs[1]: data/config-mini.json (32x16, 2x2 rooms, 26 monsters, hidden
 dungeon), 65 536 envs per GPU, per-env seed = global env index, uniform-random policy over the 11
 RL actions (device-side generator seeded 0), max_steps = 1000, gray-image observation.
@@ -30,9 +31,9 @@ sys.path.insert(0, os.path.join(ROOT, "rogue-gym_amd"))
 
 ALGO_BYTES_PER_STEP = 3200      # SURVEY.md 8(d), mini gray: 512*4 obs + 512*2 tile state + 128 scalars/entities
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-KERNELS = ["k_step", "k_render", "k_gray", "k_build"]
+KERNELS = ["k_step", "k_render", "k_obs", "k_build"]
 # per-kernel share of the algorithmic bytes (DESIGN.md "Kernels"): scalars/entities | tile state | obs write (+ mirror read)
-KERNEL_ALGO_BYTES = {"k_step": 128, "k_render": 1024, "k_gray": 2048}
+KERNEL_ALGO_BYTES = {"k_step": 128, "k_render": 1024, "k_obs": 3072}  # k_obs = fused mirror refresh + encode: 1024 tile + 2048 obs
 
 
 def mini_config():
@@ -46,17 +47,18 @@ def cpu_baseline(cfg, budget_s=12.0):
     from oracle.pyoracle import OracleBatch
 
     cores = os.cpu_count() or 1
-    n = 4096
+    n = 65536 if cores >= 64 else 8192  # enough envs per thread that the per-step barrier is noise
     b = OracleBatch([cfg] * n, max_steps=1000, n_threads=cores, seeds=list(range(n)))
     obs = np.zeros((n, 1, cfg["height"], cfg["width"]), np.float32)
     acts = np.frombuffer(b".hjklnbuy>s", np.uint8)
     rng = np.random.RandomState(0)
-    for _ in range(5):
-        b.step(acts[rng.randint(0, 11, n)], obs)
+    keys = [acts[rng.randint(0, 11, n)] for _ in range(32)]
+    for t in range(5):
+        b.step(keys[t], obs)
     steps, t0 = 0, time.time()
     while time.time() - t0 < budget_s:
-        for _ in range(10):
-            b.step(acts[rng.randint(0, 11, n)], obs)
+        for t in range(10):
+            b.step(keys[(steps + t) % 32], obs)
         steps += 10
     dt = time.time() - t0
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",

@@ -77,12 +77,14 @@ int rg_sync(rg_t *h);
  *   status  i32 [n_env][10]     Status::to_vec order (player.rs:418-430), refreshed on StatusUpdated
  *   flags   u32 [n_env]         RG_FLAG_* bits
  *   reward  f32 [n_env]         max(0, gold_after - gold_before) of the last rg_step (parallel.py:60-63)
+ *   done    u8  [n_env]         is_terminal of the state returned by the last rg_step (parallel.py:64)
  * Reading them (rg_screen/rg_hist/rg_obs_*) flushes the pending screen render first. */
 int rg_screen(rg_t *h, uint8_t **dev);
 int rg_hist(rg_t *h, uint8_t **dev);
 int rg_status(rg_t *h, int32_t **dev);
 int rg_flags(rg_t *h, uint32_t **dev);
 int rg_reward(rg_t *h, float **dev);
+int rg_done(rg_t *h, uint8_t **dev);
 
 /* PlayerState::gray_image[_with_hist] / symbol_image[_with_hist] for the whole batch
  * (python/src/lib.rs:72-111,162-205; flags.rs:88-115; symbol.rs:17-71), written straight into

@@ -163,9 +163,10 @@ typedef struct { uint32_t *map; int kx, ky; } dcache_t;
 /* Reaction list (core/src/lib.rs:378-403) and message flags (python/src/flags.rs:6-39) */
 enum { RE_REDRAW = 1, RE_STATUS = 2, RE_GRAVE = 4, RE_NOTIFY = 8 };
 enum { MSG_HIT_FROM = 1, MSG_HIT_TO = 2, MSG_MISS_TO = 4, MSG_MISS_FROM = 8, MSG_KILLED = 16, MSG_SECRET_DOOR = 32, MSG_NO_DOWNSTAIR = 64 };
-typedef struct { int kind; uint32_t msg; } reaction_t;
-typedef struct { reaction_t v[4096]; int n; } rlist_t;
-static void rpush(rlist_t *l, int kind, uint32_t msg) { if (l->n < 4096) l->v[l->n++] = (reaction_t){kind, msg}; }
+typedef struct { uint8_t kind, msg; } reaction_t;
+#define RLIST_CAP 2048 /* a run is at most W+H iterations of a few reactions each */
+typedef struct { reaction_t v[RLIST_CAP]; int n; } rlist_t;
+static void rpush(rlist_t *l, int kind, uint32_t msg) { if (l->n < RLIST_CAP) l->v[l->n++] = (reaction_t){(uint8_t)kind, (uint8_t)msg}; }
 
 
 

@@ -152,7 +152,7 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
     bool ok = dev_alloc(h, &S.cell, n * hw) && dev_alloc(h, &S.screen, n * hw) && dev_alloc(h, &S.hist, n * hw) &&
               dev_alloc(h, &S.p_pos, n) && dev_alloc(h, &S.p_hp, n) && dev_alloc(h, &S.p_hpmax, n) && dev_alloc(h, &S.p_lvl, n) &&
               dev_alloc(h, &S.p_exp, n) && dev_alloc(h, &S.food, n) && dev_alloc(h, &S.quiet, n) && dev_alloc(h, &S.pack_gold, n) &&
-              dev_alloc(h, &S.dlevel, n) && dev_alloc(h, &S.steps, n) && dev_alloc(h, &S.flags, n) && dev_alloc(h, &S.reward, n) &&
+              dev_alloc(h, &S.dlevel, n) && dev_alloc(h, &S.steps, n) && dev_alloc(h, &S.flags, n) && dev_alloc(h, &S.reward, n) && dev_alloc(h, &S.done, n) &&
               dev_alloc(h, &S.rng, 12 * n) && dev_alloc(h, &S.seed_lo, n) && dev_alloc(h, &S.seed_hi, n) && dev_alloc(h, &S.reseed, n) &&
               dev_alloc(h, &S.room_rect, RG_MAX_ROOMS * n) && dev_alloc(h, &S.room_meta, RG_MAX_ROOMS * n) &&
               dev_alloc(h, &S.mon_w0, RG_MAX_ROOMS * n) && dev_alloc(h, &S.mon_hp, RG_MAX_ROOMS * n) && dev_alloc(h, &S.mon_exp, RG_MAX_ROOMS * n) &&
@@ -295,6 +295,7 @@ int rg_hist(rg_t *h, uint8_t **dev) { HIPCHK(h, hipSetDevice(h->device)); if (fl
 int rg_status(rg_t *h, int32_t **dev) { *dev = h->S.status; return 0; }
 int rg_flags(rg_t *h, uint32_t **dev) { HIPCHK(h, hipSetDevice(h->device)); if (flush_render(h)) return 1; *dev = h->S.flags; return 0; }
 int rg_reward(rg_t *h, float **dev) { *dev = h->S.reward; return 0; }
+int rg_done(rg_t *h, uint8_t **dev) { *dev = h->S.done; return 0; }
 
 int rg_obs_channels(const rg_t *h, int symbol, uint32_t status_flag, int with_hist) {
     return (symbol ? h->cfg.symbols : 1) + __builtin_popcount(status_flag & 0x1ffu) + (with_hist ? 1 : 0);

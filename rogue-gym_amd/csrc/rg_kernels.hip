@@ -11,6 +11,8 @@
 // file:line citations are relative to /root/reference.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/rogue_gym_hip.h"
 #include "rg_state.h"
 
@@ -761,6 +763,7 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c, int nslot
     S.steps[e] = 0;
     S.flags[e] = RG_FLAG_REDRAW;
     S.reward[e] = 0.f;
+    S.done[e] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1203,11 +1206,13 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
 // k_step: one key for every env
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c, const uint8_t *__restrict__ keys, uint32_t *__restrict__ err_any, int nslots,
-                                               int use_spares) {
+                                               int use_spares, int epw) {
+    // epw = envs per wave (64, 32 or 16): the kernel is bound by dependent-load latency, not by lanes, so at 65 536 envs
+    // half-filled waves put 2+ waves on every SIMD and let their memory round trips overlap
     uint16_t *lds_grid = reinterpret_cast<uint16_t *>(g_smem);
     const int lane = threadIdx.x;
-    const int e = blockIdx.x * WAVE + lane;
-    const bool valid = e < S.n;
+    const int e = blockIdx.x * epw + lane;
+    const bool valid = lane < epw && e < S.n;
     Prof pf0; pf0.start(S.prof);
     Env E;
     uint32_t react = 0, err = 0, old_flags = 0, steps = 0, flags = 0;
@@ -1342,10 +1347,11 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
     if (err) {
         S.flags[e] = (old_flags & ~RG_FLAG_ERR_MASK) | err;
         S.reward[e] = 0.f;
+        S.done[e] = (old_flags & RG_FLAG_TERMINAL) ? 1 : 0;
         atomicOr(err_any, err);
         return;
     }
-    if (!live) { S.reward[e] = 0.f; return; }  // steps > max_steps: silent no-op
+    if (!live) { S.reward[e] = 0.f; S.done[e] = (old_flags & RG_FLAG_TERMINAL) ? 1 : 0; return; }  // steps > max_steps: silent no-op
     if (terminal && c.auto_reset) {
         write_status(S, c, E);
         S.dc_len[e] = 0; S.dc_head[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
@@ -1356,6 +1362,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
     store_env(S, E);
     S.steps[e] = steps;
     S.flags[e] = flags;
+    S.done[e] = terminal ? 1 : 0;
     int gold_after = S.status[(size_t)e * 10 + 1];
     S.reward[e] = (float)(gold_after - gold_before > 0 ? gold_after - gold_before : 0);
 }
@@ -1692,10 +1699,16 @@ void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
 }
 void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, int use_spares, hipStream_t st) {
     int hw = c->width * c->height;
-    int ns = gen_slots(hw, 32 * 1024);
+    int ns = gen_slots(hw, 8 * 1024);  // descents are rare once resets come from spares: a small LDS footprint keeps k_regen co-resident
     size_t smem = (size_t)ns * hw * 2;
     if (bfs_bytes(c) > smem) smem = bfs_bytes(c);
-    hipLaunchKernelGGL(k_step, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *SP, *c, keys, err_any, ns, use_spares);
+    static int epw_env = -1;
+    if (epw_env < 0) { const char *v = getenv("ROGUE_GYM_HIP_EPW"); epw_env = v ? atoi(v) : 0; }
+    int epw = epw_env > 0 ? epw_env : 64;
+    if (epw != 64 && epw != 32 && epw != 16) epw = 64;
+    { const char *v = getenv("ROGUE_GYM_HIP_NSLOTS"); int cap = v ? atoi(v) : epw; if (cap < 1) cap = 1; if (ns > cap) ns = cap; if (ns > epw) ns = epw;
+      smem = (size_t)ns * hw * 2; if (bfs_bytes(c) > smem) smem = bfs_bytes(c); }
+    hipLaunchKernelGGL(k_step, dim3((S->n + epw - 1) / epw), dim3(WAVE), smem, st, *S, *SP, *c, keys, err_any, ns, use_spares, epw);
 }
 void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;

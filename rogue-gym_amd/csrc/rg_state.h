@@ -53,6 +53,7 @@ struct RgState {
     uint32_t *p_exp, *food, *quiet, *pack_gold, *dlevel;
     uint32_t *steps, *flags;
     float *reward;
+    uint8_t *done;      // [n] 1 = the last key ended the episode (is_terminal of the returned state)
     uint32_t *rng;      // [12][n]  dungeon{x,y,z,w}, item{..}, enemy{..}
     uint64_t *seed_lo, *seed_hi;  // [n] seed used by the next build
     uint8_t *reseed;    // [n] 1 = config has no seed: draw a fresh one for every build (core/src/lib.rs:157-165)

@@ -47,6 +47,8 @@ class HipVecRogueEnv:
             p = C.c_void_p()
             self._h.check(L.rg_reward(h, C.byref(p)))
             self.reward = torch.as_tensor(_DevArray(p.value, (self.num_envs,), "<f4"), device=self.device)
+            self._h.check(L.rg_done(h, C.byref(p)))
+            self.done = torch.as_tensor(_DevArray(p.value, (self.num_envs,), "|b1"), device=self.device)
             self._h.check(L.rg_flags(h, C.byref(p)))
             self.flags = torch.as_tensor(_DevArray(p.value, (self.num_envs,), "<i4"), device=self.device)
             self._h.check(L.rg_status(h, C.byref(p)))
@@ -76,7 +78,7 @@ class HipVecRogueEnv:
         """keys: uint8 CUDA tensor [num_envs] of key bytes (KeyMap::ai)."""
         self._h.check(self._h.L.rg_step(self._h.h, C.c_void_p(keys.data_ptr()), 1))
         obs = self._encode()
-        return obs, self.reward, (self.flags & 1).bool()
+        return obs, self.reward, self.done
 
     def step(self, actions):
         """actions: integer CUDA tensor [num_envs] of indices into ACTIONS."""

@@ -74,6 +74,7 @@ def load_library():
     L.rg_status.argtypes = [vp, C.POINTER(vp)]
     L.rg_flags.argtypes = [vp, C.POINTER(vp)]
     L.rg_reward.argtypes = [vp, C.POINTER(vp)]
+    L.rg_done.argtypes = [vp, C.POINTER(vp)]
     L.rg_obs_gray.argtypes = [vp, C.c_uint32, C.c_int, vp]
     L.rg_obs_symbol.argtypes = [vp, C.c_uint32, C.c_int, vp]
     L.rg_obs_channels.argtypes = [vp, C.c_int, C.c_uint32, C.c_int]
@@ -84,7 +85,7 @@ def load_library():
     L.rg_dump_config.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
     L.rg_debug_fetch.argtypes = [vp, C.c_int, C.POINTER(RgDebugState), vp]
     for f in ("rg_create", "rg_dims", "rg_set_stream", "rg_seed", "rg_reset", "rg_step", "rg_sync", "rg_screen", "rg_hist", "rg_status", "rg_flags",
-              "rg_reward", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_dump_config", "rg_debug_fetch", "rg_timing_enable", "rg_timing_read"):
+              "rg_reward", "rg_done", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_dump_config", "rg_debug_fetch", "rg_timing_enable", "rg_timing_read"):
         getattr(L, f).restype = C.c_int
     _ = (u8p, i32p, u32p, f32p)
     _lib = L
