@@ -261,7 +261,8 @@ int rg_step(rg_t *h, const uint8_t *keys, int keys_on_device) {
     }
     { TimedLaunch t(h, 0); rgk_step(&h->S, &h->SP, &h->cfg, dk, h->d_err, h->spares ? 1 : 0, h->stream); }
     HIPCHK(h, hipGetLastError());
-    if (h->spares && (++h->step_count & 1) == 0) {
+    static int regen_every = getenv("ROGUE_GYM_HIP_REGEN_EVERY") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_EVERY")) : 1;
+    if (h->spares && (++h->step_count % (uint64_t)(regen_every < 1 ? 1 : regen_every)) == 0) {
         // refill the consumed spares behind this step on the side stream.  Purely stream-ordered (the host runs far ahead of
         // the GPU, so polling an event here would be meaningless); a launch that finds nothing to do costs ~10 us, concurrently.
         HIPCHK(h, hipEventRecord(h->ev_step, h->stream));

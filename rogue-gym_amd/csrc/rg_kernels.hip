@@ -25,7 +25,9 @@
 // Direction enum order (dungeon/coord.rs:198-242): Up Down Left Right LeftUp RightUp LeftDown RightDown Stay
 __device__ __constant__ int8_t kDX[9] = {0, 0, -1, 1, -1, 1, -1, 1, 0};
 __device__ __constant__ int8_t kDY[9] = {-1, 1, 0, 0, -1, -1, 1, 1, 0};
-__device__ __constant__ uint8_t kGlyph[8] = {'#', '.', '-', '|', '%', '+', '^', ' '};  // Surface::tile (rogue/mod.rs:149-163)
+// Surface::tile (rogue/mod.rs:149-163): '#' '.' '-' '|' '%' '+' '^' ' ' packed into one 64-bit immediate (a __constant__ table indexed per lane
+// would be a memory load per cell)
+__device__ __forceinline__ uint32_t glyph_of(uint32_t surface) { return (uint32_t)(0x205E2B257C2D2E23ull >> (8 * (surface & 7))) & 0xffu; }
 
 // BUILTIN_ENEMIES (character/enemies.rs:474-761), index = tile - 'A'
 #define EA_MEAN 1
@@ -1301,7 +1303,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
                     bool done = move_player(S, c, E, dir, react);
                     if (act == ACT_MOVE) { do_turn = true; running = false; break; }
                     uint32_t v = E.cell[E.py * c.width + E.px];
-                    uint32_t tile = (v & C_VISIBLE) ? kGlyph[v & C_SURF_MASK] : ' ';
+                    uint32_t tile = (v & C_VISIBLE) ? glyph_of(v) : ' ';
                     if (done || (tile != '.' && tile != '#')) running = false;  // MoveUntil stops without after_turn
                     else do_turn = true;
                     break;
@@ -1398,7 +1400,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RgState S, RgConfig c
             uint32_t v = cell[i];
             int y = i / W;
             uint8_t g = ' ';
-            if (y >= 1 && y < H - 1 && (v & C_VISIBLE)) g = kGlyph[v & C_SURF_MASK];
+            if (y >= 1 && y < H - 1 && (v & C_VISIBLE)) g = glyph_of(v);
             s_scr[i] = g;
             if (upd_hist) hist[i] = (v & C_VISITED) ? 1 : 0;
         }
@@ -1529,13 +1531,20 @@ __global__ void __launch_bounds__(256) k_symbol(const uint8_t *__restrict__ scre
 // write (Redraw envs), 2 KB observation write.  A block of 256 threads serves `epb` envs, `tpe` threads each;
 // a thread owns 8 consecutive cells (one 16-byte tile load, two float4 stores per plane).
 #define OBS_THREADS 256
+struct ObsTabs {  // per-env entity/room tables staged in LDS: every global load of an env is issued up front, in one round trip
+    uint32_t rect[RG_MAX_ROOMS], mon[RG_MAX_ROOMS], gold[RG_MAX_ROOMS];
+    uint8_t meta[RG_MAX_ROOMS];
+    uint32_t ppos, pad[3];
+};
+#define OBS_ENV_BYTES(hw) ((((size_t)(hw) + sizeof(ObsTabs)) + 15) & ~(size_t)15)
+
 template <int KIND>
 __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint32_t sflag, int with_hist, float *__restrict__ out,
                                                     uint32_t *__restrict__ err_any, int tpe, int epb) {
     extern __shared__ __align__(16) uint8_t smem[];
     float *lutf = reinterpret_cast<float *>(smem);        // glyph -> gray value (KIND 0)
     uint8_t *luts = smem + 512;                            // glyph -> symbol id
-    uint8_t *screens = smem + 512 + 128;                   // epb x HW staged screens
+    uint8_t *envs = smem + 512 + 128;                      // epb x {HW staged screen bytes, ObsTabs}
     const int tid = threadIdx.x, W = c.width, H = c.height, HW = W * H, n = S.n, Q8 = HW >> 3;
     const int nrooms = c.room_num_x * c.room_num_y;
     const int symbols = c.symbols;
@@ -1547,7 +1556,8 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
     const int le = tid / tpe, lt = tid - le * tpe;
     const int base_planes = KIND ? symbols : 1;
     const int nplanes = base_planes + __popc(sflag) + (with_hist ? 1 : 0);
-    uint8_t *scr = screens + (size_t)le * HW;
+    uint8_t *scr = envs + (size_t)le * OBS_ENV_BYTES(HW);
+    ObsTabs *tb = reinterpret_cast<ObsTabs *>(scr + HW);
     for (int base = blockIdx.x * epb; base < n; base += gridDim.x * epb) {
         const int e = base + le;
         const bool valid = le < epb && e < n;
@@ -1555,8 +1565,14 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
         bool redraw = false;
         if (valid) { fl = S.flags[e]; redraw = fl & RG_FLAG_REDRAW; }
         __syncthreads();  // LUTs ready / previous iteration's LDS reads done
+        // ---- phase A: every global load of this env, independent of each other ----
         if (valid) {
             if (redraw) {
+                if (lt < nrooms) {
+                    tb->rect[lt] = S.room_rect[lt * n + e]; tb->meta[lt] = S.room_meta[lt * n + e];
+                    tb->mon[lt] = S.mon_w0[lt * n + e]; tb->gold[lt] = S.gold_pos[lt * n + e];
+                }
+                if (lt == tpe - 1) tb->ppos = S.p_pos[e];
                 const uint4 *cell4 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW);
                 const bool upd_hist = !(fl & RG_FLAG_HIST_STALE);
                 uint2 *hist8 = reinterpret_cast<uint2 *>(S.hist + (size_t)e * HW);
@@ -1568,8 +1584,10 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                     for (int t = 0; t < 8; t++) {
                         uint32_t cw = (q[t >> 1] >> ((t & 1) * 16)) & 0xffff;
                         int idx = i * 8 + t;
+                        bool inner = idx >= W && idx < HW - W;  // rows 1..H-2 only (rogue/mod.rs:278-290)
                         uint32_t gl = ' ';
-                        if (idx >= W && idx < HW - W && (cw & C_VISIBLE)) gl = kGlyph[cw & C_SURF_MASK];  // rows 1..H-2 only (rogue/mod.rs:278-290)
+                        if (inner && (cw & C_VISIBLE)) gl = glyph_of(cw);
+                        if (inner && (cw & (C_VISIBLE | C_DRAWN))) gl |= 0x80u;  // bit 7: an object on this cell is drawn (draw_ranges)
                         g[t >> 2] |= gl << ((t & 3) * 8);
                         hb[t >> 2] |= ((cw & C_VISITED) ? 1u : 0u) << ((t & 3) * 8);
                     }
@@ -1582,31 +1600,42 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
             }
         }
         __syncthreads();
-        // entity overlays, lowest draw priority first: monster < gold < player (core/src/lib.rs:271-283)
-        uint32_t ppos = 0;
-        if (valid && redraw) ppos = S.p_pos[e];
+        // ---- phase B: entity overlays from LDS only; draw priority monster < gold < player (core/src/lib.rs:271-283) ----
+        const uint32_t ppos = (valid && redraw) ? tb->ppos : 0;
         const int px = POS_X(ppos), py = POS_Y(ppos);
         if (valid && redraw && lt < nrooms) {
-            uint32_t w = S.mon_w0[lt * n + e];
+            uint32_t w = tb->mon[lt];
             if ((w >> 24) & MF_ALIVE) {
                 int x = POS_X(w), y = POS_Y(w);
-                uint32_t v = S.cell[(size_t)e * HW + y * W + x];
                 int dx = px - x, dy = py - y;
-                if ((v & (C_VISIBLE | C_DRAWN)) && y >= 1 && y < H - 1 && (dx * dx + dy * dy <= 2 || in_same_room(S, c, e, px, py, x, y)))
-                    scr[y * W + x] = (uint8_t)('A' + ((w >> 16) & 0xff));
+                bool show = dx * dx + dy * dy <= 2;
+                if (!show) {  // Floor::in_same_room (floor.rs:381-393)
+                    int id = room_id_of(c, px, py);
+                    if (id >= 0 && room_id_of(c, x, y) == id) {
+                        if ((tb->meta[id] & RM_KIND_MASK) == RK_EMPTY) show = true;
+                        else {
+                            int x0, y0, x1, y1;
+                            unpack_rect(tb->rect[id], x0, y0, x1, y1);
+                            bool ina = px >= x0 && px < x1 && py >= y0 && py < y1, inb = x >= x0 && x < x1 && y >= y0 && y < y1;
+                            show = ina == inb;
+                        }
+                    }
+                }
+                if (show && (scr[y * W + x] & 0x80u)) scr[y * W + x] = (uint8_t)(0x80u | ('A' + ((w >> 16) & 0xff)));
             }
         }
         __syncthreads();
-        if (valid && redraw && lt < nrooms) {
-            uint32_t g = S.gold_pos[lt * n + e];
-            if (g & 0x10000u) {
-                int x = POS_X(g), y = POS_Y(g);
-                if ((S.cell[(size_t)e * HW + y * W + x] & (C_VISIBLE | C_DRAWN)) && y >= 1 && y < H - 1) scr[y * W + x] = '*';
-            }
+        if (valid && redraw) {
+            if (lt < nrooms) {
+                uint32_t g = tb->gold[lt];
+                if ((g & 0x10000u) && (g & 0xffff) != ppos) {  // the player's own cell is drawn by the player lane
+                    int x = POS_X(g), y = POS_Y(g);
+                    if (scr[y * W + x] & 0x80u) scr[y * W + x] = (uint8_t)(0x80u | '*');
+                }
+            } else if (lt == nrooms && (scr[py * W + px] & 0x80u)) scr[py * W + px] = (uint8_t)(0x80u | '@');
         }
         __syncthreads();
-        if (valid && redraw && lt == 0 && (S.cell[(size_t)e * HW + py * W + px] & (C_VISIBLE | C_DRAWN)) && py >= 1 && py < H - 1) scr[py * W + px] = '@';
-        __syncthreads();
+        // ---- phase C: mirror write-back + encode ----
         if (valid) {
             uint2 *m8 = reinterpret_cast<uint2 *>(S.screen + (size_t)e * HW);
             float4 *o = reinterpret_cast<float4 *>(out + (size_t)e * nplanes * HW);
@@ -1614,6 +1643,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
             bool bad = false;
             for (int i = lt; i < Q8; i += tpe) {
                 uint2 g = reinterpret_cast<const uint2 *>(scr)[i];
+                g.x &= 0x7f7f7f7fu; g.y &= 0x7f7f7f7fu;
                 if (redraw) m8[i] = g;
                 uint32_t gg[2] = {g.x, g.y};
 #pragma unroll
@@ -1728,7 +1758,7 @@ int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, 
     int tpe = q8 >= OBS_THREADS ? OBS_THREADS : ((q8 + 63) / 64) * 64;  // threads per env: a whole number of waves
     if (tpe > OBS_THREADS) tpe = OBS_THREADS;
     int epb = OBS_THREADS / tpe;
-    size_t smem = 512 + 128 + (size_t)epb * hw;
+    size_t smem = 512 + 128 + (size_t)epb * OBS_ENV_BYTES(hw);
     int blocks = (S->n + epb - 1) / epb;
     if (blocks > 32768) blocks = 32768;
     if (!kind) hipLaunchKernelGGL(k_obs<0>, dim3(blocks), dim3(OBS_THREADS), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb);
