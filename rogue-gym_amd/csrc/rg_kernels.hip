@@ -1211,6 +1211,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
                                                int use_spares, int epw) {
     // epw = envs per wave (64, 32 or 16): the kernel is bound by dependent-load latency, not by lanes, so at 65 536 envs
     // half-filled waves put 2+ waves on every SIMD and let their memory round trips overlap
+    __builtin_amdgcn_s_setprio(3);  // issue-bound kernel: win VALU arbitration against the co-resident background k_regen waves
     uint16_t *lds_grid = reinterpret_cast<uint16_t *>(g_smem);
     const int lane = threadIdx.x;
     const int e = blockIdx.x * epw + lane;

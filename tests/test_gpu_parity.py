@@ -152,3 +152,80 @@ def test_full_size_invariants(goldens):
     assert g.shape == (n, 1, 16, 32)
     sym = g * 43.0
     assert np.abs(sym - np.round(sym)).max() < 1e-4
+
+
+def test_inline_generation_path_without_spares(goldens, monkeypatch):
+    """The spare-level pipeline (k_regen) is an optimisation: with it disabled every reset generates inline.
+    Both paths must give identical states."""
+    monkeypatch.setenv("ROGUE_GYM_HIP_NO_SPARES", "1")
+    rng = np.random.RandomState(21)
+    lockstep(goldens["configs"]["mini"], list(range(256)), rand_keys(rng, ALL_KEYS, 256, 200), max_steps=60, check_every=1, internal_every=40)
+
+
+def test_spares_survive_reseeding(goldens):
+    """rg_seed invalidates the pre-generated spares: after seed() + reset() and further auto-resets the envs follow the new seeds."""
+    cfg = goldens["configs"]["mini"]
+    n = 128
+    hip = HipBatch(cfg, list(range(n)), max_steps=25)
+    rng = np.random.RandomState(4)
+    for k in rand_keys(rng, ACTION_KEYS, n, 40):
+        hip.step(k)
+    import ctypes as C
+    new_seeds = [1000 + 7 * i for i in range(n)]
+    lo = (C.c_uint64 * n)(*new_seeds)
+    hi = (C.c_uint64 * n)(*([0] * n))
+    hip.h.check(hip.h.L.rg_seed(hip.h.h, lo, hi, n))
+    hip.h.check(hip.h.L.rg_reset(hip.h.h))
+    oracles = make_oracles(cfg, new_seeds, max_steps=25)
+    compare_mirrors(hip, oracles, "after reseed+reset")
+    for t, k in enumerate(rand_keys(rng, ACTION_KEYS, n, 80)):
+        hip.step(k)
+        for i, o in enumerate(oracles):
+            o.step_autoreset(int(k[i]))
+        compare_mirrors(hip, oracles, "reseeded t=%d" % t)
+    compare_internal(hip, oracles, range(n), "reseeded end")
+
+
+def test_full_size_default_and_symbol_obs(goldens):
+    """BASELINE configs 3 and 4 at their per-GPU sizes (32 768 envs of the 80x24 dungeon; nohide + 43-channel symbol
+    image): run, check size-independent invariants, and compare a strided sample with the oracle."""
+    import torch
+    for name, sym in (("default", False), ("nohide", True)):
+        cfg = goldens["configs"][name]
+        n = 32768
+        rng = np.random.RandomState(13)
+        hip = HipBatch(cfg, list(range(n)), max_steps=1000)
+        keys = rand_keys(rng, ACTION_KEYS, n, 24)
+        for k in keys:
+            hip.step(k)
+        hip.sync()
+        screen, hist, status, flags = hip.fetch()
+        assert (screen[:, 0, :] == 32).all() and (screen[:, -1, :] == 32).all()
+        assert ((screen == ord("@")).sum(axis=(1, 2)) <= 1).all()
+        assert (status[:, 2] <= status[:, 3]).all() and (status[:, 0] >= 1).all()
+        sample = list(range(0, n, 256))
+        oracles = make_oracles(cfg, sample)
+        for k in keys:
+            for j, o in enumerate(oracles):
+                o.step_autoreset(int(k[sample[j]]))
+        for j, o in enumerate(oracles):
+            i = sample[j]
+            assert np.array_equal(screen[i], o.screen()), "%s env %d" % (name, i)
+            assert [int(v) for v in status[i]] == [int(v) for v in o.status_arr()]
+        obs = hip.obs(1 if sym else 0, 0x1FF if not sym else 0, False)
+        assert obs.shape == (n, (43 if sym else 1 + 9), 24, 80)
+        for j, o in enumerate(oracles[:32]):
+            i = sample[j]
+            if sym:
+                try:
+                    exp = o.symbol_image(0, False)
+                except RuntimeError:
+                    continue
+            else:
+                exp = o.gray_image(0x1FF, False)
+            assert np.array_equal(obs[i], exp), "%s obs env %d" % (name, i)
+        if sym:  # one-hot: every cell has exactly one active channel among 0..41 (unless it shows 'Z')
+            assert (obs[:, :42].sum(axis=1) <= 1.0).all()
+        hip.h.L.rg_sync(hip.h.h)
+        del obs, hip
+        torch.cuda.empty_cache()
