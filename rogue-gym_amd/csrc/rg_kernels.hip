@@ -80,9 +80,24 @@ __device__ __forceinline__ uint32_t range32(Rng &r, uint32_t low, uint32_t high)
         if (lo <= zone) return low + __umulhi(v, range);
     }
 }
-// usize / i64 call sites: next_u64 = two next_u32 (low word first), 128-bit product
+// usize / i64 call sites: next_u64 = two next_u32 (low word first), 128-bit product.
+// Every 64-bit call site of the engine has range < 2^32 (room counts, cell counts, dice), so the 128-bit product
+// v * range is two 32x32->64 multiplies: lo64 = l*range + ((h*range) << 32), hi64 = (h*range >> 32) + carry, and
+// "lo64 <= zone" with zone = ((range << clz) << 32) - 1 reduces to a compare of the high words.
 __device__ __forceinline__ uint64_t range64(Rng &r, uint64_t low, uint64_t high) {
     uint64_t range = high - low;
+    if ((range >> 32) == 0) {
+        uint32_t rg = (uint32_t)range;
+        uint32_t top = rg << __clz((int)rg);  // zone = (top << 32) - 1
+        for (;;) {
+            uint32_t l = rng_u32(r), h = rng_u32(r);
+            uint32_t p0_hi = __umulhi(l, rg);
+            uint32_t p1_lo = h * rg, p1_hi = __umulhi(h, rg);
+            uint32_t mid = p0_hi + p1_lo;          // bits 32..63 of the low half of the product
+            uint32_t carry = mid < p0_hi ? 1u : 0u;
+            if (mid < top) return low + (uint64_t)(p1_hi + carry);
+        }
+    }
     uint64_t zone = (range << __clzll((long long)range)) - 1ull;
     for (;;) {
         uint64_t l = rng_u32(r), h = rng_u32(r);
@@ -91,6 +106,9 @@ __device__ __forceinline__ uint64_t range64(Rng &r, uint64_t low, uint64_t high)
         if (lo <= zone) return low + __umul64hi(v, range);
     }
 }
+// exact n / d for the small non-negative operands of this engine (n < 2^20, 0 < d < 2^12): one v_rcp instead of the
+// ~30-instruction integer division sequence
+__device__ __forceinline__ int small_div(int n, int d) { return (int)(((float)n + 0.5f) * __frcp_rn((float)d)); }
 __device__ __forceinline__ bool does_happen(Rng &r, uint32_t p_inv) { return range32(r, 0, p_inv) == 0; }
 __device__ __forceinline__ bool parcent(Rng &r, uint32_t p) { return range32(r, 1, 101) <= p; }
 
@@ -133,8 +151,8 @@ __device__ __forceinline__ bool in_bounds(const RgConfig &c, int x, int y) { ret
 
 // Room::assigned_area of room id i (rooms.rs:192-209), half-open
 __device__ __forceinline__ void assigned_area(const RgConfig &c, int i, int &x0, int &y0, int &x1, int &y1) {
-    int rsx = c.width / c.room_num_x, rsy = c.height / c.room_num_y;
-    int cx = i % c.room_num_x, cy = i / c.room_num_x;
+    int rsx = small_div(c.width, c.room_num_x), rsy = small_div(c.height, c.room_num_y);
+    int cy = small_div(i, c.room_num_x), cx = i - cy * c.room_num_x;
     x0 = cx * rsx; x1 = x0 + rsx;
     y0 = cy == 0 ? 1 : cy * rsy;
     y1 = (cy + 1) * rsy;
@@ -142,9 +160,9 @@ __device__ __forceinline__ void assigned_area(const RgConfig &c, int i, int &x0,
 }
 // Floor::cd_to_room_id (floor.rs:194-200): areas are disjoint, so arithmetic replaces the scan
 __device__ __forceinline__ int room_id_of(const RgConfig &c, int x, int y) {
-    int rsx = c.width / c.room_num_x, rsy = c.height / c.room_num_y;
+    int rsx = small_div(c.width, c.room_num_x), rsy = small_div(c.height, c.room_num_y);
     if (y < 1 || x < 0) return -1;
-    int cx = x / rsx, cy = y / rsy;
+    int cx = small_div(x, rsx), cy = small_div(y, rsy);
     if (cx >= c.room_num_x || cy >= c.room_num_y) return -1;
     if ((cy + 1) * rsy == c.height && y == c.height - 1) return -1;
     return cy * c.room_num_x + cx;
@@ -287,7 +305,8 @@ __device__ __forceinline__ bool room_select(const RgState &S, const RgConfig &c,
         if (count <= 0) return false;
         int nth = (int)range64(E.rd, 0, (uint64_t)count);
         if (eo >= 0 && eo <= nth) nth++;
-        out = POS(x0 + 1 + nth % iw, y0 + 1 + nth / iw);
+        int qy = small_div(nth, iw);
+        out = POS(x0 + 1 + (nth - qy * iw), y0 + 1 + qy);
         return true;
     }
     int count = 0;
@@ -423,10 +442,11 @@ __device__ __forceinline__ void paint_corridor(const RgConfig &c, Env &E, uint32
 // select_candidate (passages.rs:69-82): reservoir over grid-neighbour rooms in ascending id
 __device__ __forceinline__ int select_candidate(const RgConfig &c, Env &E, int nrooms, int node, uint32_t excl_mask, int &dir_out) {
     int rnx = c.room_num_x, rny = c.room_num_y;
-    int nx0 = node % rnx, ny0 = node / rnx, res = -1, i = 0;
-    for (int id = 0; id < nrooms; id++) {
+    int ny0 = small_div(node, rnx), nx0 = node - ny0 * rnx, res = -1, i = 0;
+    for (int id = 0, ox = 0, oy = 0; id < nrooms; id++, ox++) {
+        if (ox == rnx) { ox = 0; oy++; }
         if ((excl_mask >> id) & 1) continue;
-        int ox = id % rnx, oy = id / rnx, d;
+        int d;
         if (ox == nx0 && oy == ny0 - 1) d = 0;
         else if (ox == nx0 && oy == ny0 + 1) d = 1;
         else if (oy == ny0 && ox == nx0 - 1) d = 2;
@@ -1549,10 +1569,10 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
     const int tid = threadIdx.x, W = c.width, H = c.height, HW = W * H, n = S.n, Q8 = HW >> 3;
     const int nrooms = c.room_num_x * c.room_num_y;
     const int symbols = c.symbols;
-    if (tid < 128) {
-        uint32_t sy = tile_to_sym((uint32_t)tid);
-        luts[tid] = (uint8_t)sy;
-        lutf[tid] = (float)(uint8_t)sy / (float)(uint8_t)symbols;  // python/src/lib.rs:84 (same single division)
+    for (int g = tid; g < 128; g += blockDim.x) {
+        uint32_t sy = tile_to_sym((uint32_t)g);
+        luts[g] = (uint8_t)sy;
+        lutf[g] = (float)(uint8_t)sy / (float)(uint8_t)symbols;  // python/src/lib.rs:84 (same single division)
     }
     const int le = tid / tpe, lt = tid - le * tpe;
     const int base_planes = KIND ? symbols : 1;
@@ -1758,12 +1778,15 @@ int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, 
     int q8 = hw / 8;
     int tpe = q8 >= OBS_THREADS ? OBS_THREADS : ((q8 + 63) / 64) * 64;  // threads per env: a whole number of waves
     if (tpe > OBS_THREADS) tpe = OBS_THREADS;
-    int epb = OBS_THREADS / tpe;
+    static int bt_env = -1;
+    if (bt_env < 0) { const char *v = getenv("ROGUE_GYM_HIP_OBS_THREADS"); bt_env = v ? atoi(v) : 0; }
+    int bthreads = bt_env >= tpe && bt_env <= OBS_THREADS && bt_env % tpe == 0 ? bt_env : tpe;  // one env per block: no cross-env barrier coupling
+    int epb = bthreads / tpe;
     size_t smem = 512 + 128 + (size_t)epb * OBS_ENV_BYTES(hw);
     int blocks = (S->n + epb - 1) / epb;
-    if (blocks > 32768) blocks = 32768;
-    if (!kind) hipLaunchKernelGGL(k_obs<0>, dim3(blocks), dim3(OBS_THREADS), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb);
-    else hipLaunchKernelGGL(k_obs<1>, dim3(blocks), dim3(OBS_THREADS), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb);
+    if (blocks > 65536) blocks = 65536;
+    if (!kind) hipLaunchKernelGGL(k_obs<0>, dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb);
+    else hipLaunchKernelGGL(k_obs<1>, dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb);
     return 1;
 }
 void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, int symbols,

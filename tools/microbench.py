@@ -93,3 +93,26 @@ def prof(name, cfg, keys_table, n=65536, steps=200, max_steps=1000, do_reset=Fal
 if __name__ == "__main__" and "prof" in sys.argv[1:]:
     prof("k_step mini 11-act", G["configs"]["mini"], b".hjklnbuy>s")
     prof("k_build mini", G["configs"]["mini"], b".", do_reset=True)
+
+
+def single_gen(name, cfg, n=1, reps=200):
+    cfgs = [json.dumps(dict(cfg, seed=i)) for i in range(n)]
+    h = inner._Handle(cfgs, 1000, True)
+    L = h.L
+    for _ in range(20):
+        L.rg_reset(h.h)
+    L.rg_timing_enable(h.h, 1)
+    for _ in range(reps):
+        L.rg_reset(h.h)
+    ms = (C.c_double * 4)()
+    cnt = (C.c_uint64 * 4)()
+    L.rg_timing_read(h.h, ms, cnt)
+    print("%-20s n=%d k_build avg %.1f us" % (name, n, ms[3] / cnt[3] * 1e3), flush=True)
+    h.close()
+
+
+if __name__ == "__main__" and "gen1" in sys.argv[1:]:
+    for n in (1, 2, 8, 64, 64 * 256):
+        single_gen("mini", G["configs"]["mini"], n)
+    single_gen("default", G["configs"]["default"], 1)
+    single_gen("mini-noenemy", dict(G["configs"]["mini"], enemies={"enemies": []}), 1)
