@@ -143,8 +143,8 @@ typedef struct {
     uint8_t *maze_passages;    /* Maze only */
 } room_t;
 
-#define MAX_ROOMS 64
-#define MAX_MON 64
+#define MAX_ROOMS 32
+#define MAX_MON 32
 #define DIST_INF 0xFFFFFFFFu
 #define DIST_CACHE_CAP 10
 
@@ -166,6 +166,7 @@ enum { MSG_HIT_FROM = 1, MSG_HIT_TO = 2, MSG_MISS_TO = 4, MSG_MISS_FROM = 8, MSG
 typedef struct { uint8_t kind, msg; } reaction_t;
 #define RLIST_CAP 2048 /* a run is at most W+H iterations of a few reactions each */
 typedef struct { reaction_t v[RLIST_CAP]; int n; } rlist_t;
+static __thread rlist_t tls_scratch_a, tls_scratch_b; /* reaction lists of the current react (per thread, no per-step malloc) */
 static void rpush(rlist_t *l, int kind, uint32_t msg) { if (l->n < RLIST_CAP) l->v[l->n++] = (reaction_t){(uint8_t)kind, (uint8_t)msg}; }
 
 
@@ -195,7 +196,6 @@ struct orc_env {
     uint32_t status[10];
     uint32_t message;
     int is_terminal;
-    rlist_t scratch_a, scratch_b; /* reaction lists of the current react (no per-step malloc) */
 };
 
 static inline int IDX(const orc_env *e, int x, int y) { return y * e->W + x; }
@@ -1013,7 +1013,7 @@ static int process_action(orc_env *e, int act, int dir, rlist_t *out) {
         break;
     case ACT_MOVE_UNTIL:
         for (;;) {
-            rlist_t *res = &e->scratch_b; res->n = 0;
+            rlist_t *res = &tls_scratch_b; res->n = 0;
             int done = move_player(e, dir, res);
             int id = IDX(e, e->px, e->py);
             uint8_t tile = (e->fl.attr[id] & A_VISIBLE) ? SURFACE_GLYPH[e->fl.surface[id]] : ' '; /* Cell::tile (field.rs:91-98) */
@@ -1144,7 +1144,7 @@ int orc_react(orc_env *e, uint8_t key) {
     int dir = 0, act = key_to_action(key, &dir);
     if (act < 0) return 1;
     if (e->dead) return 2; /* UiState::Mordal + InputCode::Act => IgnoredInput */
-    rlist_t *res = &e->scratch_a; res->n = 0;
+    rlist_t *res = &tls_scratch_a; res->n = 0;
     if (process_action(e, act, dir, res)) e->dead = 1;
     e->message = 0;
     int dead = 0;

@@ -363,13 +363,13 @@ done:
     return rc;
 }
 
-// development aid: in-kernel phase profile (cycles); out[0..31] = max over waves, out[32..63] = sum over waves
+// development aid: in-kernel phase profile (cycles); out[0..31] = max over waves, out[32..63] = sum over waves, out[64..79] = wave-duration histogram
 int rg_prof(rg_t *h, int enable, unsigned long long *out) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (out && h->S.prof) HIPCHK(h, hipMemcpy(out, h->S.prof, 64 * 8, hipMemcpyDeviceToHost));
-    if (enable && !h->S.prof) { if (!dev_alloc(h, &h->S.prof, 64)) return 1; }
-    if (h->S.prof) HIPCHK(h, hipMemset(h->S.prof, 0, 64 * 8));
+    if (out && h->S.prof) HIPCHK(h, hipMemcpy(out, h->S.prof, 128 * 8, hipMemcpyDeviceToHost));
+    if (enable && !h->S.prof) { if (!dev_alloc(h, &h->S.prof, 128)) return 1; }
+    if (h->S.prof) HIPCHK(h, hipMemset(h->S.prof, 0, 128 * 8));
     if (!enable) h->S.prof = nullptr;
     return 0;
 }

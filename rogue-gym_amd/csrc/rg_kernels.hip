@@ -114,8 +114,8 @@ __device__ __forceinline__ bool parcent(Rng &r, uint32_t p) { return range32(r, 
 
 // optional phase profile: lane 0 of every wave folds its elapsed cycles per phase into S.prof (max and sum)
 struct Prof {
-    unsigned long long *p; unsigned long long t;
-    __device__ __forceinline__ void start(unsigned long long *pp) { p = pp; if (p) t = __builtin_amdgcn_s_memtime(); }
+    unsigned long long *p; unsigned long long t, t0;
+    __device__ __forceinline__ void start(unsigned long long *pp) { p = pp; if (p) t = t0 = __builtin_amdgcn_s_memtime(); }
     __device__ __forceinline__ void mark(int phase) {
         if (!p) return;
         unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -1366,6 +1366,11 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
         }
     }
     pf.mark(6);
+    if (pf0.p && lane == 0) {  // histogram of whole-wave durations: 16 buckets of 38400 ticks (16 us @ 2.4 GHz) in prof[64..79]
+        unsigned long long tot = __builtin_amdgcn_s_memtime() - pf0.t0;
+        int b = (int)(tot / 38400ull); if (b > 15) b = 15;
+        atomicAdd(&pf0.p[64 + b], 1ull);
+    }
     if (!valid) return;
     if (err) {
         S.flags[e] = (old_flags & ~RG_FLAG_ERR_MASK) | err;

@@ -71,7 +71,7 @@ def prof(name, cfg, keys_table, n=65536, steps=200, max_steps=1000, do_reset=Fal
     else:
         for t in range(steps):
             L.rg_step(h.h, C.c_void_p(keys[t % 64].data_ptr()), 1)
-    out = (C.c_ulonglong * 64)()
+    out = (C.c_ulonglong * 128)()
     L.rg_prof(h.h, 0, out)
     nw = (n + 63) // 64
     names = {0: "load", 1: "pre-gen", 2: "gen_service", 3: "player+prepass", 4: "bfs", 5: "monsters", 6: "tail", 8: "g.clear", 9: "g.rooms", 10: "g.paint",
@@ -84,6 +84,8 @@ def prof(name, cfg, keys_table, n=65536, steps=200, max_steps=1000, do_reset=Fal
     if ngen:
         print("   per-generation averages (us, ticks/2400): " + "  ".join("%s %.1f" % (names[i][2:], out[32 + i] / ngen / 2400.0) for i in range(8, 16))
               + "  | place+copy %.1f" % ((out[32 + 20] + out[32 + 22]) / ngen / 2400.0 - sum(out[32 + i] for i in range(9, 16)) / ngen / 2400.0))
+    if not do_reset:
+        print("   wave-duration histogram (16 us buckets, waves per launch): " + " ".join("%.0f" % (out[64 + b] / steps) for b in range(16)))
     for nm, k in (("gen (1 lane)", 20), ("gen (>1 lanes)", 22), ("bfs", 24)):
         if out[32 + k + 1]:
             print("   %-16s count/launch %.1f  avg %.1f ticks  max %.1f ticks" % (nm, out[32 + k + 1] / steps, out[32 + k] / out[32 + k + 1], out[k]))
