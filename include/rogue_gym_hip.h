@@ -115,6 +115,11 @@ int rg_timing_read(rg_t *h, double ms[4], uint64_t launches[4]);
 /* GameState::dump_config (python/src/lib.rs:252-254): canonical JSON of env i's effective config. */
 int rg_dump_config(const rg_t *h, int env, char *buf, size_t cap);
 
+/* Stateless: parse one GameConfig JSON (GameConfig::from_json, core/src/lib.rs:144-149) and write its canonical
+ * re-serialisation (GameConfig::to_json with the reference's skip-if-default rules) into buf.  Needs no device.
+ * Returns non-zero and sets rg_last_error(NULL) on a parse / validation error. */
+int rg_config_canonical(const char *cfg_json, char *buf, size_t cap);
+
 /* Parity/debug: synchronous copy of env i's internal state to the host. */
 typedef struct rg_debug_state {
     int32_t px, py, dungeon_level, hp, hp_max, player_level, n_monsters, n_gold;

@@ -411,6 +411,16 @@ int rg_dump_config(const rg_t *h, int env, char *buf, size_t cap) {
     return 0;
 }
 
+int rg_config_canonical(const char *cfg_json, char *buf, size_t cap) {
+    RgParsed p;
+    std::string e = rg_parse_config(cfg_json, &p);
+    if (!e.empty()) { g_create_err = "Failed to parse config: " + e; return 1; }
+    std::string s = rg_dump_config_json(p, p.seed_lo, p.seed_hi, p.has_seed);
+    if (s.size() + 1 > cap) { g_create_err = "buffer too small"; return 1; }
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return 0;
+}
+
 int rg_debug_fetch(rg_t *h, int env, rg_debug_state *out, uint16_t *cells) {
     HIPCHK(h, hipSetDevice(h->device));
     if (env < 0 || env >= h->S.n) { h->err = "env out of range"; return 1; }

@@ -83,9 +83,10 @@ def load_library():
     L.rg_timing_enable.argtypes = [vp, C.c_int]
     L.rg_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rg_dump_config.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
+    L.rg_config_canonical.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     L.rg_debug_fetch.argtypes = [vp, C.c_int, C.POINTER(RgDebugState), vp]
     for f in ("rg_create", "rg_dims", "rg_set_stream", "rg_seed", "rg_reset", "rg_step", "rg_sync", "rg_screen", "rg_hist", "rg_status", "rg_flags",
-              "rg_reward", "rg_done", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_dump_config", "rg_debug_fetch", "rg_timing_enable", "rg_timing_read"):
+              "rg_reward", "rg_done", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_dump_config", "rg_config_canonical", "rg_debug_fetch", "rg_timing_enable", "rg_timing_read"):
         getattr(L, f).restype = C.c_int
     _ = (u8p, i32p, u32p, f32p)
     _lib = L

@@ -87,3 +87,40 @@ def test_python_surface_imports():
     assert ImageSetting().dim(17) == 26
     assert len(RogueEnv.SYMBOLS) == 43
     _ = (rogue_gym, FirstFloorEnv, HipVecRogueEnv, ParallelRogueEnv, StairRewardEnv, StairRewardParallel)
+
+
+def _canon(lib, cfg):
+    buf = C.create_string_buffer(1 << 16)
+    rc = lib.rg_config_canonical(None if cfg is None else json.dumps(cfg).encode(), buf, len(buf))
+    if rc:
+        raise RuntimeError(lib.rg_last_error(None).decode())
+    return json.loads(buf.value.decode())
+
+
+def test_config_canonical_roundtrip(lib, goldens):
+    """GameState.dump_config must satisfy `json.loads(dump) == config_dict` for the reference's test configs
+    (python/tests/test_ff_env.py:22): default-valued sections are skipped, `hide_dungeon` is always written."""
+    assert _canon(lib, goldens["configs"]["ff"]) == goldens["configs"]["ff"]
+    assert _canon(lib, {"seed": 1}) == {"seed": 1, "hide_dungeon": True}
+    assert _canon(lib, None) == {"hide_dungeon": True}
+    st = _canon(lib, goldens["configs"]["st"])
+    assert st["width"] == 32 and st["height"] == 16 and st["seed"] == 5 and st["hide_dungeon"] is False
+    assert st["dungeon"]["room_num_x"] == 2 and st["dungeon"]["style"] == "rogue" and st["enemies"] == {"enemies": []}
+    big = 2**100 + 12345
+    assert _canon(lib, {"seed": big})["seed"] == big                      # u128 seeds survive
+    d = _canon(lib, goldens["configs"]["default"])                          # data/config-default.json == all defaults, seed null
+    assert d == {"hide_dungeon": True}
+    m = _canon(lib, goldens["configs"]["mini"])
+    assert m["dungeon"]["min_room_size"] == {"x": 4, "y": 4} and m["seed"] == 4
+    assert _canon(lib, _canon(lib, goldens["configs"]["st"])) == st        # idempotent
+
+
+def test_config_validation(lib):
+    for bad, frag in [({"dungeon": {"style": "rogue", "room_num_x": 5, "room_num_y": 5}}, "room_num"),
+                      ({"enemies": {"enemies": [99]}}, "builtin"),
+                      ({"enemies": {"enemies": [{"name": "x"}]}}, "builtin"),
+                      ({"dungeon": {"style": "rogue", "dark_level": 0}}, "zero rate"),
+                      ({"width": "wide"}, "width")]:
+        with pytest.raises(RuntimeError) as ei:
+            _canon(lib, bad)
+        assert frag in str(ei.value), (bad, str(ei.value))
