@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-every", type=int, default=8, help="bracket every N-th kernel launch with HIP events (roofline leg)")
     ap.add_argument("--gather-steps", type=int, default=50, help="extra steps timed WITH the observation all-gather (N>1)")
     args = ap.parse_args()
 
@@ -117,7 +118,7 @@ def main():
 
     for t in range(W):
         one_step(t)
-    env._h.check(L.rg_timing_enable(h, 1))
+    env._h.check(L.rg_timing_enable(h, args.time_every))  # HIP-event pairs on the launch stream around every N-th launch
     barrier()
     t0 = time.perf_counter()
     for t in range(K):

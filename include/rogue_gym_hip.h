@@ -108,7 +108,8 @@ int rg_encode_host(int device, const uint8_t *screen, const uint8_t *hist, const
  * While enabled, every rg_step / render flush / rg_obs_* launch is bracketed by an event pair (up to
  * 4096 launches per kernel between reads).  rg_timing_read synchronises, returns the summed elapsed
  * milliseconds and launch counts per kernel {0: k_step, 1: k_render, 2: k_gray|k_symbol, 3: k_build}
- * and clears the accumulators. */
+ * and clears the accumulators.  on = N > 1 brackets only every N-th launch of each kernel (an event pair costs a few
+ * microseconds of stream time). */
 int rg_timing_enable(rg_t *h, int on);
 int rg_timing_read(rg_t *h, double ms[4], uint64_t launches[4]);
 

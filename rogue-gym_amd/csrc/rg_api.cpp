@@ -45,13 +45,18 @@ struct rg_handle {
     bool timing = false;
     std::vector<hipEvent_t> ev[4];   // start/stop pairs
     size_t ev_used[4] = {0, 0, 0, 0};
+    uint64_t timing_seq[4] = {0, 0, 0, 0};
+    uint64_t timing_stride = 1;
 };
 
 #define RG_TIMING_MAX 4096
 struct TimedLaunch {  // brackets one kernel launch with an event pair when timing is on
     rg_handle *h; int k; bool on;
     TimedLaunch(rg_handle *h_, int k_) : h(h_), k(k_), on(false) {
-        if (h->timing && h->ev_used[k] + 2 <= h->ev[k].size()) { on = true; (void)hipEventRecord(h->ev[k][h->ev_used[k]], h->stream); }
+        // sampled: an event pair costs a few us of stream time, so only every `timing_stride`-th launch of a kernel is bracketed
+        if (h->timing && (h->timing_seq[k]++ % h->timing_stride) == 0 && h->ev_used[k] + 2 <= h->ev[k].size()) {
+            on = true; (void)hipEventRecord(h->ev[k][h->ev_used[k]], h->stream);
+        }
     }
     ~TimedLaunch() { if (on) { (void)hipEventRecord(h->ev[k][h->ev_used[k] + 1], h->stream); h->ev_used[k] += 2; } }
 };
@@ -384,6 +389,7 @@ int rg_timing_enable(rg_t *h, int on) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int k = 0; k < 4; k++) h->ev_used[k] = 0;
     h->timing = on != 0;
+    h->timing_stride = on > 1 ? (uint64_t)on : 1;  // on = N > 1: bracket every N-th launch only
     return 0;
 }
 
