@@ -1557,6 +1557,13 @@ __global__ void __launch_bounds__(256) k_symbol(const uint8_t *__restrict__ scre
 // write (Redraw envs), 2 KB observation write.  A block of 256 threads serves `epb` envs, `tpe` threads each;
 // a thread owns 8 consecutive cells (one 16-byte tile load, two float4 stores per plane).
 #define OBS_THREADS 256
+// The observation tensor is a write-once 134 MB stream per step (mini gray): non-temporal stores keep it from evicting the
+// env state (tile grids, mirrors, tables) that the next k_step re-reads from L2 / Infinity Cache.
+__device__ __forceinline__ void store_obs(float4 *p, float4 v) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v nv = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(nv, reinterpret_cast<f4v *>(p));
+}
 struct ObsTabs {  // per-env entity/room tables staged in LDS: every global load of an env is issued up front, in one round trip
     uint32_t rect[RG_MAX_ROOMS], mon[RG_MAX_ROOMS], gold[RG_MAX_ROOMS];
     uint8_t meta[RG_MAX_ROOMS];
@@ -1677,7 +1684,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                     uint32_t b0 = gg[half] & 0x7f, b1 = (gg[half] >> 8) & 0x7f, b2 = (gg[half] >> 16) & 0x7f, b3 = (gg[half] >> 24) & 0x7f;
                     if (KIND == 0) {
                         float4 v; v.x = lutf[b0]; v.y = lutf[b1]; v.z = lutf[b2]; v.w = lutf[b3];
-                        o[2 * i + half] = v;
+                        store_obs(&o[2 * i + half], v);
                     } else {
                         uint32_t s0 = luts[b0], s1 = luts[b1], s2 = luts[b2], s3 = luts[b3];
                         uint32_t smax = (uint32_t)symbols - 1;  // construct_symbol_map fills channels 0..symbols-2 (symbol.rs:51-71)
@@ -1686,7 +1693,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                             float4 v;
                             v.x = s0 == ch ? 1.f : 0.f; v.y = s1 == ch ? 1.f : 0.f; v.z = s2 == ch ? 1.f : 0.f; v.w = s3 == ch ? 1.f : 0.f;
                             if (ch >= smax) v.x = v.y = v.z = v.w = 0.f;
-                            o[(size_t)ch * q4 + 2 * i + half] = v;
+                            store_obs(&o[(size_t)ch * q4 + 2 * i + half], v);
                         }
                     }
                 }
@@ -1695,7 +1702,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                     if (sflag & (1u << b)) {
                         float f = (float)S.status[(size_t)e * 10 + kStatusIdx[b]];
                         float4 sv; sv.x = sv.y = sv.z = sv.w = f;
-                        o[(size_t)p * q4 + 2 * i] = sv; o[(size_t)p * q4 + 2 * i + 1] = sv;
+                        store_obs(&o[(size_t)p * q4 + 2 * i], sv); store_obs(&o[(size_t)p * q4 + 2 * i + 1], sv);
                         p++;
                     }
                 if (with_hist) {
@@ -1703,7 +1710,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                     float4 a, b2;
                     a.x = (h8.x & 0xff) ? 1.f : 0.f; a.y = (h8.x & 0xff00) ? 1.f : 0.f; a.z = (h8.x & 0xff0000) ? 1.f : 0.f; a.w = (h8.x >> 24) ? 1.f : 0.f;
                     b2.x = (h8.y & 0xff) ? 1.f : 0.f; b2.y = (h8.y & 0xff00) ? 1.f : 0.f; b2.z = (h8.y & 0xff0000) ? 1.f : 0.f; b2.w = (h8.y >> 24) ? 1.f : 0.f;
-                    o[(size_t)p * q4 + 2 * i] = a; o[(size_t)p * q4 + 2 * i + 1] = b2;
+                    store_obs(&o[(size_t)p * q4 + 2 * i], a); store_obs(&o[(size_t)p * q4 + 2 * i + 1], b2);
                 }
             }
             if (KIND == 1 && bad) { atomicOr(&S.flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
@@ -1768,7 +1775,12 @@ void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint
 }
 void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
-    int ns = gen_slots(hw, 32 * 1024);
+    // few lanes of a wave refill at a time (~0.4 per wave and step): a small LDS footprint leaves the CU's LDS to the step /
+    // observation kernels this one runs beside
+    static int ns_env = -1;
+    if (ns_env < 0) { const char *v = getenv("ROGUE_GYM_HIP_REGEN_SLOTS"); ns_env = v ? atoi(v) : 0; }
+    int ns = gen_slots(hw, 8 * 1024);
+    if (ns_env > 0) ns = ns_env > WAVE ? WAVE : ns_env;
     size_t smem = (size_t)ns * hw * 2;
     hipLaunchKernelGGL(k_regen, dim3((SP->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *SP, *c, ns);
 }
