@@ -14,6 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "librogue_oracle.so")
 
 
+class OrcMonStat(C.Structure):
+    _fields_ = [("n_attack", C.c_int32), ("att_times", C.c_int32 * 4), ("att_max", C.c_int32 * 4), ("attr", C.c_int32), ("defense", C.c_int32),
+                ("exp", C.c_uint32), ("level", C.c_int32), ("rarity", C.c_int32), ("tile", C.c_int32)]
+
+
 class OrcConfig(C.Structure):
     _fields_ = [
         ("width", C.c_int32), ("height", C.c_int32),
@@ -33,6 +38,7 @@ class OrcConfig(C.Structure):
         ("appear_rate_gold", C.c_uint32), ("appear_rate_nogold", C.c_uint32),
         ("n_enemies", C.c_int32),
         ("enemy_builtin", C.c_int32 * 32),
+        ("enemy_custom", OrcMonStat * 32),
         ("choose_width", C.c_int32),
     ]
 
@@ -127,9 +133,15 @@ def config_from_dict(d, seed=None, choose_width=64):
         ids = en["enemies"]
         c.n_enemies = len(ids)
         for i, v in enumerate(ids):
-            if not isinstance(v, int):
-                raise ValueError("oracle supports builtin enemy presets only")
-            c.enemy_builtin[i] = v
+            if isinstance(v, int):
+                c.enemy_builtin[i] = v
+                continue
+            c.enemy_builtin[i] = -1  # Preset::Custom(Status)
+            m = c.enemy_custom[i]
+            m.n_attack = len(v["attack"])
+            for k, die in enumerate(v["attack"]):
+                m.att_times[k], m.att_max[k] = die["times"], die["max"]
+            m.attr, m.defense, m.exp, m.level, m.rarity, m.tile = v["attr"], v["defense"], v["exp"], v["level"], v["rarelity"], v["tile"]
     if "appear_rate_gold" in en:
         c.appear_rate_gold = en["appear_rate_gold"]
     if "appear_rate_nogold" in en:

@@ -90,7 +90,7 @@ enum { A_VISITED = 1, A_HIDDEN = 2, A_VISIBLE = 4, A_DRAWN = 8, A_LOCKED = 16, A
 /* ------------------------------------------------------------------------------------------ */
 enum { EA_MEAN = 1, EA_FLYING = 2, EA_REGENERATE = 4, EA_GREEDY = 8, EA_INVISIBLE = 16, EA_RUSTS = 32,
        EA_STEAL_GOLD = 64, EA_REDUCE_STR = 128, EA_FREEZES = 256, EA_RANDOM = 512, EA_CONFUSED = 1024 };
-typedef struct { int n_attack; int att_times[3]; int att_max[3]; int attr; int defense; uint32_t exp; int level; int rarity; uint8_t tile; } mstat_t;
+typedef struct { int n_attack; int att_times[4]; int att_max[4]; int attr; int defense; uint32_t exp; int level; int rarity; uint8_t tile; } mstat_t;
 static const mstat_t BUILTIN[26] = {
     /* A aquator   */ {1, {0}, {0}, EA_MEAN | EA_RUSTS, 2 | 8, 20, 5, 12, 'A'},
     /* B bat       */ {1, {1}, {2}, EA_FLYING | EA_RANDOM, 3, 1, 1, 2, 'B'},
@@ -182,7 +182,7 @@ struct orc_env {
     uint8_t **past_visited; int n_past, cap_past; /* past_floors' history maps (rogue/mod.rs:329-338) */
     dcache_t dcache[DIST_CACHE_CAP]; int n_dcache;
     /* enemies */
-    int sorted_stats[32]; int n_stats;    /* builtin ids sorted by rarity (enemies.rs:250-261) */
+    mstat_t stats[32]; int n_stats;       /* monster statuses sorted by rarity (enemies.rs:250-261); mon_t.type indexes this */
     mon_t placed[MAX_MON]; int n_placed;  /* asleep */
     mon_t active[MAX_MON]; int n_active;
     /* player (player.rs:280-306) */
@@ -587,13 +587,13 @@ static int gen_enemy(orc_env *e, uint32_t min, uint32_t max, int64_t lev_add, in
     size_t idx = range32(r, min, max);
     if (idx > len) { size_t rg = len < 5 ? len : 5; idx = (size_t)range64(r, len - rg, len); }
     if (idx >= len) return 0; /* enemy_stats.get(idx)? */
-    const mstat_t *st = &BUILTIN[e->sorted_stats[idx]];
+    const mstat_t *st = &e->stats[idx];
     int64_t level = st->level + lev_add, hp = 0;
     for (int i = 0; i < 8; i++) hp += (int64_t)range64(r, 1, (uint64_t)level + 1); /* Dice::new(8, level).exec::<i64> */
     int64_t base = level == 1 ? hp / 8 : hp / 6;
     uint32_t exp_add = level >= 10 ? (uint32_t)base * 20u : (uint32_t)base * 4u;
     memset(out, 0, sizeof *out);
-    out->type = e->sorted_stats[idx];
+    out->type = (int)idx;
     out->level = level; out->hp = out->max_hp = hp;
     out->defense = st->defense - (int)lev_add;
     out->exp = st->exp + (uint32_t)(lev_add * 10) + exp_add;
@@ -649,7 +649,7 @@ static int activate_at(orc_env *e, int x, int y) {
 static void activate_area(orc_env *e, const rect_t *area) {
     int xs[MAX_MON], ys[MAX_MON], n = 0;
     for (int k = 0; k < e->n_placed; k++)
-        if (rect_contains(area, e->placed[k].x, e->placed[k].y) && (BUILTIN[e->placed[k].type].attr & EA_MEAN)) { xs[n] = e->placed[k].x; ys[n++] = e->placed[k].y; }
+        if (rect_contains(area, e->placed[k].x, e->placed[k].y) && (e->stats[e->placed[k].type].attr & EA_MEAN)) { xs[n] = e->placed[k].x; ys[n++] = e->placed[k].y; }
     for (int i = 0; i < n; i++) activate_at(e, xs[i], ys[i]);
 }
 /* Floor::with_current_room / enters_room / leaves_room (floor.rs:201-261) */
@@ -876,7 +876,7 @@ static int move_active_enemies(orc_env *e, rlist_t *res) {
     for (int i = 0; i < n; i++) {
         mon_t m = tmp[i];
         int nx = m.x, ny = m.y, ox = 0, oy = 0, r;
-        int attr = BUILTIN[m.type].attr;
+        int attr = e->stats[m.type].attr;
         /* (rng.does_happen(2) && is_random) || (!rng.does_happen(5) && is_confused) */
         int random_move = 0;
         if (does_happen(&e->rng_e, 2) && (attr & EA_RANDOM)) random_move = 1;
@@ -891,7 +891,7 @@ static int move_active_enemies(orc_env *e, rlist_t *res) {
     if (n_att > 0) e->quiet = 0; /* player.buttle() */
     int did_hit = 0;
     for (int i = 0; i < n_att; i++) {
-        const mon_t *m = &attackers[i]; const mstat_t *st = &BUILTIN[m->type];
+        const mon_t *m = &attackers[i]; const mstat_t *st = &e->stats[m->type];
         uint32_t rate = attack_rate(m->level, ARMOR_DEF, hit_prob_plus(ENEMY_STR));
         int64_t dam_plus = damage_plus(ENEMY_STR) + damage_plus(PLAYER_STR), sum = 0; int hit = 0;
         for (int k = 0; k < st->n_attack; k++) {
@@ -1049,7 +1049,7 @@ static void draw_screen(const orc_env *e, uint8_t *map) {
         const mon_t *m = mon_at(e, x, y, NULL);
         if (m) {
             int dx = e->px - x, dy = e->py - y;
-            if (dx * dx + dy * dy <= 2 || in_same_room(e, e->px, e->py, x, y)) map[id] = BUILTIN[m->type].tile;
+            if (dx * dx + dy * dy <= 2 || in_same_room(e, e->px, e->py, x, y)) map[id] = e->stats[m->type].tile;
         }
     }
 }
@@ -1090,11 +1090,20 @@ static void runtime_build(orc_env *e) {
     rng_seed(&e->rng_d, c->seed_lo, c->seed_hi);  /* rogue::Dungeon::new (rogue/mod.rs:417) */
     /* EnemyHandler::new: stable sort by rarity (enemies.rs:250-261) */
     e->n_stats = c->n_enemies;
-    for (int i = 0; i < e->n_stats; i++) e->sorted_stats[i] = c->enemy_builtin[i];
-    for (int i = 1; i < e->n_stats; i++) { /* insertion sort = stable */
-        int v = e->sorted_stats[i], j = i;
-        while (j > 0 && BUILTIN[e->sorted_stats[j - 1]].rarity > BUILTIN[v].rarity) { e->sorted_stats[j] = e->sorted_stats[j - 1]; j--; }
-        e->sorted_stats[j] = v;
+    for (int i = 0; i < e->n_stats; i++) {
+        if (c->enemy_builtin[i] >= 0) e->stats[i] = BUILTIN[c->enemy_builtin[i]];
+        else {
+            const orc_monstat *q = &c->enemy_custom[i]; mstat_t *t = &e->stats[i];
+            memset(t, 0, sizeof *t);
+            t->n_attack = q->n_attack;
+            for (int k = 0; k < 4; k++) { t->att_times[k] = q->att_times[k]; t->att_max[k] = q->att_max[k]; }
+            t->attr = q->attr; t->defense = q->defense; t->exp = q->exp; t->level = q->level; t->rarity = q->rarity; t->tile = (uint8_t)q->tile;
+        }
+    }
+    for (int i = 1; i < e->n_stats; i++) { /* insertion sort = stable, like Vec::sort_by_key */
+        mstat_t v = e->stats[i]; int j = i;
+        while (j > 0 && e->stats[j - 1].rarity > v.rarity) { e->stats[j] = e->stats[j - 1]; j--; }
+        e->stats[j] = v;
     }
     e->level = 0;
     new_level_(e, 1);
@@ -1114,7 +1123,10 @@ static void mirror_reset(orc_env *e) { /* PlayerState::reset (python/src/lib.rs:
 static int symbols_of(const orc_config *c) { /* GameConfig::symbol_max (core/src/lib.rs:150-155) + 1 */
     if (c->n_enemies == 0) return 17;
     int mx = 0;
-    for (int i = 0; i < c->n_enemies; i++) if (BUILTIN[c->enemy_builtin[i]].tile > mx) mx = BUILTIN[c->enemy_builtin[i]].tile;
+    for (int i = 0; i < c->n_enemies; i++) {
+        int t = c->enemy_builtin[i] >= 0 ? BUILTIN[c->enemy_builtin[i]].tile : c->enemy_custom[i].tile;
+        if (t > mx) mx = t;
+    }
     return mx - 'A' + 17 + 1;
 }
 orc_env *orc_new(const orc_config *cfg, uint64_t max_steps) {
@@ -1199,7 +1211,7 @@ int orc_monsters(const orc_env *e, orc_monster *out, int cap) {
         all[j] = v; act[j] = a;
     }
     for (int i = 0; i < n && i < cap; i++) {
-        out[i].x = all[i].x; out[i].y = all[i].y; out[i].type = all[i].type; out[i].active = act[i]; out[i].running = all[i].running;
+        out[i].x = all[i].x; out[i].y = all[i].y; out[i].type = e->stats[all[i].type].tile - 'A'; out[i].active = act[i]; out[i].running = all[i].running;
         out[i].hp = all[i].hp; out[i].max_hp = all[i].max_hp; out[i].level = all[i].level; out[i].defense = all[i].defense; out[i].exp = all[i].exp;
     }
     return n;

@@ -23,6 +23,14 @@
 extern "C" {
 #endif
 
+/* a custom monster status (Preset::Custom(Status), character/enemies.rs:87-121) */
+typedef struct orc_monstat {
+    int32_t n_attack, att_times[4], att_max[4];
+    int32_t attr, defense;
+    uint32_t exp;
+    int32_t level, rarity, tile;
+} orc_monstat;
+
 /* Flat config (the test harness parses the JSON; the oracle stays JSON-free).
  * Field defaults: core/src/lib.rs:134-140, dungeon/rogue/mod.rs:23-134,
  * character/enemies.rs:56-85, character/player.rs:37-66, item/gold.rs:27-52. */
@@ -39,7 +47,8 @@ typedef struct orc_config {
     int64_t init_hp;
     uint32_t appear_rate_gold, appear_rate_nogold;
     int32_t n_enemies;          /* number of entries of enemy_builtin in use (0 = no enemies) */
-    int32_t enemy_builtin[32];  /* indices into BUILTIN_ENEMIES (enemies.rs:474-761) */
+    int32_t enemy_builtin[32];  /* indices into BUILTIN_ENEMIES (enemies.rs:474-761), or -1: use enemy_custom[i] */
+    orc_monstat enemy_custom[32];
     int32_t choose_width;       /* 64 (what reproduces the goldens) or 32; SliceRandom::choose */
 } orc_config;
 
@@ -70,7 +79,7 @@ void orc_flags(const orc_env *e, uint32_t out[5]);
 
 /* ---- internal state, for deep GPU==oracle comparison ---- */
 typedef struct orc_monster {
-    int32_t x, y, type /* builtin index */, active, running;
+    int32_t x, y, type /* glyph - 'A' (= builtin index for builtin monsters) */, active, running;
     int64_t hp, max_hp, level;
     int32_t defense;
     uint32_t exp;

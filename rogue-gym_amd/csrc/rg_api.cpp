@@ -455,7 +455,7 @@ int rg_debug_fetch(rg_t *h, int env, rg_debug_state *out, uint16_t *cells) {
     }
     for (int i = 1; i < cnt; i++) { M v = ms[i]; int j = i; while (j > 0 && (ms[j - 1].w & 0xffff) > (v.w & 0xffff)) { ms[j] = ms[j - 1]; j--; } ms[j] = v; }
     for (int i = 0; i < cnt; i++) {
-        out->mon_x[nm] = (ms[i].w >> 8) & 0xff; out->mon_y[nm] = ms[i].w & 0xff; out->mon_type[nm] = (ms[i].w >> 16) & 0xff;
+        out->mon_x[nm] = (ms[i].w >> 8) & 0xff; out->mon_y[nm] = ms[i].w & 0xff; out->mon_type[nm] = h->cfg.mon[(ms[i].w >> 16) & 0xff].tile - 'A';  /* reported as glyph index so builtin monsters keep their builtin id */
         out->mon_active[nm] = ((ms[i].w >> 24) & MF_ACTIVE) ? 1 : 0; out->mon_hp[nm] = ms[i].hp; out->mon_exp[nm] = ms[i].exp; nm++;
     }
     out->n_monsters = nm;

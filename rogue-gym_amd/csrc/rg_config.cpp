@@ -113,13 +113,52 @@ bool get_int(Ctx &c, const JVal *o, const char *key, int64_t lo, int64_t hi, int
 #define GET_U32(obj, key, field) do { int64_t t_ = (field); if (!get_int(c, obj, key, 0, 0xffffffffLL, &t_)) return c.err; (field) = (uint32_t)t_; } while (0)
 #define GET_I32(obj, key, field) do { int64_t t_ = (field); if (!get_int(c, obj, key, -0x80000000LL, 0x7fffffffLL, &t_)) return c.err; (field) = (int32_t)t_; } while (0)
 
-// rarity of BUILTIN_ENEMIES[i] (enemies.rs:474-761), tile = 'A' + i
-const uint8_t BUILTIN_RARITY[26] = {12, 2, 10, 25, 1, 15, 23, 4, 5, 24, 0, 9, 21, 13, 7, 18, 11, 6, 3, 16, 20, 22, 17, 19, 14, 8};
+// BUILTIN_ENEMIES (character/enemies.rs:474-761), index = tile - 'A'
+struct Builtin { const char *name; uint32_t exp; int defense; int level; int attr; int rarity; uint32_t gold; int n_att; int att[3][2]; };
+const Builtin BUILTIN[26] = {
+    {"aquator", 20, 2 | 8, 5, 1 | 32, 12, 0, 1, {{0, 0}}},
+    {"bat", 1, 3, 1, 2 | 512, 2, 0, 1, {{1, 2}}},
+    {"centaur", 17, 4, 4, 0, 10, 15, 3, {{1, 2}, {1, 5}, {1, 5}}},
+    {"dragon", 5000, 3, 10, 1, 25, 100, 3, {{1, 8}, {1, 8}, {3, 10}}},
+    {"emu", 2, 7, 1, 1, 1, 0, 1, {{1, 2}}},
+    {"venus flytrap", 80, 3, 8, 1, 15, 0, 0, {{0, 0}}},
+    {"griffin", 2000, 2, 13, 2 | 1 | 4, 23, 20, 2, {{4, 3}, {3, 5}}},
+    {"hobgoblin", 3, 5, 1, 1, 4, 0, 1, {{1, 8}}},
+    {"icemonster", 5, 9, 1, 256, 5, 0, 1, {{0, 0}}},
+    {"jabberwock", 3000, 6, 15, 0, 24, 70, 2, {{2, 12}, {2, 4}}},
+    {"kestrel", 1, 7, 1, 1, 0, 0, 1, {{1, 4}}},
+    {"leperachaun", 10, 8, 3, 64, 9, 0, 1, {{1, 1}}},
+    {"medusa", 200, 2, 8, 1, 21, 40, 3, {{3, 4}, {3, 4}, {2, 5}}},
+    {"nymph", 37, 9, 3, 0, 13, 100, 1, {{0, 0}}},
+    {"orc", 5, 6, 1, 8, 7, 15, 1, {{1, 8}}},
+    {"phantom", 120, 3, 8, 16, 18, 0, 1, {{4, 4}}},
+    {"quagga", 15, 3, 3, 1, 11, 0, 2, {{1, 5}, {1, 5}}},
+    {"rattlesnake", 9, 3, 2, 128 | 1, 6, 0, 1, {{1, 6}}},
+    {"snake", 2, 5, 1, 1, 3, 0, 1, {{1, 3}}},
+    {"troll", 120, 4, 6, 1 | 4, 16, 50, 3, {{1, 8}, {1, 8}, {2, 6}}},
+    {"urvile", 190, -2, 7, 1, 20, 0, 3, {{1, 9}, {1, 9}, {2, 9}}},
+    {"vampire", 350, 1, 8, 1 | 4, 22, 20, 1, {{1, 19}}},
+    {"wraith", 55, 4, 5, 0, 17, 0, 1, {{1, 6}}},
+    {"xeroc", 100, 7, 7, 0, 19, 30, 1, {{4, 4}}},
+    {"yeti", 50, 6, 4, 0, 14, 30, 2, {{1, 6}, {1, 6}}},
+    {"zombie", 6, 8, 2, 1, 8, 0, 1, {{1, 8}}},
+};
+void fill_builtin(RgParsed *p, int slot, int id) {
+    RgMonStat &m = p->presets[slot];
+    memset(&m, 0, sizeof m);
+    const Builtin &b = BUILTIN[id];
+    m.exp = b.exp; m.defense = b.defense; m.level = (int16_t)b.level; m.attr = (uint16_t)b.attr; m.tile = (uint8_t)('A' + id);
+    m.rarity = (uint8_t)b.rarity; m.n_att = (uint8_t)b.n_att;
+    for (int k = 0; k < b.n_att; k++) { m.att[k][0] = (uint8_t)b.att[k][0]; m.att[k][1] = (uint8_t)b.att[k][1]; }
+    p->preset_builtin[slot] = id; p->preset_name[slot] = b.name; p->preset_gold[slot] = b.gold;
+}
 const uint32_t DEFAULT_EXPS[21] = {10, 20, 40, 80, 160, 320, 640, 1300, 2600, 5200, 13000, 26000, 50000, 100000,
                                    200000, 400000, 800000, 2000000, 4000000, 8000000, 0xFFFFFFFFu};
 
 void set_defaults(RgParsed *p) {
-    memset(p, 0, sizeof *p);
+    memset(&p->cfg, 0, sizeof p->cfg);
+    p->has_seed = p->has_seed_range = p->enemies_given = false;
+    p->seed_lo = p->seed_hi = 0; p->seed_range[0] = p->seed_range[1] = 0;
     RgConfig &c = p->cfg;
     c.width = 80; c.height = 24; c.hide_dungeon = 1;
     c.room_num_x = 3; c.room_num_y = 3; c.min_room_x = 4; c.min_room_y = 4;
@@ -129,8 +168,8 @@ void set_defaults(RgParsed *p) {
     c.gold_rate_inv = 2; c.gold_base = 50; c.gold_per_level = 10; c.gold_minimum = 2;
     c.hunger_time = 1300; c.init_hp = 12;
     c.appear_rate_gold = 80; c.appear_rate_nogold = 25;
-    p->n_enemy_ids = 26;
-    for (int i = 0; i < 26; i++) p->enemy_ids[i] = i;
+    p->n_presets = 26;
+    for (int i = 0; i < 26; i++) fill_builtin(p, i, i);
     memcpy(c.level_exps, DEFAULT_EXPS, sizeof DEFAULT_EXPS);
     c.n_level_exps = 21;
 }
@@ -151,16 +190,17 @@ std::string finish(RgParsed *p) {
         c.max_extra_edges == 0 || c.door_unlock_rate_inv == 0 || c.passage_unlock_rate_inv == 0 || c.gold_rate_inv == 0)
         return "Invalid Setting: zero rate (the reference asserts `invalid range!!`)";
     // EnemyHandler::new: stable sort by rarity
-    c.n_enemies = p->n_enemy_ids;
-    for (int i = 0; i < c.n_enemies; i++) c.enemy_sorted[i] = (uint8_t)p->enemy_ids[i];
-    for (int i = 1; i < c.n_enemies; i++) {
-        uint8_t v = c.enemy_sorted[i]; int j = i;
-        while (j > 0 && BUILTIN_RARITY[c.enemy_sorted[j - 1]] > BUILTIN_RARITY[v]) { c.enemy_sorted[j] = c.enemy_sorted[j - 1]; j--; }
-        c.enemy_sorted[j] = v;
+    c.n_enemies = p->n_presets;
+    memset(c.mon, 0, sizeof c.mon);
+    for (int i = 0; i < c.n_enemies; i++) c.mon[i] = p->presets[i];
+    for (int i = 1; i < c.n_enemies; i++) {  // insertion sort = stable, like Vec::sort_by_key
+        RgMonStat v = c.mon[i]; int j = i;
+        while (j > 0 && c.mon[j - 1].rarity > v.rarity) { c.mon[j] = c.mon[j - 1]; j--; }
+        c.mon[j] = v;
     }
     // GameConfig::symbol_max (+1): max enemy tile, or 'A' decremented when there are none
     int mx = -1;
-    for (int i = 0; i < c.n_enemies; i++) if (p->enemy_ids[i] > mx) mx = p->enemy_ids[i];
+    for (int i = 0; i < c.n_enemies; i++) if (p->presets[i].tile - 'A' > mx) mx = p->presets[i].tile - 'A';
     c.symbols = mx < 0 ? 17 : mx + 17 + 1;
     return "";
 }
@@ -243,13 +283,43 @@ std::string rg_parse_config(const char *json, RgParsed *out) {
         if (en->kind != JVal::Obj) return "invalid type for `enemies`";
         if (const JVal *l = en->get("enemies")) {
             if (l->kind != JVal::Arr) return "invalid type for `enemies.enemies`, expected a sequence";
-            if (l->arr.size() > RG_MAX_ENEMY_KINDS) return "too many enemy presets";
+            if (l->arr.size() > RG_MAX_ENEMY_KINDS + 6) return "too many enemy presets (at most 32)";
             out->enemies_given = true;
-            out->n_enemy_ids = 0;
+            out->n_presets = 0;
             for (auto &x : l->arr) {
-                if (x.kind != JVal::Num || !x.is_int || x.neg || x.mag > 25)
-                    return "enemy presets must be builtin indices 0..=25 (custom monster statuses are not supported by the HIP stepper yet)";
-                out->enemy_ids[out->n_enemy_ids++] = (int)x.mag;
+                int slot = out->n_presets;
+                if (x.kind == JVal::Num && x.is_int && !x.neg) {  // Preset::Builtin(usize)
+                    if (x.mag > 25) return "enemy preset index out of range (builtin monsters are 0..=25)";
+                    fill_builtin(out, slot, (int)x.mag);
+                } else if (x.kind == JVal::Obj) {  // Preset::Custom(Status) (enemies.rs:110-121)
+                    RgMonStat &m = out->presets[slot];
+                    memset(&m, 0, sizeof m);
+                    int64_t attr = 0, defense = 0, exp = 0, gold = 0, level = 0, tile = 0, rarity = 0;
+                    for (const char *k : {"attack", "attr", "defense", "exp", "gold", "level", "name", "tile", "rarelity"})
+                        if (!x.get(k)) return std::string("custom enemy status: missing field `") + k + "`";
+                    if (!get_int(c, &x, "attr", 0, 0xffff, &attr) || !get_int(c, &x, "defense", -1000, 1000, &defense) ||
+                        !get_int(c, &x, "exp", 0, 0xffffffffLL, &exp) || !get_int(c, &x, "gold", 0, 0xffffffffLL, &gold) ||
+                        !get_int(c, &x, "level", 1, 1000, &level) || !get_int(c, &x, "tile", 'A', 'Z', &tile) ||
+                        !get_int(c, &x, "rarelity", 0, 255, &rarity))
+                        return "custom enemy status: " + c.err + " (tile must be 'A'..'Z' = 65..90)";
+                    const JVal *nm = x.get("name");
+                    if (nm->kind != JVal::Str) return "custom enemy status: invalid type for `name`";
+                    const JVal *at = x.get("attack");
+                    if (at->kind != JVal::Arr || at->arr.size() > 4) return "custom enemy status: `attack` must be a sequence of at most 4 dice";
+                    for (size_t k = 0; k < at->arr.size(); k++) {
+                        int64_t times = 0, mx = 0;
+                        if (at->arr[k].kind != JVal::Obj || !at->arr[k].get("times") || !at->arr[k].get("max") ||
+                            !get_int(c, &at->arr[k], "times", 0, 255, &times) || !get_int(c, &at->arr[k], "max", 0, 255, &mx))
+                            return "custom enemy status: each attack die needs `times` and `max` in 0..=255";
+                        if (times > 0 && mx < 1) return "custom enemy status: a die that is rolled needs max >= 1";
+                        m.att[k][0] = (uint8_t)times; m.att[k][1] = (uint8_t)mx;
+                    }
+                    m.n_att = (uint8_t)at->arr.size();
+                    m.attr = (uint16_t)attr; m.defense = (int32_t)defense; m.exp = (uint32_t)exp; m.level = (int16_t)level;
+                    m.tile = (uint8_t)tile; m.rarity = (uint8_t)rarity;
+                    out->preset_builtin[slot] = -1; out->preset_name[slot] = nm->s; out->preset_gold[slot] = (uint32_t)gold;
+                } else return "invalid enemy preset: expected a builtin index or a status object";
+                out->n_presets++;
             }
         }
         GET_U32(en, "appear_rate_gold", g.appear_rate_gold);
@@ -301,12 +371,21 @@ std::string rg_dump_config_json(const RgParsed &p, uint64_t seed_lo, uint64_t se
         sep();
         s += "\"player\": {\"hunger_time\": " + std::to_string(c.hunger_time) + ", \"init_hp\": " + std::to_string(c.init_hp) + "}";
     }
-    bool en_default = p.n_enemy_ids == 26;
-    for (int i = 0; en_default && i < 26; i++) en_default = p.enemy_ids[i] == i;
+    bool en_default = p.n_presets == 26;
+    for (int i = 0; en_default && i < 26; i++) en_default = p.preset_builtin[i] == i;
     if (!en_default || c.appear_rate_gold != 80 || c.appear_rate_nogold != 25) {
         sep();
         s += "\"enemies\": {\"enemies\": [";
-        for (int i = 0; i < p.n_enemy_ids; i++) { if (i) s += ", "; s += std::to_string(p.enemy_ids[i]); }
+        for (int i = 0; i < p.n_presets; i++) {
+            if (i) s += ", ";
+            if (p.preset_builtin[i] >= 0) { s += std::to_string(p.preset_builtin[i]); continue; }
+            const RgMonStat &m = p.presets[i];
+            s += "{\"attack\": [";
+            for (int k = 0; k < m.n_att; k++) s += std::string(k ? ", " : "") + "{\"times\": " + std::to_string(m.att[k][0]) + ", \"max\": " + std::to_string(m.att[k][1]) + "}";
+            s += "], \"attr\": " + std::to_string(m.attr) + ", \"defense\": " + std::to_string(m.defense) + ", \"exp\": " + std::to_string(m.exp) +
+                 ", \"gold\": " + std::to_string(p.preset_gold[i]) + ", \"level\": " + std::to_string(m.level) + ", \"name\": \"" + p.preset_name[i] +
+                 "\", \"tile\": " + std::to_string(m.tile) + ", \"rarelity\": " + std::to_string(m.rarity) + "}";
+        }
         s += "]";
         if (c.appear_rate_gold != 80) s += ", \"appear_rate_gold\": " + std::to_string(c.appear_rate_gold);
         if (c.appear_rate_nogold != 25) s += ", \"appear_rate_nogold\": " + std::to_string(c.appear_rate_nogold);

@@ -11,6 +11,19 @@
 #define RG_MIN_H 16
 #define RG_DIST_SLOTS 9     // DistCache holds up to 9 maps (rogue/mod.rs:492-518)
 
+// One monster status (character/enemies.rs:110-121): a builtin preset or a custom one from the config
+struct RgMonStat {
+    uint32_t exp;
+    int32_t defense;
+    int16_t level;
+    uint16_t attr;          // EnemyAttr bits (enemies.rs:126-139)
+    uint8_t tile;           // glyph 'A'..'Z'
+    uint8_t rarity;
+    uint8_t n_att;          // attack dice in use (<= 4)
+    uint8_t att[4][2];      // {times, max} per die
+    uint8_t pad;
+};
+
 // Everything the device code needs; identical for all envs of a handle (seeds are per-env arrays).
 struct RgConfig {
     int32_t width, height;
@@ -24,7 +37,7 @@ struct RgConfig {
     int32_t init_hp;
     uint32_t appear_rate_gold, appear_rate_nogold;
     int32_t n_enemies;                            // length of the rarity-sorted table
-    uint8_t enemy_sorted[RG_MAX_ENEMY_KINDS + 6]; // builtin ids, stable-sorted by rarity (enemies.rs:250-261)
+    RgMonStat mon[RG_MAX_ENEMY_KINDS + 6];        // monster statuses, stable-sorted by rarity (enemies.rs:250-261)
     uint32_t level_exps[21];                      // Leveling::exps (player.rs:308-343)
     int32_t n_level_exps;
     int32_t symbols;                              // symbol_max + 1 (core/src/lib.rs:150-155)
@@ -38,8 +51,11 @@ struct RgParsed {
     uint64_t seed_lo, seed_hi;
     bool has_seed_range;
     unsigned __int128 seed_range[2];
-    int enemy_ids[RG_MAX_ENEMY_KINDS + 6]; // as given (unsorted), for dump_config
-    int n_enemy_ids;
+    RgMonStat presets[RG_MAX_ENEMY_KINDS + 6];   // as given (unsorted), for dump_config
+    int preset_builtin[RG_MAX_ENEMY_KINDS + 6];  // builtin index, or -1 for a custom status
+    std::string preset_name[RG_MAX_ENEMY_KINDS + 6];
+    uint32_t preset_gold[RG_MAX_ENEMY_KINDS + 6];
+    int n_presets;
     bool enemies_given;
 };
 

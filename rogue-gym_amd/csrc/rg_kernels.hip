@@ -29,21 +29,11 @@ __device__ __constant__ int8_t kDY[9] = {-1, 1, 0, 0, -1, -1, 1, 1, 0};
 // would be a memory load per cell)
 __device__ __forceinline__ uint32_t glyph_of(uint32_t surface) { return (uint32_t)(0x205E2B257C2D2E23ull >> (8 * (surface & 7))) & 0xffu; }
 
-// BUILTIN_ENEMIES (character/enemies.rs:474-761), index = tile - 'A'
+// monster statuses come from the config (RgConfig::mon, rarity-sorted): builtin presets (character/enemies.rs:474-761)
+// or custom ones; a monster's `type` is its index in that table
 #define EA_MEAN 1
 #define EA_RANDOM 512
 #define EA_CONFUSED 1024
-__device__ __constant__ uint16_t kMonAttr[26] = {1 | 32, 2 | 512, 0, 1, 1, 1, 2 | 1 | 4, 1, 256, 0, 1, 64, 1, 0, 8, 16, 1, 128 | 1, 1, 1 | 4, 1, 1 | 4, 0, 0, 0, 1};
-__device__ __constant__ int8_t kMonDef[26] = {2 | 8, 3, 4, 3, 7, 3, 2, 5, 9, 6, 7, 8, 2, 9, 6, 3, 3, 3, 5, 4, -2, 1, 4, 7, 6, 8};
-__device__ __constant__ uint16_t kMonExp[26] = {20, 1, 17, 5000, 2, 80, 2000, 3, 5, 3000, 1, 10, 200, 37, 5, 120, 15, 9, 2, 120, 190, 350, 55, 100, 50, 6};
-__device__ __constant__ uint8_t kMonLevel[26] = {5, 1, 4, 10, 1, 8, 13, 1, 1, 15, 1, 3, 8, 3, 1, 8, 3, 2, 1, 6, 7, 8, 5, 7, 4, 2};
-__device__ __constant__ uint8_t kMonNAtt[26] = {1, 1, 3, 3, 1, 0, 2, 1, 1, 2, 1, 1, 3, 1, 1, 1, 2, 1, 1, 3, 3, 1, 1, 1, 2, 1};
-// attack dice (times, max) x3
-__device__ __constant__ uint8_t kMonAtt[26][6] = {
-    {0, 0, 0, 0, 0, 0}, {1, 2, 0, 0, 0, 0}, {1, 2, 1, 5, 1, 5}, {1, 8, 1, 8, 3, 10}, {1, 2, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {4, 3, 3, 5, 0, 0},
-    {1, 8, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {2, 12, 2, 4, 0, 0}, {1, 4, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0}, {3, 4, 3, 4, 2, 5}, {0, 0, 0, 0, 0, 0},
-    {1, 8, 0, 0, 0, 0}, {4, 4, 0, 0, 0, 0}, {1, 5, 1, 5, 0, 0}, {1, 6, 0, 0, 0, 0}, {1, 3, 0, 0, 0, 0}, {1, 8, 1, 8, 2, 6}, {1, 9, 1, 9, 2, 9},
-    {1, 19, 0, 0, 0, 0}, {1, 6, 0, 0, 0, 0}, {4, 4, 0, 0, 0, 0}, {1, 6, 1, 6, 0, 0}, {1, 8, 0, 0, 0, 0}};
 
 // Symbol::from_tile (core/src/symbol.rs:17-40); 255 = not a symbol
 __device__ __forceinline__ uint32_t tile_to_sym(uint32_t t) {
@@ -220,7 +210,7 @@ __device__ __forceinline__ void activate_room(const RgState &S, const RgConfig &
         uint32_t w = S.mon_w0[s * E.n + E.e];
         uint32_t fl = w >> 24;
         if (!(fl & MF_ALIVE) || (fl & MF_ACTIVE)) continue;
-        if (!(kMonAttr[(w >> 16) & 0xff] & EA_MEAN)) continue;
+        if (!(c.mon[(w >> 16) & 0xff].attr & EA_MEAN)) continue;
         if (room_id_of(c, POS_X(w), POS_Y(w)) != rid) continue;
         S.mon_w0[s * E.n + E.e] = w | (MF_ACTIVE << 24);
         E.mon_active++;
@@ -638,14 +628,14 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
             uint32_t idx = range32(E.re, mn, mx);
             if (idx > len) { uint32_t rg = len < 5 ? len : 5; idx = (uint32_t)range64(E.re, len - rg, len); }
             if (idx >= len) continue;
-            uint32_t type = c.enemy_sorted[idx];
-            int64_t mlevel = (int64_t)kMonLevel[type] + lev_add, hp = 0;
+            uint32_t type = idx;
+            int64_t mlevel = (int64_t)c.mon[type].level + lev_add, hp = 0;
             for (int k = 0; k < 8; k++) hp += (int64_t)range64(E.re, 1, (uint64_t)mlevel + 1);
             int64_t base = mlevel == 1 ? hp / 8 : hp / 6;
             uint32_t exp_add = mlevel >= 10 ? (uint32_t)base * 20u : (uint32_t)base * 4u;
             S.mon_w0[i * n + e] = pos | (type << 16) | ((uint32_t)MF_ALIVE << 24);
             S.mon_hp[i * n + e] = (int32_t)hp;
-            S.mon_exp[i * n + e] = (uint32_t)kMonExp[type] + lev_add * 10u + exp_add;
+            S.mon_exp[i * n + e] = c.mon[type].exp + lev_add * 10u + exp_add;
             E.mon_alive++;
         }
     }
@@ -1029,7 +1019,7 @@ __device__ __forceinline__ void player_attack(const RgState &S, const RgConfig &
     E.quiet = 0;
     if (!((w >> 24) & MF_ACTIVE)) { w |= (uint32_t)MF_ACTIVE << 24; E.mon_active++; S.mon_w0[idx] = w; }
     uint32_t type = (w >> 16) & 0xff;
-    int64_t def = (int64_t)kMonDef[type] - (int64_t)lev_add_of(c, E.dlevel);
+    int64_t def = (int64_t)c.mon[type].defense - (int64_t)lev_add_of(c, E.dlevel);
     uint32_t rate = attack_rate(E.plvl, def, 1);
     if (parcent(E.re, rate)) {
         int dmg = (int)range64(E.re, 1, 5);
@@ -1131,7 +1121,7 @@ __device__ __forceinline__ bool monsters_prepass(const RgState &S, const RgConfi
     bool need_map = false;
     int last = -1, slot;
     while ((last = next_pending(S, E, nrooms, last, slot)) >= 0) {
-        uint32_t attr = kMonAttr[(S.mon_w0[slot * E.n + E.e] >> 16) & 0xff];
+        uint32_t attr = c.mon[(S.mon_w0[slot * E.n + E.e] >> 16) & 0xff].attr;
         bool rnd = false;
         if (does_happen(E.re, 2) && (attr & EA_RANDOM)) rnd = true;
         else if (!does_happen(E.re, 5) && (attr & EA_CONFUSED)) rnd = true;
@@ -1205,12 +1195,12 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
     for (int i = 0; i < n_att; i++) {
         int s = (int)((att_list >> (4 * i)) & 15);
         uint32_t type = (S.mon_w0[s * n + e] >> 16) & 0xff;
-        uint32_t rate = attack_rate((int64_t)kMonLevel[type] + lev_add, 4 /* ring mail 3 + 1 */, 0 /* hit_prob_plus(10) */);
+        uint32_t rate = attack_rate((int64_t)c.mon[type].level + lev_add, 4 /* ring mail 3 + 1 */, 0 /* hit_prob_plus(10) */);
         int sum = 0; bool hit = false;
-        for (int k = 0; k < kMonNAtt[type]; k++) {
+        for (int k = 0; k < c.mon[type].n_att; k++) {
             if (!parcent(E.re, rate)) continue;
             hit = true;
-            int times = kMonAtt[type][2 * k], mx = kMonAtt[type][2 * k + 1];
+            int times = c.mon[type].att[k][0], mx = c.mon[type].att[k][1];
             for (int t = 0; t < times; t++) sum += (int)range64(E.re, 1, (uint64_t)mx + 1);
         }
         if (hit) {
@@ -1441,7 +1431,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RgState S, RgConfig c
                 uint32_t v = cell[y * W + x];
                 int dx = px - x, dy = py - y;
                 if ((v & (C_VISIBLE | C_DRAWN)) && y >= 1 && y < H - 1 && (dx * dx + dy * dy <= 2 || in_same_room(S, c, e, px, py, x, y)))
-                    s_scr[y * W + x] = (uint8_t)('A' + ((w >> 16) & 0xff));
+                    s_scr[y * W + x] = c.mon[(w >> 16) & 0xff].tile;
             }
         }
         __syncthreads();
@@ -1654,7 +1644,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                         }
                     }
                 }
-                if (show && (scr[y * W + x] & 0x80u)) scr[y * W + x] = (uint8_t)(0x80u | ('A' + ((w >> 16) & 0xff)));
+                if (show && (scr[y * W + x] & 0x80u)) scr[y * W + x] = (uint8_t)(0x80u | c.mon[(w >> 16) & 0xff].tile);
             }
         }
         __syncthreads();

@@ -112,3 +112,18 @@ def lockstep(cfg, seeds, keys_per_step, max_steps=1000, check_every=1, internal_
     compare_mirrors(hip, oracles, "end")
     compare_internal(hip, oracles, range(len(seeds)), "end")
     return hip, oracles
+
+
+def custom_enemy_config(base):
+    """A config mixing builtin presets with Preset::Custom(Status) objects (character/enemies.rs:87-121)."""
+    cfg = dict(base)
+    cfg["enemies"] = {"enemies": [
+        1,   # bat (random mover)
+        18,  # snake
+        {"attack": [{"times": 1, "max": 3}, {"times": 1, "max": 3}], "attr": 513, "defense": 6, "exp": 4, "gold": 0, "level": 2,
+         "name": "gremlin", "tile": 71, "rarelity": 0},           # mean + random, two dice, glyph 'G'
+        {"attack": [], "attr": 0, "defense": 9, "exp": 3, "gold": 5, "level": 1, "name": "ooze", "tile": 79, "rarelity": 1},   # harmless sleeper 'O'
+        {"attack": [{"times": 2, "max": 4}], "attr": 1, "defense": 2, "exp": 30, "gold": 0, "level": 3, "name": "warg", "tile": 87, "rarelity": 3},
+        10,  # kestrel
+    ], "appear_rate_gold": 90, "appear_rate_nogold": 60}
+    return cfg

@@ -118,9 +118,27 @@ def test_config_canonical_roundtrip(lib, goldens):
 def test_config_validation(lib):
     for bad, frag in [({"dungeon": {"style": "rogue", "room_num_x": 5, "room_num_y": 5}}, "room_num"),
                       ({"enemies": {"enemies": [99]}}, "builtin"),
-                      ({"enemies": {"enemies": [{"name": "x"}]}}, "builtin"),
+                      ({"enemies": {"enemies": [{"name": "x"}]}}, "missing field"),
+                      ({"enemies": {"enemies": ["kestrel"]}}, "invalid enemy preset"),
                       ({"dungeon": {"style": "rogue", "dark_level": 0}}, "zero rate"),
                       ({"width": "wide"}, "width")]:
         with pytest.raises(RuntimeError) as ei:
             _canon(lib, bad)
         assert frag in str(ei.value), (bad, str(ei.value))
+
+
+def test_custom_enemy_config_roundtrip(lib, goldens):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from parity_util import custom_enemy_config
+    cfg = custom_enemy_config(goldens["configs"]["mini"])
+    c1 = _canon(lib, cfg)
+    assert c1["enemies"] == cfg["enemies"]
+    assert _canon(lib, c1) == c1
+    bad = json.loads(json.dumps(cfg))
+    bad["enemies"]["enemies"][2]["tile"] = 38  # '&' has no symbol id (core/src/symbol.rs:17-40)
+    with pytest.raises(RuntimeError):
+        _canon(lib, bad)
+    del bad["enemies"]["enemies"][2]["tile"]
+    with pytest.raises(RuntimeError, match="missing field"):
+        _canon(lib, bad)

@@ -229,3 +229,19 @@ def test_full_size_default_and_symbol_obs(goldens):
         hip.h.L.rg_sync(hip.h.h)
         del obs, hip
         torch.cuda.empty_cache()
+
+
+def test_custom_enemy_presets(goldens):
+    """Full GameConfig coverage: custom monster statuses mixed with builtin presets, custom appear rates."""
+    from parity_util import custom_enemy_config
+    cfg = custom_enemy_config(goldens["configs"]["mini"])
+    rng = np.random.RandomState(17)
+    hip, oracles = lockstep(cfg, list(range(384)), rand_keys(rng, ALL_KEYS, 384, 400), max_steps=300, check_every=1, internal_every=50)
+    assert oracles[0].symbols == ord("W") - ord("A") + 18
+    g = hip.obs(0, 0, False)
+    for i, o in enumerate(oracles[:64]):
+        assert np.array_equal(g[i], o.gray_image(0, False))
+    seen = set()
+    for o in oracles:
+        seen.update(chr(65 + m["type"]) for m in o.monsters())
+    assert {"G", "W"} <= seen  # the custom monsters actually spawn
