@@ -83,11 +83,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # development aid: ROGUE_GYM_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 with the gloo backend, so the multi-rank control flow
+    # (sharding, barrier, max-over-ranks, gather) can be exercised on a 1-GPU box.  Never set by the driver.
+    one_device = os.environ.get("ROGUE_GYM_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
