@@ -935,6 +935,66 @@ __device__ __forceinline__ void bfs_rows(const RgState &S, const RgConfig &c, ui
     (void)grp_lane0;
 }
 
+// W <= 32 (the mini dungeon): a row is one 32-bit mask, the level step is ~25 scalar-width VALU ops + 2 DPP moves
+__device__ __forceinline__ void bfs_rows_w32(const RgState &S, const RgConfig &c, uint16_t *lds_dist, bool active, int env, int tx, int ty, int slot, int row,
+                                             int rows_pow2) {
+    const int W = c.width, H = c.height, HW = W * H;
+    const uint16_t *cell = S.cell + (size_t)env * HW;
+    const bool row_ok = active && row < H;
+    uint32_t wk = 0, vis = 0, fr = 0;
+    if (row_ok) {
+        const uint16_t *rowp = cell + row * W;
+        if ((W & 7) == 0) {
+            const uint4 *r4 = reinterpret_cast<const uint4 *>(rowp);
+            for (int j = 0; j < W / 8; j++) {
+                uint4 v = r4[j];
+                uint32_t q[4] = {v.x, v.y, v.z, v.w};
+                uint32_t bits = 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    bits |= (uint32_t)can_walk(q[t] & 0xffff) << (2 * t);
+                    bits |= (uint32_t)can_walk(q[t] >> 16) << (2 * t + 1);
+                }
+                wk |= bits << (j * 8);
+            }
+        } else
+            for (int x = 0; x < W; x++) wk |= (uint32_t)can_walk(rowp[x]) << x;
+    }
+    const bool up_ok = row > 0, dn_ok = row + 1 < H;
+    const uint32_t wu = up_ok ? wave_shr1(wk) : 0u, wd = dn_ok ? wave_shl1(wk) : 0u;
+    if (active) for (int i = row; i < HW; i += rows_pow2) lds_dist[i] = DIST_INF;
+    if (row_ok && row == ty) { fr = 1u << tx; vis = fr; }
+    __syncthreads();
+    if (row_ok && row == ty) lds_dist[ty * W + tx] = 0;
+    for (uint32_t level = 1; level < (uint32_t)HW; level++) {
+        uint32_t fu = wave_shr1(fr), fd = wave_shl1(fr);
+        fu = up_ok ? fu : 0u; fd = dn_ok ? fd : 0u;
+        const uint32_t au = fu & wk, ad = fd & wk;
+        const uint32_t tgt = (fr << 1) | (fr >> 1) | fu | fd | (((au << 1) | (au >> 1)) & wu) | (((ad << 1) | (ad >> 1)) & wd);
+        uint32_t nw = tgt & wk & ~vis;
+        vis |= nw;
+        fr = nw;
+        const bool any = nw != 0;
+        while (nw) {
+            int bit = __ffs((int)nw) - 1;
+            nw &= nw - 1;
+            lds_dist[row * W + bit] = (uint16_t)level;
+        }
+        if (!__any(any)) break;
+    }
+    __syncthreads();
+    if (active) {
+        uint16_t *out = S.dc_map + ((size_t)env * RG_DIST_SLOTS + slot) * HW;
+        if ((HW & 7) == 0) {
+            uint4 *o4 = reinterpret_cast<uint4 *>(out);
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(lds_dist);
+            for (int i = row; i < HW / 8; i += rows_pow2) o4[i] = s4[i];
+        } else
+            for (int i = row; i < HW; i += rows_pow2) out[i] = lds_dist[i];
+    }
+    __syncthreads();
+}
+
 // serve every lane of `need` (ballot mask): G requests per round
 __device__ __forceinline__ void bfs_service(const RgState &S, const RgConfig &c, uint16_t *lds, uint64_t need, int e, int px, int py, int map_slot, int lane) {
     const int H = c.height, HW = c.width * H;
@@ -952,7 +1012,7 @@ __device__ __forceinline__ void bfs_service(const RgState &S, const RgConfig &c,
         const int s = active ? src : 0;
         int env_s = __shfl(e, s), tx = __shfl(px, s), ty = __shfl(py, s), sl = __shfl(map_slot, s);
         uint16_t *ld = lds + (size_t)grp * HW;
-        if (c.width <= 32) bfs_rows<1, true>(S, c, ld, active, env_s, tx, ty, sl, row, grp * rows_pow2, rows_pow2);
+        if (c.width <= 32) bfs_rows_w32(S, c, ld, active, env_s, tx, ty, sl, row, rows_pow2);
         else if (c.width <= 64) bfs_rows<1, false>(S, c, ld, active, env_s, tx, ty, sl, row, grp * rows_pow2, rows_pow2);
         else if (c.width <= 128) bfs_rows<2, false>(S, c, ld, active, env_s, tx, ty, sl, row, grp * rows_pow2, rows_pow2);
         else bfs_rows<3, false>(S, c, ld, active, env_s, tx, ty, sl, row, grp * rows_pow2, rows_pow2);
