@@ -1278,14 +1278,12 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
 // k_step: one key for every env
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c, const uint8_t *__restrict__ keys, uint32_t *__restrict__ err_any, int nslots,
-                                               int use_spares, int epw) {
-    // epw = envs per wave (64, 32 or 16): the kernel is bound by dependent-load latency, not by lanes, so at 65 536 envs
-    // half-filled waves put 2+ waves on every SIMD and let their memory round trips overlap
+                                               int use_spares) {
     __builtin_amdgcn_s_setprio(3);  // issue-bound kernel: win VALU arbitration against the co-resident background k_regen waves
     uint16_t *lds_grid = reinterpret_cast<uint16_t *>(g_smem);
     const int lane = threadIdx.x;
-    const int e = blockIdx.x * epw + lane;
-    const bool valid = lane < epw && e < S.n;
+    const int e = blockIdx.x * WAVE + lane;
+    const bool valid = e < S.n;
     Prof pf0; pf0.start(S.prof);
     Env E;
     uint32_t react = 0, err = 0, old_flags = 0, steps = 0, flags = 0;
@@ -1812,25 +1810,14 @@ void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
 }
 void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, int use_spares, hipStream_t st) {
     int hw = c->width * c->height;
-    int ns = gen_slots(hw, 8 * 1024);  // descents are rare once resets come from spares: a small LDS footprint keeps k_regen co-resident
+    int ns = gen_slots(hw, 8 * 1024);  // inline generation is rare (descents, spare misses): a small LDS footprint keeps k_regen co-resident
     size_t smem = (size_t)ns * hw * 2;
     if (bfs_bytes(c) > smem) smem = bfs_bytes(c);
-    static int epw_env = -1;
-    if (epw_env < 0) { const char *v = getenv("ROGUE_GYM_HIP_EPW"); epw_env = v ? atoi(v) : 0; }
-    int epw = epw_env > 0 ? epw_env : 64;
-    if (epw != 64 && epw != 32 && epw != 16) epw = 64;
-    { const char *v = getenv("ROGUE_GYM_HIP_NSLOTS"); int cap = v ? atoi(v) : epw; if (cap < 1) cap = 1; if (ns > cap) ns = cap; if (ns > epw) ns = epw;
-      smem = (size_t)ns * hw * 2; if (bfs_bytes(c) > smem) smem = bfs_bytes(c); }
-    hipLaunchKernelGGL(k_step, dim3((S->n + epw - 1) / epw), dim3(WAVE), smem, st, *S, *SP, *c, keys, err_any, ns, use_spares, epw);
+    hipLaunchKernelGGL(k_step, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *SP, *c, keys, err_any, ns, use_spares);
 }
 void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
-    // few lanes of a wave refill at a time (~0.4 per wave and step): a small LDS footprint leaves the CU's LDS to the step /
-    // observation kernels this one runs beside
-    static int ns_env = -1;
-    if (ns_env < 0) { const char *v = getenv("ROGUE_GYM_HIP_REGEN_SLOTS"); ns_env = v ? atoi(v) : 0; }
-    int ns = gen_slots(hw, 8 * 1024);
-    if (ns_env > 0) ns = ns_env > WAVE ? WAVE : ns_env;
+    int ns = gen_slots(hw, 8 * 1024);  // ~0.4 refills per wave and step; fewer than 4 slots costs spare misses, more buys nothing
     size_t smem = (size_t)ns * hw * 2;
     hipLaunchKernelGGL(k_regen, dim3((SP->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *SP, *c, ns);
 }
@@ -1845,10 +1832,7 @@ int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, 
     int q8 = hw / 8;
     int tpe = q8 >= OBS_THREADS ? OBS_THREADS : ((q8 + 63) / 64) * 64;  // threads per env: a whole number of waves
     if (tpe > OBS_THREADS) tpe = OBS_THREADS;
-    static int bt_env = -1;
-    if (bt_env < 0) { const char *v = getenv("ROGUE_GYM_HIP_OBS_THREADS"); bt_env = v ? atoi(v) : 0; }
-    int bthreads = bt_env >= tpe && bt_env <= OBS_THREADS && bt_env % tpe == 0 ? bt_env : tpe;  // one env per block: no cross-env barrier coupling
-    int epb = bthreads / tpe;
+    const int bthreads = tpe, epb = 1;  // one env per block: no cross-env barrier coupling (4 envs per 256-thread block measured 10-20 % slower)
     size_t smem = 512 + 128 + (size_t)epb * OBS_ENV_BYTES(hw);
     int blocks = (S->n + epb - 1) / epb;
     if (blocks > 65536) blocks = 65536;
