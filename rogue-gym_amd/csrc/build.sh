@@ -1,8 +1,14 @@
 #!/bin/bash
 # Builds librogue_gym_hip.so for gfx950 in-tree (cross-compiles without a GPU).
+# The step kernels want -O3; the bandwidth-bound render/observation kernels are faster with -Os (less unrolling).
 set -e
 cd "$(dirname "$0")"
 OUT=../librogue_gym_hip.so
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
-    rg_kernels.hip rg_api.cpp rg_config.cpp -o "$OUT"
+F="--offload-arch=gfx950 -std=c++17 -fPIC -Wall -Wno-unused-function"
+mkdir -p ../build
+hipcc $F -O3 -c rg_kernels.hip -o ../build/rg_kernels.o
+hipcc $F -Os -c rg_obs.hip -o ../build/rg_obs.o
+hipcc $F -O2 -c rg_api.cpp -o ../build/rg_api.o
+hipcc $F -O2 -c rg_config.cpp -o ../build/rg_config.o
+hipcc --offload-arch=gfx950 -shared ../build/rg_kernels.o ../build/rg_obs.o ../build/rg_api.o ../build/rg_config.o -o "$OUT"
 echo "built $OUT"

@@ -1,0 +1,395 @@
+// rg_obs.hip -- render / observation-encode kernels of the batched Rogue-Gym stepper (gfx950).
+//
+//   k_obs<gray|symbol> : fused RunTime::draw_screen (mirror refresh of Redraw envs) + PlayerState::{gray,symbol}_image
+//   k_render, k_gray, k_symbol, k_encode_scalar : unfused fallbacks
+//
+// Built as its own translation unit with -Os: these kernels are bandwidth/latency-bound and measurably faster with less
+// unrolling (k_obs 83 -> 67-70 us at 65 536 mini envs), while the issue-bound step kernel wants -O3.
+// file:line citations are relative to /root/reference.
+#include "rg_device.h"
+
+// ---------------------------------------------------------------------------------------------
+// k_render: RunTime::draw_screen (core/src/lib.rs:264-285; rogue/mod.rs:278-300,398-404) into the
+// PlayerState mirrors, only for envs whose last key produced Reaction::Redraw
+// ---------------------------------------------------------------------------------------------
+#define RENDER_THREADS 256
+__device__ __forceinline__ bool in_same_room(const RgState &S, const RgConfig &c, int e, int ax, int ay, int bx, int by) {
+    int id = room_id_of(c, ax, ay);  // Floor::in_same_room (floor.rs:381-393)
+    if (id < 0 || room_id_of(c, bx, by) != id) return false;
+    uint8_t meta = S.room_meta[id * S.n + e];
+    if ((meta & RM_KIND_MASK) == RK_EMPTY) return true;
+    int x0, y0, x1, y1;
+    unpack_rect(S.room_rect[id * S.n + e], x0, y0, x1, y1);
+    bool ina = ax >= x0 && ax < x1 && ay >= y0 && ay < y1, inb = bx >= x0 && bx < x1 && by >= y0 && by < y1;
+    return ina == inb;
+}
+
+__global__ void __launch_bounds__(RENDER_THREADS) k_render(RgState S, RgConfig c) {
+    __shared__ uint8_t s_scr[RG_MAX_W * RG_MAX_H];
+    __shared__ uint16_t s_cell_at[2 * RG_MAX_ROOMS];  // cell words under gold / monster overlays
+    const int tid = threadIdx.x, W = c.width, H = c.height, HW = W * H, n = S.n;
+    const int nrooms = c.room_num_x * c.room_num_y;
+    for (int e = blockIdx.x; e < n; e += gridDim.x) {
+        const uint32_t fl = S.flags[e];
+        if (!(fl & RG_FLAG_REDRAW)) continue;
+        const uint16_t *cell = S.cell + (size_t)e * HW;
+        const bool upd_hist = !(fl & RG_FLAG_HIST_STALE);
+        uint8_t *hist = S.hist + (size_t)e * HW;
+        for (int i = tid; i < HW; i += RENDER_THREADS) {
+            uint32_t v = cell[i];
+            int y = i / W;
+            uint8_t g = ' ';
+            if (y >= 1 && y < H - 1 && (v & C_VISIBLE)) g = glyph_of(v);
+            s_scr[i] = g;
+            if (upd_hist) hist[i] = (v & C_VISITED) ? 1 : 0;
+        }
+        __syncthreads();
+        const uint32_t ppos = S.p_pos[e];
+        const int px = POS_X(ppos), py = POS_Y(ppos);
+        // draw priority: player > gold > monster (core/src/lib.rs:271-283): lowest priority first
+        if (tid < nrooms) {
+            uint32_t w = S.mon_w0[tid * n + e];
+            if ((w >> 24) & MF_ALIVE) {
+                int x = POS_X(w), y = POS_Y(w);
+                uint32_t v = cell[y * W + x];
+                int dx = px - x, dy = py - y;
+                if ((v & (C_VISIBLE | C_DRAWN)) && y >= 1 && y < H - 1 && (dx * dx + dy * dy <= 2 || in_same_room(S, c, e, px, py, x, y)))
+                    s_scr[y * W + x] = c.mon[(w >> 16) & 0xff].tile;
+            }
+        }
+        __syncthreads();
+        if (tid < nrooms) {
+            uint32_t g = S.gold_pos[tid * n + e];
+            if (g & 0x10000u) {
+                int x = POS_X(g), y = POS_Y(g);
+                if ((cell[y * W + x] & (C_VISIBLE | C_DRAWN)) && y >= 1 && y < H - 1) s_scr[y * W + x] = '*';
+            }
+        }
+        __syncthreads();
+        if (tid == 0 && (cell[py * W + px] & (C_VISIBLE | C_DRAWN)) && py >= 1 && py < H - 1) s_scr[py * W + px] = '@';
+        __syncthreads();
+        uint8_t *scr = S.screen + (size_t)e * HW;
+        if ((HW & 3) == 0) {
+            uint32_t *d4 = reinterpret_cast<uint32_t *>(scr);
+            const uint32_t *s4 = reinterpret_cast<const uint32_t *>(s_scr);
+            for (int i = tid; i < HW / 4; i += RENDER_THREADS) d4[i] = s4[i];
+        } else
+            for (int i = tid; i < HW; i += RENDER_THREADS) scr[i] = s_scr[i];
+        if (tid == 0) S.flags[e] = fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE);
+        __syncthreads();
+    }
+    (void)s_cell_at;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gray / k_symbol: observation encode (python/src/lib.rs:72-111,162-205; flags.rs:88-115)
+// one thread = 4 consecutive cells of one env, all planes; float4 (16-byte) stores
+// ---------------------------------------------------------------------------------------------
+// StatusFlagInner bit b -> index into Status::to_vec
+__device__ __constant__ uint8_t kStatusIdx[9] = {0, 2, 3, 4, 5, 6, 7, 8, 9};
+
+__global__ void __launch_bounds__(256) k_gray(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status,
+                                              int n, int hw, int symbols, uint32_t sflag, int with_hist, float *__restrict__ out) {
+    const int q = hw >> 2;  // quads per env (hw % 4 == 0 checked on the host)
+    const size_t total = (size_t)n * q;
+    const int nplanes = 1 + __popc(sflag) + (with_hist ? 1 : 0);
+    const float fsym = (float)(uint8_t)symbols;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        int e = (int)(g / q), i = (int)(g - (size_t)e * q);
+        uint32_t s4 = reinterpret_cast<const uint32_t *>(screen + (size_t)e * hw)[i];
+        float4 v;
+        v.x = (float)(uint8_t)tile_to_sym(s4 & 0xff) / fsym;
+        v.y = (float)(uint8_t)tile_to_sym((s4 >> 8) & 0xff) / fsym;
+        v.z = (float)(uint8_t)tile_to_sym((s4 >> 16) & 0xff) / fsym;
+        v.w = (float)(uint8_t)tile_to_sym(s4 >> 24) / fsym;
+        float4 *o = reinterpret_cast<float4 *>(out + (size_t)e * nplanes * hw) + i;
+        o[0] = v;
+        int p = 1;
+        for (int b = 0; b < 9; b++)
+            if (sflag & (1u << b)) {
+                float f = (float)status[(size_t)e * 10 + kStatusIdx[b]];
+                float4 sv; sv.x = sv.y = sv.z = sv.w = f;
+                o[(size_t)p * q] = sv;
+                p++;
+            }
+        if (with_hist) {
+            uint32_t h4 = reinterpret_cast<const uint32_t *>(hist + (size_t)e * hw)[i];
+            float4 hv;
+            hv.x = (h4 & 0xff) ? 1.f : 0.f; hv.y = (h4 & 0xff00) ? 1.f : 0.f; hv.z = (h4 & 0xff0000) ? 1.f : 0.f; hv.w = (h4 >> 24) ? 1.f : 0.f;
+            o[(size_t)p * q] = hv;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_symbol(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status,
+                                                uint32_t *__restrict__ flags, uint32_t *__restrict__ err_any,
+                                                int n, int hw, int symbols, uint32_t sflag, int with_hist, float *__restrict__ out) {
+    const int q = hw >> 2;
+    const size_t total = (size_t)n * q;
+    const int nplanes = symbols + __popc(sflag) + (with_hist ? 1 : 0);
+    const uint32_t symbol_max = (uint32_t)symbols - 1;  // construct_symbol_map fills channels 0..symbols-2 (symbol.rs:51-71)
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        int e = (int)(g / q), i = (int)(g - (size_t)e * q);
+        uint32_t s4 = reinterpret_cast<const uint32_t *>(screen + (size_t)e * hw)[i];
+        uint32_t a = tile_to_sym(s4 & 0xff), b = tile_to_sym((s4 >> 8) & 0xff), cc = tile_to_sym((s4 >> 16) & 0xff), d = tile_to_sym(s4 >> 24);
+        if (a >= symbol_max || b >= symbol_max || cc >= symbol_max || d >= symbol_max) {  // InvalidTileError (e.g. 'Z')
+            if (flags) atomicOr(&flags[e], RG_FLAG_ERR_TILE);
+            atomicOr(err_any, RG_FLAG_ERR_TILE);
+        }
+        float4 *o = reinterpret_cast<float4 *>(out + (size_t)e * nplanes * hw) + i;
+        for (uint32_t ch = 0; ch < (uint32_t)symbols; ch++) {
+            float4 v;
+            v.x = a == ch ? 1.f : 0.f; v.y = b == ch ? 1.f : 0.f; v.z = cc == ch ? 1.f : 0.f; v.w = d == ch ? 1.f : 0.f;
+            if (ch >= symbol_max) v.x = v.y = v.z = v.w = 0.f;
+            o[(size_t)ch * q] = v;
+        }
+        int p = symbols;
+        for (int bb = 0; bb < 9; bb++)
+            if (sflag & (1u << bb)) {
+                float f = (float)status[(size_t)e * 10 + kStatusIdx[bb]];
+                float4 sv; sv.x = sv.y = sv.z = sv.w = f;
+                o[(size_t)p * q] = sv;
+                p++;
+            }
+        if (with_hist) {
+            uint32_t h4 = reinterpret_cast<const uint32_t *>(hist + (size_t)e * hw)[i];
+            float4 hv;
+            hv.x = (h4 & 0xff) ? 1.f : 0.f; hv.y = (h4 & 0xff00) ? 1.f : 0.f; hv.z = (h4 & 0xff0000) ? 1.f : 0.f; hv.w = (h4 >> 24) ? 1.f : 0.f;
+            o[(size_t)p * q] = hv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_obs: fused mirror refresh + observation encode (the steady-state path: one pass per step)
+// ---------------------------------------------------------------------------------------------
+// For every env: if the last key produced a Redraw, draw the screen from the tile words (+ entity
+// overlays) and refresh the screen / history mirrors; otherwise re-read the 1-byte-per-cell mirror.  The
+// screen is staged in LDS, then encoded straight into the caller's f32 tensor with float4 stores.
+// HBM traffic per env-step (mini gray): 1 KB tiles (Redraw envs) or 0.5 KB mirror read, 0.5 KB mirror
+// write (Redraw envs), 2 KB observation write.  A block of 256 threads serves `epb` envs, `tpe` threads each;
+// a thread owns 8 consecutive cells (one 16-byte tile load, two float4 stores per plane).
+#define OBS_THREADS 256
+// The observation tensor is a write-once 134 MB stream per step (mini gray): non-temporal stores keep it from evicting the
+// env state (tile grids, mirrors, tables) that the next k_step re-reads from L2 / Infinity Cache.
+__device__ __forceinline__ void store_obs(float4 *p, float4 v) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v nv = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(nv, reinterpret_cast<f4v *>(p));
+}
+struct ObsTabs {  // per-env entity/room tables staged in LDS: every global load of an env is issued up front, in one round trip
+    uint32_t rect[RG_MAX_ROOMS], mon[RG_MAX_ROOMS], gold[RG_MAX_ROOMS];
+    uint8_t meta[RG_MAX_ROOMS];
+    uint32_t ppos, pad[3];
+};
+#define OBS_ENV_BYTES(hw) ((((size_t)(hw) + sizeof(ObsTabs)) + 15) & ~(size_t)15)
+
+template <int KIND>
+__global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint32_t sflag, int with_hist, float *__restrict__ out,
+                                                    uint32_t *__restrict__ err_any, int tpe, int epb) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    float *lutf = reinterpret_cast<float *>(smem);        // glyph -> gray value (KIND 0)
+    uint8_t *luts = smem + 512;                            // glyph -> symbol id
+    uint8_t *envs = smem + 512 + 128;                      // epb x {HW staged screen bytes, ObsTabs}
+    const int tid = threadIdx.x, W = c.width, H = c.height, HW = W * H, n = S.n, Q8 = HW >> 3;
+    const int nrooms = c.room_num_x * c.room_num_y;
+    const int symbols = c.symbols;
+    for (int g = tid; g < 128; g += blockDim.x) {
+        uint32_t sy = tile_to_sym((uint32_t)g);
+        luts[g] = (uint8_t)sy;
+        lutf[g] = (float)(uint8_t)sy / (float)(uint8_t)symbols;  // python/src/lib.rs:84 (same single division)
+    }
+    const int le = tid / tpe, lt = tid - le * tpe;
+    const int base_planes = KIND ? symbols : 1;
+    const int nplanes = base_planes + __popc(sflag) + (with_hist ? 1 : 0);
+    uint8_t *scr = envs + (size_t)le * OBS_ENV_BYTES(HW);
+    ObsTabs *tb = reinterpret_cast<ObsTabs *>(scr + HW);
+    for (int base = blockIdx.x * epb; base < n; base += gridDim.x * epb) {
+        const int e = base + le;
+        const bool valid = le < epb && e < n;
+        uint32_t fl = 0;
+        bool redraw = false;
+        if (valid) { fl = S.flags[e]; redraw = fl & RG_FLAG_REDRAW; }
+        __syncthreads();  // LUTs ready / previous iteration's LDS reads done
+        // ---- phase A: every global load of this env, independent of each other ----
+        if (valid) {
+            if (redraw) {
+                if (lt < nrooms) {
+                    tb->rect[lt] = S.room_rect[lt * n + e]; tb->meta[lt] = S.room_meta[lt * n + e];
+                    tb->mon[lt] = S.mon_w0[lt * n + e]; tb->gold[lt] = S.gold_pos[lt * n + e];
+                }
+                if (lt == tpe - 1) tb->ppos = S.p_pos[e];
+                const uint4 *cell4 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW);
+                const bool upd_hist = !(fl & RG_FLAG_HIST_STALE);
+                uint2 *hist8 = reinterpret_cast<uint2 *>(S.hist + (size_t)e * HW);
+                for (int i = lt; i < Q8; i += tpe) {
+                    uint4 v = cell4[i];
+                    uint32_t q[4] = {v.x, v.y, v.z, v.w};
+                    uint32_t g[2] = {0, 0}, hb[2] = {0, 0};
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        uint32_t cw = (q[t >> 1] >> ((t & 1) * 16)) & 0xffff;
+                        int idx = i * 8 + t;
+                        bool inner = idx >= W && idx < HW - W;  // rows 1..H-2 only (rogue/mod.rs:278-290)
+                        uint32_t gl = ' ';
+                        if (inner && (cw & C_VISIBLE)) gl = glyph_of(cw);
+                        if (inner && (cw & (C_VISIBLE | C_DRAWN))) gl |= 0x80u;  // bit 7: an object on this cell is drawn (draw_ranges)
+                        g[t >> 2] |= gl << ((t & 3) * 8);
+                        hb[t >> 2] |= ((cw & C_VISITED) ? 1u : 0u) << ((t & 3) * 8);
+                    }
+                    reinterpret_cast<uint2 *>(scr)[i] = make_uint2(g[0], g[1]);
+                    if (upd_hist) hist8[i] = make_uint2(hb[0], hb[1]);
+                }
+            } else {
+                const uint2 *m8 = reinterpret_cast<const uint2 *>(S.screen + (size_t)e * HW);
+                for (int i = lt; i < Q8; i += tpe) reinterpret_cast<uint2 *>(scr)[i] = m8[i];
+            }
+        }
+        __syncthreads();
+        // ---- phase B: entity overlays from LDS only; draw priority monster < gold < player (core/src/lib.rs:271-283) ----
+        const uint32_t ppos = (valid && redraw) ? tb->ppos : 0;
+        const int px = POS_X(ppos), py = POS_Y(ppos);
+        if (valid && redraw && lt < nrooms) {
+            uint32_t w = tb->mon[lt];
+            if ((w >> 24) & MF_ALIVE) {
+                int x = POS_X(w), y = POS_Y(w);
+                int dx = px - x, dy = py - y;
+                bool show = dx * dx + dy * dy <= 2;
+                if (!show) {  // Floor::in_same_room (floor.rs:381-393)
+                    int id = room_id_of(c, px, py);
+                    if (id >= 0 && room_id_of(c, x, y) == id) {
+                        if ((tb->meta[id] & RM_KIND_MASK) == RK_EMPTY) show = true;
+                        else {
+                            int x0, y0, x1, y1;
+                            unpack_rect(tb->rect[id], x0, y0, x1, y1);
+                            bool ina = px >= x0 && px < x1 && py >= y0 && py < y1, inb = x >= x0 && x < x1 && y >= y0 && y < y1;
+                            show = ina == inb;
+                        }
+                    }
+                }
+                if (show && (scr[y * W + x] & 0x80u)) scr[y * W + x] = (uint8_t)(0x80u | c.mon[(w >> 16) & 0xff].tile);
+            }
+        }
+        __syncthreads();
+        if (valid && redraw) {
+            if (lt < nrooms) {
+                uint32_t g = tb->gold[lt];
+                if ((g & 0x10000u) && (g & 0xffff) != ppos) {  // the player's own cell is drawn by the player lane
+                    int x = POS_X(g), y = POS_Y(g);
+                    if (scr[y * W + x] & 0x80u) scr[y * W + x] = (uint8_t)(0x80u | '*');
+                }
+            } else if (lt == nrooms && (scr[py * W + px] & 0x80u)) scr[py * W + px] = (uint8_t)(0x80u | '@');
+        }
+        __syncthreads();
+        // ---- phase C: mirror write-back + encode ----
+        if (valid) {
+            uint2 *m8 = reinterpret_cast<uint2 *>(S.screen + (size_t)e * HW);
+            float4 *o = reinterpret_cast<float4 *>(out + (size_t)e * nplanes * HW);
+            const int q4 = HW >> 2;
+            bool bad = false;
+            for (int i = lt; i < Q8; i += tpe) {
+                uint2 g = reinterpret_cast<const uint2 *>(scr)[i];
+                g.x &= 0x7f7f7f7fu; g.y &= 0x7f7f7f7fu;
+                if (redraw) m8[i] = g;
+                uint32_t gg[2] = {g.x, g.y};
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    uint32_t b0 = gg[half] & 0x7f, b1 = (gg[half] >> 8) & 0x7f, b2 = (gg[half] >> 16) & 0x7f, b3 = (gg[half] >> 24) & 0x7f;
+                    if (KIND == 0) {
+                        float4 v; v.x = lutf[b0]; v.y = lutf[b1]; v.z = lutf[b2]; v.w = lutf[b3];
+                        store_obs(&o[2 * i + half], v);
+                    } else {
+                        uint32_t s0 = luts[b0], s1 = luts[b1], s2 = luts[b2], s3 = luts[b3];
+                        uint32_t smax = (uint32_t)symbols - 1;  // construct_symbol_map fills channels 0..symbols-2 (symbol.rs:51-71)
+                        bad = bad || s0 >= smax || s1 >= smax || s2 >= smax || s3 >= smax;
+                        for (uint32_t ch = 0; ch < (uint32_t)symbols; ch++) {
+                            float4 v;
+                            v.x = s0 == ch ? 1.f : 0.f; v.y = s1 == ch ? 1.f : 0.f; v.z = s2 == ch ? 1.f : 0.f; v.w = s3 == ch ? 1.f : 0.f;
+                            if (ch >= smax) v.x = v.y = v.z = v.w = 0.f;
+                            store_obs(&o[(size_t)ch * q4 + 2 * i + half], v);
+                        }
+                    }
+                }
+                int p = base_planes;
+                for (int b = 0; b < 9; b++)
+                    if (sflag & (1u << b)) {
+                        float f = (float)S.status[(size_t)e * 10 + kStatusIdx[b]];
+                        float4 sv; sv.x = sv.y = sv.z = sv.w = f;
+                        store_obs(&o[(size_t)p * q4 + 2 * i], sv); store_obs(&o[(size_t)p * q4 + 2 * i + 1], sv);
+                        p++;
+                    }
+                if (with_hist) {
+                    uint2 h8 = reinterpret_cast<const uint2 *>(S.hist + (size_t)e * HW)[i];
+                    float4 a, b2;
+                    a.x = (h8.x & 0xff) ? 1.f : 0.f; a.y = (h8.x & 0xff00) ? 1.f : 0.f; a.z = (h8.x & 0xff0000) ? 1.f : 0.f; a.w = (h8.x >> 24) ? 1.f : 0.f;
+                    b2.x = (h8.y & 0xff) ? 1.f : 0.f; b2.y = (h8.y & 0xff00) ? 1.f : 0.f; b2.z = (h8.y & 0xff0000) ? 1.f : 0.f; b2.w = (h8.y >> 24) ? 1.f : 0.f;
+                    store_obs(&o[(size_t)p * q4 + 2 * i], a); store_obs(&o[(size_t)p * q4 + 2 * i + 1], b2);
+                }
+            }
+            if (KIND == 1 && bad) { atomicOr(&S.flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
+            if (redraw && lt == 0) S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE)) | (KIND == 1 && bad ? RG_FLAG_ERR_TILE : 0);
+        }
+    }
+}
+
+// scalar fallbacks for H*W not divisible by 4 (never the case for the benchmark sizes)
+__global__ void __launch_bounds__(256) k_encode_scalar(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status,
+                                                       uint32_t *__restrict__ flags, uint32_t *__restrict__ err_any, int n, int hw, int symbols,
+                                                       uint32_t sflag, int with_hist, int kind, float *__restrict__ out) {
+    const size_t total = (size_t)n * hw;
+    const int base = kind ? symbols : 1;
+    const int nplanes = base + __popc(sflag) + (with_hist ? 1 : 0);
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        int e = (int)(g / hw), i = (int)(g - (size_t)e * hw);
+        uint32_t sym = tile_to_sym(screen[g]);
+        float *o = out + (size_t)e * nplanes * hw + i;
+        if (!kind) o[0] = (float)(uint8_t)sym / (float)(uint8_t)symbols;
+        else {
+            if (sym >= (uint32_t)symbols - 1) { if (flags) atomicOr(&flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
+            for (int ch = 0; ch < symbols; ch++) o[(size_t)ch * hw] = (sym == (uint32_t)ch && ch < symbols - 1) ? 1.f : 0.f;
+        }
+        int p = base;
+        for (int b = 0; b < 9; b++)
+            if (sflag & (1u << b)) { o[(size_t)p * hw] = (float)status[(size_t)e * 10 + kStatusIdx[b]]; p++; }
+        if (with_hist) o[(size_t)p * hw] = hist[g] ? 1.f : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-callable launchers (used by rg_api.cpp)
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st) {
+    int blocks = S->n < 8192 ? S->n : 8192;
+    hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RENDER_THREADS), 0, st, *S, *c);
+}
+// fused mirror refresh + encode; returns 0 if the geometry is not supported (caller falls back to k_render + encode)
+int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, hipStream_t st) {
+    int hw = c->width * c->height;
+    if (hw & 7) return 0;
+    int q8 = hw / 8;
+    int tpe = q8 >= OBS_THREADS ? OBS_THREADS : ((q8 + 63) / 64) * 64;  // threads per env: a whole number of waves
+    if (tpe > OBS_THREADS) tpe = OBS_THREADS;
+    const int bthreads = tpe, epb = 1;  // one env per block: no cross-env barrier coupling (4 envs per 256-thread block measured 10-20 % slower)
+    size_t smem = 512 + 128 + (size_t)epb * OBS_ENV_BYTES(hw);
+    int blocks = (S->n + epb - 1) / epb;
+    if (blocks > 65536) blocks = 65536;
+    if (!kind) hipLaunchKernelGGL(k_obs<0>, dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb);
+    else hipLaunchKernelGGL(k_obs<1>, dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb);
+    return 1;
+}
+void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, int symbols,
+                uint32_t sflag, int with_hist, int kind, float *out, hipStream_t st) {
+    if ((hw & 3) == 0) {
+        size_t total = (size_t)n * (hw >> 2);
+        int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+        if (blocks < 1) blocks = 1;
+        if (!kind) hipLaunchKernelGGL(k_gray, dim3(blocks), dim3(256), 0, st, screen, hist, status, n, hw, symbols, sflag, with_hist, out);
+        else hipLaunchKernelGGL(k_symbol, dim3(blocks), dim3(256), 0, st, screen, hist, status, flags, err_any, n, hw, symbols, sflag, with_hist, out);
+    } else {
+        size_t total = (size_t)n * hw;
+        int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+        hipLaunchKernelGGL(k_encode_scalar, dim3(blocks), dim3(256), 0, st, screen, hist, status, flags, err_any, n, hw, symbols, sflag, with_hist, kind, out);
+    }
+}
+}
