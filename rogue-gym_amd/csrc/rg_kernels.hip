@@ -93,6 +93,7 @@ struct Env {
     int hp, hpmax, plvl;
     uint32_t exp, food, quiet, gold, dlevel;
     uint32_t mon_alive, mon_active;
+    uint32_t *mc;       // k_step: this lane's column of the wave's LDS monster cache (word s at mc[s * WAVE]); write-through
 };
 
 // Floor::can_move_impl (floor.rs:169-182)
@@ -113,11 +114,20 @@ __device__ __forceinline__ bool can_move(const RgConfig &c, const uint16_t *cell
 // ---------------------------------------------------------------------------------------------
 // monsters table helpers
 // ---------------------------------------------------------------------------------------------
+// Monster word 0 accessors.  MC = true (the turn code of k_step): read from the wave's LDS cache, loaded once per launch --
+// the monster phases re-read the table dozens of times (ordering, blocking tests for 9 directions, overwrite checks), and
+// against global memory every pass is another round of VMEM instructions and waits.  Stores go to both.
+template <bool MC> __device__ __forceinline__ uint32_t mon_rd(const RgState &S, const Env &E, int s) { return MC ? E.mc[s * WAVE] : S.mon_w0[s * E.n + E.e]; }
+template <bool MC> __device__ __forceinline__ void mon_wr(const RgState &S, const Env &E, int s, uint32_t w) {
+    S.mon_w0[s * E.n + E.e] = w;
+    if (MC) E.mc[s * WAVE] = w;
+}
+
 __device__ __forceinline__ int mon_find(const RgState &S, const Env &E, int nrooms, uint32_t pos) {
     if (E.mon_alive == 0) return -1;
     int found = -1;
     for (int s = 0; s < nrooms; s++) {
-        uint32_t w = S.mon_w0[s * E.n + E.e];
+        uint32_t w = mon_rd<true>(S, E, s);
         uint32_t fl = w >> 24;
         if ((fl & MF_ALIVE) && (w & 0xffff) == pos) found = s;
     }
@@ -128,7 +138,7 @@ __device__ __forceinline__ int mon_find(const RgState &S, const Env &E, int nroo
 __device__ __forceinline__ bool blocked_for(const RgState &S, const Env &E, int nrooms, uint32_t pos, int self) {
     bool blk = false;
     for (int s = 0; s < nrooms; s++) {
-        uint32_t w = S.mon_w0[s * E.n + E.e];
+        uint32_t w = mon_rd<true>(S, E, s);
         uint32_t fl = w >> 24;
         if (s != self && (fl & MF_ALIVE) && !(fl & MF_PENDING) && (w & 0xffff) == pos) blk = true;
     }
@@ -137,16 +147,17 @@ __device__ __forceinline__ bool blocked_for(const RgState &S, const Env &E, int 
 __device__ __forceinline__ uint32_t lev_add_of(const RgConfig &c, uint32_t level) { return c.amulet_level < level ? level - c.amulet_level : 0; }
 
 // EnemyHandler::activate_area (enemies.rs:342-362): wake MEAN sleepers inside room `rid`'s assigned area
+template <bool MC>
 __device__ __forceinline__ void activate_room(const RgState &S, const RgConfig &c, Env &E, int rid) {
     if (E.mon_alive == E.mon_active) return;
     int nrooms = c.room_num_x * c.room_num_y;
     for (int s = 0; s < nrooms; s++) {
-        uint32_t w = S.mon_w0[s * E.n + E.e];
+        uint32_t w = mon_rd<MC>(S, E, s);
         uint32_t fl = w >> 24;
         if (!(fl & MF_ALIVE) || (fl & MF_ACTIVE)) continue;
         if (!(c.mon[(w >> 16) & 0xff].attr & EA_MEAN)) continue;
         if (room_id_of(c, POS_X(w), POS_Y(w)) != rid) continue;
-        S.mon_w0[s * E.n + E.e] = w | (MF_ACTIVE << 24);
+        mon_wr<MC>(S, E, s, w | (MF_ACTIVE << 24));
         E.mon_active++;
     }
 }
@@ -154,6 +165,7 @@ __device__ __forceinline__ void activate_room(const RgState &S, const RgConfig &
 // ---------------------------------------------------------------------------------------------
 // field-of-view (floor.rs:201-312)
 // ---------------------------------------------------------------------------------------------
+template <bool MC>
 __device__ __forceinline__ void player_in(const RgState &S, const RgConfig &c, Env &E, int x, int y, bool init) {
     uint16_t *cell = E.cell;
     int W = c.width;
@@ -171,7 +183,7 @@ __device__ __forceinline__ void player_in(const RgState &S, const RgConfig &c, E
                         for (int xx = x0; xx < x1; xx++) cell[yy * W + xx] |= C_DRAWN | C_VISIBLE;
                 }
             }
-            activate_room(S, c, E, rid);
+            activate_room<MC>(S, c, E, rid);
         }
     }
     cell[y * W + x] |= C_VISITED;
@@ -585,7 +597,7 @@ __device__ __forceinline__ void place_player(const RgState &S, const RgConfig &c
     uint32_t pos = 0;
     floor_select(S, c, E, non_empty, 1, pos);
     E.px = POS_X(pos); E.py = POS_Y(pos);
-    player_in(S, c, E, E.px, E.py, true);
+    player_in<false>(S, c, E, E.px, E.py, true);
 }
 
 // GameConfig::build (core/src/lib.rs:193-228), split around the level generator
@@ -1009,9 +1021,9 @@ __device__ __forceinline__ bool level_up(const RgConfig &c, Env &E, uint32_t exp
 // mace 2d4 hit+1 dam+1, strength 16 => +0/+0; the monster is always `running` by the time of the roll
 __device__ __forceinline__ void player_attack(const RgState &S, const RgConfig &c, Env &E, int slot, uint32_t &react) {
     int idx = slot * E.n + E.e;
-    uint32_t w = S.mon_w0[idx];
+    uint32_t w = mon_rd<true>(S, E, slot);
     E.quiet = 0;
-    if (!((w >> 24) & MF_ACTIVE)) { w |= (uint32_t)MF_ACTIVE << 24; E.mon_active++; S.mon_w0[idx] = w; }
+    if (!((w >> 24) & MF_ACTIVE)) { w |= (uint32_t)MF_ACTIVE << 24; E.mon_active++; mon_wr<true>(S, E, slot, w); }
     uint32_t type = (w >> 16) & 0xff;
     int64_t def = (int64_t)c.mon[type].defense - (int64_t)lev_add_of(c, E.dlevel);
     uint32_t rate = attack_rate(E.plvl, def, 1);
@@ -1022,7 +1034,7 @@ __device__ __forceinline__ void player_attack(const RgState &S, const RgConfig &
         react |= MSG_HIT_TO;
         int hp = S.mon_hp[idx];
         if (hp <= dmg) {  // Enemy::get_damage (enemies.rs:205-213)
-            S.mon_w0[idx] = 0;
+            mon_wr<true>(S, E, slot, 0);
             E.mon_alive--; E.mon_active--;
             if (level_up(c, E, S.mon_exp[idx])) react |= R_STATUS;
             react |= MSG_KILLED | R_REDRAW;
@@ -1038,7 +1050,7 @@ __device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c,
     int ms = mon_find(S, E, nrooms, POS(nx, ny));
     if (ms >= 0) { player_attack(S, c, E, ms, react); return true; }
     player_out(S, c, E, E.px, E.py);
-    player_in(S, c, E, nx, ny, false);
+    player_in<true>(S, c, E, nx, ny, false);
     E.px = nx; E.py = ny;
     react |= R_REDRAW;
     uint32_t v = E.cell[ny * c.width + nx];
@@ -1094,7 +1106,7 @@ __device__ __forceinline__ void turn_passed(const RgConfig &c, Env &E, uint32_t 
 __device__ __forceinline__ int next_pending(const RgState &S, const Env &E, int nrooms, int last, int &slot_out) {
     int best = 0x7fffffff, bs = -1;
     for (int s = 0; s < nrooms; s++) {
-        uint32_t w = S.mon_w0[s * E.n + E.e];
+        uint32_t w = mon_rd<true>(S, E, s);
         if (!((w >> 24) & MF_PENDING)) continue;
         int key = (int)(w & 0xffff);
         if (key > last && key < best) { best = key; bs = s; }
@@ -1109,13 +1121,13 @@ __device__ __forceinline__ bool monsters_prepass(const RgState &S, const RgConfi
     const int nrooms = c.room_num_x * c.room_num_y;
     rand_mask = 0; rand_dir = 0;
     for (int s = 0; s < nrooms; s++) {  // the taken map: every active monster is pending
-        uint32_t w = S.mon_w0[s * E.n + E.e];
-        if (((w >> 24) & (MF_ALIVE | MF_ACTIVE)) == (MF_ALIVE | MF_ACTIVE)) S.mon_w0[s * E.n + E.e] = w | ((uint32_t)MF_PENDING << 24);
+        uint32_t w = mon_rd<true>(S, E, s);
+        if (((w >> 24) & (MF_ALIVE | MF_ACTIVE)) == (MF_ALIVE | MF_ACTIVE)) E.mc[s * WAVE] = w | ((uint32_t)MF_PENDING << 24);  // PENDING lives in the cache only
     }
     bool need_map = false;
     int last = -1, slot;
     while ((last = next_pending(S, E, nrooms, last, slot)) >= 0) {
-        uint32_t attr = c.mon[(S.mon_w0[slot * E.n + E.e] >> 16) & 0xff].attr;
+        uint32_t attr = c.mon[(mon_rd<true>(S, E, slot) >> 16) & 0xff].attr;
         bool rnd = false;
         if (does_happen(E.re, 2) && (attr & EA_RANDOM)) rnd = true;
         else if (!does_happen(E.re, 5) && (attr & EA_CONFUSED)) rnd = true;
@@ -1149,8 +1161,8 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
     uint64_t att_list = 0; int n_att = 0;
     int last = -1, slot;
     while ((last = next_pending(S, E, nrooms, last, slot)) >= 0) {
-        uint32_t w = S.mon_w0[slot * n + e] & ~((uint32_t)MF_PENDING << 24);
-        S.mon_w0[slot * n + e] = w;  // leaves the taken map; not yet in the new one, so it never blocks itself
+        uint32_t w = mon_rd<true>(S, E, slot) & ~((uint32_t)MF_PENDING << 24);
+        E.mc[slot * WAVE] = w;  // leaves the taken map; not yet in the new one, so it never blocks itself
         int cx = POS_X(w), cy = POS_Y(w);
         uint32_t fin = w & 0xffff;
         bool reach = false;
@@ -1177,18 +1189,18 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
             // BTreeMap::insert on its own key replaces a monster that already moved onto this cell
             for (int s = 0; s < nrooms; s++) {
                 if (s == slot) continue;
-                uint32_t o = S.mon_w0[s * n + e];
+                uint32_t o = mon_rd<true>(S, E, s);
                 uint32_t fl = o >> 24;
-                if ((fl & MF_ALIVE) && (fl & MF_ACTIVE) && !(fl & MF_PENDING) && (o & 0xffff) == fin) { S.mon_w0[s * n + e] = 0; E.mon_alive--; E.mon_active--; }
+                if ((fl & MF_ALIVE) && (fl & MF_ACTIVE) && !(fl & MF_PENDING) && (o & 0xffff) == fin) { mon_wr<true>(S, E, s, 0); E.mon_alive--; E.mon_active--; }
             }
-        } else S.mon_w0[slot * n + e] = (w & 0xffff0000u) | fin;
+        } else mon_wr<true>(S, E, slot, (w & 0xffff0000u) | fin);
     }
     if (n_att > 0) E.quiet = 0;  // player.buttle()
     bool did_hit = false;
     uint32_t lev_add = lev_add_of(c, E.dlevel);
     for (int i = 0; i < n_att; i++) {
         int s = (int)((att_list >> (4 * i)) & 15);
-        uint32_t type = (S.mon_w0[s * n + e] >> 16) & 0xff;
+        uint32_t type = (mon_rd<true>(S, E, s) >> 16) & 0xff;
         uint32_t rate = attack_rate((int64_t)c.mon[type].level + lev_add, 4 /* ring mail 3 + 1 */, 0 /* hit_prob_plus(10) */);
         int sum = 0; bool hit = false;
         for (int k = 0; k < c.mon[type].n_att; k++) {
@@ -1212,7 +1224,7 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
 // k_step: one key for every env
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c, const uint8_t *__restrict__ keys, uint32_t *__restrict__ err_any, int nslots,
-                                               int use_spares) {
+                                               int use_spares, int mc_offset) {
     __builtin_amdgcn_s_setprio(3);  // issue-bound kernel: win VALU arbitration against the co-resident background k_regen waves
     uint16_t *lds_grid = reinterpret_cast<uint16_t *>(g_smem);
     const int lane = threadIdx.x;
@@ -1237,6 +1249,10 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
         }
         if (live) load_env(S, E, e);
     }
+    // LDS monster cache: column `lane` of [nrooms][64] words behind the generation / BFS staging area
+    const int nrooms_k = c.room_num_x * c.room_num_y;
+    E.mc = reinterpret_cast<uint32_t *>(g_smem + mc_offset) + lane;
+    if (live) for (int s = 0; s < nrooms_k; s++) E.mc[s * WAVE] = S.mon_w0[s * S.n + e];
     // Action::DownStair (actions.rs:27-36): the new level is produced by the generation service below
     pf0.mark(0);
     Prof pf; pf.start(S.prof);
@@ -1286,7 +1302,9 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
                 if (take) __hip_atomic_store(&S.sp_ready[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // consumed: k_regen refills it
             }
         }
+        const bool regenerated = need_gen && pass == 0;
         gen_service(S, c, E, lane, e, need_gen, pass == 1, lds_grid, nslots, pf);
+        if (regenerated) for (int s = 0; s < nrooms_k; s++) E.mc[s * WAVE] = S.mon_w0[s * S.n + e];  // descended: reload this lane's cache column (after a reset nothing reads it again)
         pf.mark(2);
         need_gen = false;
         if (pass == 1) break;
@@ -1400,7 +1418,10 @@ void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint
     int ns = gen_slots(hw, 8 * 1024);  // inline generation is rare (descents, spare misses): a small LDS footprint keeps k_regen co-resident
     size_t smem = (size_t)ns * hw * 2;
     if (bfs_bytes(c) > smem) smem = bfs_bytes(c);
-    hipLaunchKernelGGL(k_step, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *SP, *c, keys, err_any, ns, use_spares);
+    smem = (smem + 15) & ~(size_t)15;
+    int mc_offset = (int)smem;
+    smem += (size_t)c->room_num_x * c->room_num_y * WAVE * 4;  // LDS monster cache
+    hipLaunchKernelGGL(k_step, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *SP, *c, keys, err_any, ns, use_spares, mc_offset);
 }
 void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
