@@ -29,19 +29,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "rogue-gym_amd"))
 
-ALGO_BYTES_PER_STEP = 3200      # SURVEY.md 8(d), mini gray: 512*4 obs + 512*2 tile state + 128 scalars/entities
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 KERNELS = ["k_step", "k_render", "k_obs", "k_build"]
 # per-kernel share of the algorithmic bytes (DESIGN.md "Kernels"): scalars/entities | tile state | obs write (+ mirror read)
 KERNEL_ALGO_BYTES = {"k_step": 128, "k_render": 1024, "k_obs": 3072}  # k_obs = fused mirror refresh + encode: 1024 tile + 2048 obs
 
 
-def mini_config():
+# --workload: the default is BASELINE.json configs[1] (the one the metric is quoted on).  The others are the larger parity configs of
+# SURVEY.md 8(d), benchable through the same harness for DESIGN.md's tables; they are not the headline line.
+WORKLOADS = {
+    #  name            golden config, envs/GPU, obs kind, algorithmic B/env-step, per-kernel {k_step, k_obs} bytes, description
+    "mini":          ("mini", 65536, "gray", 3200, (128, 3072), "config-mini.json 32x16"),
+    "default":       ("default", 32768, "gray", 11776, (256, 11520), "config-default.json 80x24 multi-level"),
+    "nohide-symbol": ("nohide", 32768, "symbol", 334336, (256, 334080), "config-nohide.json 80x24, one-hot symbol obs [N,43,24,80]"),
+}
+
+
+def golden_config(name):
     with open(os.path.join(ROOT, "tests", "golden", "reference_goldens.json")) as f:
-        return json.load(f)["configs"]["mini"]
+        return json.load(f)["configs"][name]
 
 
-def cpu_baseline(cfg, budget_s=12.0):
+def cpu_baseline(cfg, desc, budget_s=12.0):
     """The C oracle (a port, not the Rust reference) on all host cores, same workload shape."""
     import numpy as np
     from oracle.pyoracle import OracleBatch
@@ -62,8 +71,8 @@ def cpu_baseline(cfg, budget_s=12.0):
         steps += 10
     dt = time.time() - t0
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d lock-step steps of config-mini (seeds 0..%d, random 11-action policy, gray obs), C oracle -O3, %d pthreads, %.1f s"
-                      % (n, steps, n - 1, cores, dt)}
+            "sample": "%d envs x %d lock-step steps of %s (seeds 0..%d, random 11-action policy, gray obs), C oracle -O3, %d pthreads, %.1f s"
+                      % (n, steps, desc, n - 1, cores, dt)}
 
 
 def main():
@@ -71,7 +80,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mini")
+    ap.add_argument("--envs-per-gpu", type=int, default=0, help="default: the workload's own size (65 536 for mini)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--time-every", type=int, default=8, help="bracket every N-th kernel launch with HIP events (roofline leg)")
     ap.add_argument("--gather-steps", type=int, default=50, help="extra steps timed WITH the observation all-gather (N>1)")
@@ -102,11 +112,14 @@ def main():
 
     from rogue_gym.envs import DungeonType, HipVecRogueEnv, ImageSetting, StatusFlag
 
-    cfg = mini_config()
-    n = args.envs_per_gpu
+    cfg_name, n_default, obs_kind, algo_bytes, (step_bytes, obs_bytes), wl_desc = WORKLOADS[args.workload]
+    cfg = golden_config(cfg_name)
+    n = args.envs_per_gpu or n_default
+    KERNEL_ALGO_BYTES.update({"k_step": step_bytes, "k_obs": obs_bytes})
     first = rank * n
     cfgs = [json.dumps(dict(cfg, seed=first + i)) for i in range(n)]
-    env = HipVecRogueEnv(cfgs, max_steps=1000, image_setting=ImageSetting(DungeonType.GRAY, StatusFlag.EMPTY, False), device=local_rank)
+    env = HipVecRogueEnv(cfgs, max_steps=1000, image_setting=ImageSetting(DungeonType.GRAY if obs_kind == "gray" else DungeonType.SYMBOL, StatusFlag.EMPTY, False),
+                         device=local_rank)
     L, h = env._h.L, env._h.h
 
     K, W = args.steps, args.warmup
@@ -168,14 +181,15 @@ def main():
                                           "algo_GBps": KERNEL_ALGO_BYTES[KERNELS[k]] * n / (avg_ms * 1e-3) / 1e9}
         dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_us"]) if per_kernel else "k_step"
         dom_s = per_kernel[dom]["avg_us"] * 1e-6 if per_kernel else dt_max / K
-        achieved = ALGO_BYTES_PER_STEP * n / dom_s / 1e9
+        achieved = algo_bytes * n / dom_s / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from rocprofv3 --pmc passes (see profiles/README.md)
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.workload == "mini":
             with open(pmc) as f:
                 traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
         out = {
-            "metric": "env-steps/sec (whole node) at 65 536 envs, 32x16 mini-dungeon",
+            "metric": "env-steps/sec (whole node) at 65 536 envs, 32x16 mini-dungeon" if args.workload == "mini" and n == 65536
+                      else "env-steps/sec (whole node), workload %s, %d envs per GPU" % (args.workload, n),
             "value": n * world * K / dt_max,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -187,18 +201,18 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/u16 integer state, f32 observation",
             "data": "synthetic (per-env seed = env index, uniform-random 11-action policy)",
-            "config": {"workload": "config-mini.json 32x16, %d envs per GPU (%d total), gray-image obs [N,1,16,32] f32, max_steps 1000, auto-reset"
-                                   % (n, n * world), "envs_per_gpu": n, "parallelism": "env-sharded x%d, no data-path collective" % world},
+            "config": {"workload": "%s, %d envs per GPU (%d total), %s-image obs [N,%d,%d,%d] f32, max_steps 1000, auto-reset"
+                                   % (wl_desc, n, n * world, obs_kind, env.channels, env.height, env.width), "envs_per_gpu": n, "parallelism": "env-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic,
                          "note": "achieved = %d algorithmic B/env-step x %d envs / avg %s duration (HIP events on the launch stream); "
-                                 "the step kernel is latency/divergence-bound, not bandwidth-bound" % (ALGO_BYTES_PER_STEP, n, dom),
+                                 "the step kernel is latency/divergence-bound, not bandwidth-bound" % (algo_bytes, n, dom),
                          "per_kernel": per_kernel},
         }
         if gather:
             out["allgather"] = gather
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+        if world == 1 and not args.no_cpu_baseline and obs_kind == "gray":
+            out["cpu_baseline"] = cpu_baseline(cfg, wl_desc)
         print(json.dumps(out), flush=True)
     env.close()
     if world > 1:

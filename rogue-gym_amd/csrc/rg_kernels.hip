@@ -1155,7 +1155,7 @@ __device__ __forceinline__ bool dist_cache_lookup(const RgState &S, const Env &E
 // EnemyHandler::move_actives moves + actions::move_active_enemies attacks
 // (enemies.rs:366-424, rogue/mod.rs:339-397, actions.rs:82-119, fight.rs:41-72)
 __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &c, Env &E, uint32_t rand_mask, uint64_t rand_dir, int map_slot, uint32_t &react) {
-    const int nrooms = c.room_num_x * c.room_num_y, W = c.width, n = E.n, e = E.e;
+    const int nrooms = c.room_num_x * c.room_num_y, W = c.width, e = E.e;
     const uint16_t *dist = S.dc_map + ((size_t)e * RG_DIST_SLOTS + (map_slot < 0 ? 0 : map_slot)) * S.hw;
     const uint32_t ppos = POS(E.px, E.py);
     uint64_t att_list = 0; int n_att = 0;

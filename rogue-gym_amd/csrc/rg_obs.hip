@@ -6,6 +6,7 @@
 // Built as its own translation unit with -Os: these kernels are bandwidth/latency-bound and measurably faster with less
 // unrolling (k_obs 83 -> 67-70 us at 65 536 mini envs), while the issue-bound step kernel wants -O3.
 // file:line citations are relative to /root/reference.
+#include <cstdlib>
 #include "rg_device.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -184,6 +185,9 @@ struct ObsTabs {  // per-env entity/room tables staged in LDS: every global load
 };
 #define OBS_ENV_BYTES(hw) ((((size_t)(hw) + sizeof(ObsTabs)) + 15) & ~(size_t)15)
 
+// LDS-only workgroup barrier: unlike __syncthreads() it does not drain vmcnt, so the prefetched global loads of the next env stay in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int KIND>
 __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint32_t sflag, int with_hist, float *__restrict__ out,
                                                     uint32_t *__restrict__ err_any, int tpe, int epb) {
@@ -204,26 +208,41 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
     const int nplanes = base_planes + __popc(sflag) + (with_hist ? 1 : 0);
     uint8_t *scr = envs + (size_t)le * OBS_ENV_BYTES(HW);
     ObsTabs *tb = reinterpret_cast<ObsTabs *>(scr + HW);
+    // Persistent blocks, software-pipelined: the loads of the NEXT env of this block (flag word and, speculatively -- most steps redraw --
+    // its first tile quad + entity tables) are requested before the current env is encoded, so every env costs one exposed round trip at most.
+    // An env that did not redraw wastes <= 1 KB of reads.
+    struct Pre { uint32_t fl; uint4 v0; uint32_t rect, mon, gold, meta, ppos; };
+    auto prefetch = [&](int base) {
+        Pre p; p.fl = 0; p.v0 = make_uint4(0, 0, 0, 0); p.rect = p.mon = p.gold = p.meta = p.ppos = 0;
+        const int e = base + le;
+        if (le < epb && e < n) {
+            p.fl = S.flags[e];
+            if (lt < Q8) p.v0 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW)[lt];
+            if (lt < nrooms) { p.rect = S.room_rect[lt * n + e]; p.meta = S.room_meta[lt * n + e]; p.mon = S.mon_w0[lt * n + e]; p.gold = S.gold_pos[lt * n + e]; }
+            if (lt == tpe - 1) p.ppos = S.p_pos[e];
+        }
+        return p;
+    };
+    Pre nxt = prefetch(blockIdx.x * epb);
     for (int base = blockIdx.x * epb; base < n; base += gridDim.x * epb) {
         const int e = base + le;
         const bool valid = le < epb && e < n;
-        uint32_t fl = 0;
-        bool redraw = false;
-        if (valid) { fl = S.flags[e]; redraw = fl & RG_FLAG_REDRAW; }
-        __syncthreads();  // LUTs ready / previous iteration's LDS reads done
-        // ---- phase A: every global load of this env, independent of each other ----
+        const Pre cur = nxt;
+        if (base + (int)gridDim.x * epb < n) nxt = prefetch(base + gridDim.x * epb);
+        const uint32_t fl = cur.fl;
+        const bool redraw = valid && (fl & RG_FLAG_REDRAW);
+        const uint4 *cell4 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW);
+        const uint4 v0 = cur.v0;
+        const uint32_t t_rect = cur.rect, t_mon = cur.mon, t_gold = cur.gold, t_meta = cur.meta, t_ppos = cur.ppos;
+        lds_barrier();  // LUTs ready / previous iteration's LDS reads done
         if (valid) {
             if (redraw) {
-                if (lt < nrooms) {
-                    tb->rect[lt] = S.room_rect[lt * n + e]; tb->meta[lt] = S.room_meta[lt * n + e];
-                    tb->mon[lt] = S.mon_w0[lt * n + e]; tb->gold[lt] = S.gold_pos[lt * n + e];
-                }
-                if (lt == tpe - 1) tb->ppos = S.p_pos[e];
-                const uint4 *cell4 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW);
+                if (lt < nrooms) { tb->rect[lt] = t_rect; tb->meta[lt] = (uint8_t)t_meta; tb->mon[lt] = t_mon; tb->gold[lt] = t_gold; }
+                if (lt == tpe - 1) tb->ppos = t_ppos;
                 const bool upd_hist = !(fl & RG_FLAG_HIST_STALE);
                 uint2 *hist8 = reinterpret_cast<uint2 *>(S.hist + (size_t)e * HW);
                 for (int i = lt; i < Q8; i += tpe) {
-                    uint4 v = cell4[i];
+                    uint4 v = i == lt ? v0 : cell4[i];
                     uint32_t q[4] = {v.x, v.y, v.z, v.w};
                     uint32_t g[2] = {0, 0}, hb[2] = {0, 0};
 #pragma unroll
@@ -245,7 +264,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                 for (int i = lt; i < Q8; i += tpe) reinterpret_cast<uint2 *>(scr)[i] = m8[i];
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- phase B: entity overlays from LDS only; draw priority monster < gold < player (core/src/lib.rs:271-283) ----
         const uint32_t ppos = (valid && redraw) ? tb->ppos : 0;
         const int px = POS_X(ppos), py = POS_Y(ppos);
@@ -270,7 +289,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                 if (show && (scr[y * W + x] & 0x80u)) scr[y * W + x] = (uint8_t)(0x80u | c.mon[(w >> 16) & 0xff].tile);
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (valid && redraw) {
             if (lt < nrooms) {
                 uint32_t g = tb->gold[lt];
@@ -280,50 +299,50 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                 }
             } else if (lt == nrooms && (scr[py * W + px] & 0x80u)) scr[py * W + px] = (uint8_t)(0x80u | '@');
         }
-        __syncthreads();
-        // ---- phase C: mirror write-back + encode ----
+        lds_barrier();
+        if (with_hist) __syncthreads();  // the history plane is re-read from global memory below (written in phase A by other lanes)
+        // ---- phase C: mirror write-back + encode.  One float4 (4 cells) per lane per plane, lanes contiguous: every wave-level store
+        //      covers whole 128-byte lines (1 KB per instruction) ----
         if (valid) {
-            uint2 *m8 = reinterpret_cast<uint2 *>(S.screen + (size_t)e * HW);
+            uint32_t *m4 = reinterpret_cast<uint32_t *>(S.screen + (size_t)e * HW);
+            const uint32_t *scr4 = reinterpret_cast<const uint32_t *>(scr);
+            const uint32_t *hist4 = reinterpret_cast<const uint32_t *>(S.hist + (size_t)e * HW);
             float4 *o = reinterpret_cast<float4 *>(out + (size_t)e * nplanes * HW);
             const int q4 = HW >> 2;
+            const uint32_t smax = (uint32_t)symbols - 1;  // construct_symbol_map fills channels 0..symbols-2 (symbol.rs:51-71)
+            float stf[9];
+            int nst = 0;
+            for (int b = 0; b < 9; b++)
+                if (sflag & (1u << b)) stf[nst++] = (float)S.status[(size_t)e * 10 + kStatusIdx[b]];
             bool bad = false;
-            for (int i = lt; i < Q8; i += tpe) {
-                uint2 g = reinterpret_cast<const uint2 *>(scr)[i];
-                g.x &= 0x7f7f7f7fu; g.y &= 0x7f7f7f7fu;
-                if (redraw) m8[i] = g;
-                uint32_t gg[2] = {g.x, g.y};
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    uint32_t b0 = gg[half] & 0x7f, b1 = (gg[half] >> 8) & 0x7f, b2 = (gg[half] >> 16) & 0x7f, b3 = (gg[half] >> 24) & 0x7f;
-                    if (KIND == 0) {
-                        float4 v; v.x = lutf[b0]; v.y = lutf[b1]; v.z = lutf[b2]; v.w = lutf[b3];
-                        store_obs(&o[2 * i + half], v);
-                    } else {
-                        uint32_t s0 = luts[b0], s1 = luts[b1], s2 = luts[b2], s3 = luts[b3];
-                        uint32_t smax = (uint32_t)symbols - 1;  // construct_symbol_map fills channels 0..symbols-2 (symbol.rs:51-71)
-                        bad = bad || s0 >= smax || s1 >= smax || s2 >= smax || s3 >= smax;
-                        for (uint32_t ch = 0; ch < (uint32_t)symbols; ch++) {
-                            float4 v;
-                            v.x = s0 == ch ? 1.f : 0.f; v.y = s1 == ch ? 1.f : 0.f; v.z = s2 == ch ? 1.f : 0.f; v.w = s3 == ch ? 1.f : 0.f;
-                            if (ch >= smax) v.x = v.y = v.z = v.w = 0.f;
-                            store_obs(&o[(size_t)ch * q4 + 2 * i + half], v);
-                        }
+            for (int q = lt; q < q4; q += tpe) {
+                const uint32_t g = scr4[q] & 0x7f7f7f7fu;
+                if (redraw) m4[q] = g;
+                const uint32_t b0 = g & 0x7f, b1 = (g >> 8) & 0x7f, b2 = (g >> 16) & 0x7f, b3 = g >> 24;
+                if (KIND == 0) {
+                    float4 v; v.x = lutf[b0]; v.y = lutf[b1]; v.z = lutf[b2]; v.w = lutf[b3];
+                    store_obs(&o[q], v);
+                } else {
+                    const uint32_t s0 = luts[b0], s1 = luts[b1], s2 = luts[b2], s3 = luts[b3];
+                    bad = bad || s0 >= smax || s1 >= smax || s2 >= smax || s3 >= smax;
+                    for (uint32_t ch = 0; ch < smax; ch++) {
+                        float4 v;
+                        v.x = s0 == ch ? 1.f : 0.f; v.y = s1 == ch ? 1.f : 0.f; v.z = s2 == ch ? 1.f : 0.f; v.w = s3 == ch ? 1.f : 0.f;
+                        store_obs(&o[(size_t)ch * q4 + q], v);
                     }
+                    float4 z; z.x = z.y = z.z = z.w = 0.f;
+                    store_obs(&o[(size_t)smax * q4 + q], z);  // the last channel is never set
                 }
                 int p = base_planes;
-                for (int b = 0; b < 9; b++)
-                    if (sflag & (1u << b)) {
-                        float f = (float)S.status[(size_t)e * 10 + kStatusIdx[b]];
-                        float4 sv; sv.x = sv.y = sv.z = sv.w = f;
-                        store_obs(&o[(size_t)p * q4 + 2 * i], sv); store_obs(&o[(size_t)p * q4 + 2 * i + 1], sv);
-                        p++;
-                    }
+                for (int b = 0; b < nst; b++, p++) {
+                    float4 sv; sv.x = sv.y = sv.z = sv.w = stf[b];
+                    store_obs(&o[(size_t)p * q4 + q], sv);
+                }
                 if (with_hist) {
-                    uint2 h8 = reinterpret_cast<const uint2 *>(S.hist + (size_t)e * HW)[i];
-                    float4 a, b2;
-                    a.x = (h8.x & 0xff) ? 1.f : 0.f; a.y = (h8.x & 0xff00) ? 1.f : 0.f; a.z = (h8.x & 0xff0000) ? 1.f : 0.f; a.w = (h8.x >> 24) ? 1.f : 0.f;
-                    b2.x = (h8.y & 0xff) ? 1.f : 0.f; b2.y = (h8.y & 0xff00) ? 1.f : 0.f; b2.z = (h8.y & 0xff0000) ? 1.f : 0.f; b2.w = (h8.y >> 24) ? 1.f : 0.f;
-                    store_obs(&o[(size_t)p * q4 + 2 * i], a); store_obs(&o[(size_t)p * q4 + 2 * i + 1], b2);
+                    const uint32_t h4 = hist4[q];  // written in phase A by this block when the env was redrawn (barrier in between)
+                    float4 a;
+                    a.x = (h4 & 0xff) ? 1.f : 0.f; a.y = (h4 & 0xff00) ? 1.f : 0.f; a.z = (h4 & 0xff0000) ? 1.f : 0.f; a.w = (h4 >> 24) ? 1.f : 0.f;
+                    store_obs(&o[(size_t)p * q4 + q], a);
                 }
             }
             if (KIND == 1 && bad) { atomicOr(&S.flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
@@ -373,7 +392,8 @@ int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, 
     const int bthreads = tpe, epb = 1;  // one env per block: no cross-env barrier coupling (4 envs per 256-thread block measured 10-20 % slower)
     size_t smem = 512 + 128 + (size_t)epb * OBS_ENV_BYTES(hw);
     int blocks = (S->n + epb - 1) / epb;
-    if (blocks > 65536) blocks = 65536;
+    // persistent grid: launching one tiny workgroup per env is dispatch-rate bound (65 536 one-wave blocks: 71 us; 16 384 looping blocks: 51 us)
+    { const char *ev = getenv("RG_OBS_BLOCKS"); int cap = ev ? atoi(ev) : (bthreads <= 64 ? 16384 : 8192); if (blocks > cap) blocks = cap; }
     if (!kind) hipLaunchKernelGGL(k_obs<0>, dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb);
     else hipLaunchKernelGGL(k_obs<1>, dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb);
     return 1;

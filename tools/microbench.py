@@ -118,3 +118,34 @@ if __name__ == "__main__" and "gen1" in sys.argv[1:]:
         single_gen("mini", G["configs"]["mini"], n)
     single_gen("default", G["configs"]["default"], 1)
     single_gen("mini-noenemy", dict(G["configs"]["mini"], enemies={"enemies": []}), 1)
+
+
+def obs_only(name, cfg, n=65536, reps=300, step_every=0):
+    """k_obs in isolation: without steps in between no env redraws (mirror path: 512 B read + 2 KB write per mini env)."""
+    cfgs = [json.dumps(dict(cfg, seed=i)) for i in range(n)]
+    h = inner._Handle(cfgs, 1000, True)
+    L = h.L
+    dev = torch.device("cuda", 0)
+    obs = torch.empty((n, 1, h.height, h.width), dtype=torch.float32, device=dev)
+    table = torch.tensor(list(b".hjklnbuy>s"), dtype=torch.uint8, device=dev)
+    keys = table[torch.randint(0, 11, (64, n), device=dev)].contiguous()
+    for t in range(100):
+        L.rg_step(h.h, C.c_void_p(keys[t % 64].data_ptr()), 1)
+        L.rg_obs_gray(h.h, 0, 0, C.c_void_p(obs.data_ptr()))
+    torch.cuda.synchronize()
+    L.rg_timing_enable(h.h, 1)
+    for t in range(reps):
+        if step_every and t % step_every == 0:
+            L.rg_step(h.h, C.c_void_p(keys[t % 64].data_ptr()), 1)
+        L.rg_obs_gray(h.h, 0, 0, C.c_void_p(obs.data_ptr()))
+    ms = (C.c_double * 4)()
+    cnt = (C.c_uint64 * 4)()
+    L.rg_timing_read(h.h, ms, cnt)
+    print("%-34s n=%d k_obs avg %.1f us (step avg %.1f us)" % (name, n, ms[2] / cnt[2] * 1e3, ms[0] / max(cnt[0], 1) * 1e3), flush=True)
+    h.close()
+
+
+if __name__ == "__main__" and "obs" in sys.argv[1:]:
+    obs_only("mini obs-only (no redraw)", G["configs"]["mini"])
+    obs_only("mini step+obs", G["configs"]["mini"], step_every=1)
+    obs_only("mini step + 2 obs", G["configs"]["mini"], step_every=2)
