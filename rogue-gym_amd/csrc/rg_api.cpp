@@ -368,13 +368,15 @@ done:
     return rc;
 }
 
-// development aid: in-kernel phase profile (cycles); out[0..31] = max over waves, out[32..63] = sum over waves, out[64..79] = wave-duration histogram
+// development aid: in-kernel phase trace; out = [ceil(n_env / 64)][64] words, one row per wave of the LAST k_step / k_build launch
+// (word 0 = record count, words 1.. = phase << 48 | ticks, word 63 = whole-wave ticks)
 int rg_prof(rg_t *h, int enable, unsigned long long *out) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (out && h->S.prof) HIPCHK(h, hipMemcpy(out, h->S.prof, 128 * 8, hipMemcpyDeviceToHost));
-    if (enable && !h->S.prof) { if (!dev_alloc(h, &h->S.prof, 128)) return 1; }
-    if (h->S.prof) HIPCHK(h, hipMemset(h->S.prof, 0, 128 * 8));
+    const size_t words = (size_t)((h->S.n + 63) / 64) * 64;
+    if (out && h->S.prof) HIPCHK(h, hipMemcpy(out, h->S.prof, words * 8, hipMemcpyDeviceToHost));
+    if (enable && !h->S.prof) { if (!dev_alloc(h, &h->S.prof, words)) return 1; }
+    if (h->S.prof) HIPCHK(h, hipMemset(h->S.prof, 0, words * 8));
     if (!enable) h->S.prof = nullptr;
     return 0;
 }

@@ -68,21 +68,41 @@ __device__ __forceinline__ uint64_t range64(Rng &r, uint64_t low, uint64_t high)
 __device__ __forceinline__ bool does_happen(Rng &r, uint32_t p_inv) { return range32(r, 0, p_inv) == 0; }
 __device__ __forceinline__ bool parcent(Rng &r, uint32_t p) { return range32(r, 1, 101) <= p; }
 
-// optional phase profile: lane 0 of every wave folds its elapsed cycles per phase into S.prof (max and sum)
+// Direction -> (dx, dy) as immediates (a __constant__ table indexed per lane is a memory load); same order as kDX / kDY
+constexpr uint32_t dir_pack(const int (&t)[9]) {
+    uint32_t r = 0;
+    for (int d = 0; d < 9; d++) r |= (uint32_t)(t[d] + 1) << (2 * d);
+    return r;
+}
+constexpr int kDXc[9] = {0, 0, -1, 1, -1, 1, -1, 1, 0}, kDYc[9] = {-1, 1, 0, 0, -1, -1, 1, 1, 0};
+__device__ __forceinline__ int dir_dx(int d) { return (int)((dir_pack(kDXc) >> (2 * d)) & 3u) - 1; }
+__device__ __forceinline__ int dir_dy(int d) { return (int)((dir_pack(kDYc) >> (2 * d)) & 3u) - 1; }
+
+
+// optional phase trace (development aid, tools/microbench.py prof): lane 0 of every wave appends (phase, elapsed shader-clock ticks)
+// records to the wave's own 64-word row of S.prof with plain stores -- no atomics, so the trace does not perturb what it measures.
+// Word 0 = number of records, word 63 = whole-wave ticks.
 struct Prof {
-    unsigned long long *p; unsigned long long t, t0;
-    __device__ __forceinline__ void start(unsigned long long *pp) { p = pp; if (p) t = t0 = __builtin_amdgcn_s_memtime(); }
+    unsigned long long *p; unsigned long long t, t0; int k;
+    __device__ __forceinline__ void start(unsigned long long *pp) { p = pp ? pp + (size_t)blockIdx.x * 64 : nullptr; k = 0; if (p) t = t0 = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void rec(int phase, unsigned long long v) {
+        if (p && threadIdx.x == 0 && k < 61) p[1 + k++] = ((unsigned long long)phase << 48) | (v & 0xffffffffffffull);
+    }
     __device__ __forceinline__ void mark(int phase) {
         if (!p) return;
         unsigned long long now = __builtin_amdgcn_s_memtime();
-        if (threadIdx.x == 0) { atomicMax(&p[phase], now - t); atomicAdd(&p[32 + phase], now - t); }
+        rec(phase, now - t);
         t = now;
+    }
+    __device__ __forceinline__ void finish() {
+        if (p && threadIdx.x == 0) { p[0] = (unsigned long long)k; p[63] = __builtin_amdgcn_s_memtime() - t0; }
     }
 };
 
 // ---------------------------------------------------------------------------------------------
 // per-lane environment view
 // ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
 struct Env {
     int e;              // env index
     int n;              // env count (SoA stride)
@@ -93,12 +113,14 @@ struct Env {
     int hp, hpmax, plvl;
     uint32_t exp, food, quiet, gold, dlevel;
     uint32_t mon_alive, mon_active;
+    lds_u16 *lc;        // generation: the lane's LDS staging grid through an LDS-typed pointer (ds_read / ds_write instead of flat accesses)
+    uint16_t *stk_lds;  // generation: LDS maze stack of the lane's slot (GEN_STACK_LDS entries), else nullptr
     uint32_t *mc;       // k_step: this lane's column of the wave's LDS monster cache (word s at mc[s * WAVE]); write-through
 };
 
 // Floor::can_move_impl (floor.rs:169-182)
 __device__ __forceinline__ bool can_move(const RgConfig &c, const uint16_t *cell, int x, int y, int d, bool is_enemy) {
-    int dx = kDX[d], dy = kDY[d];
+    int dx = dir_dx(d), dy = dir_dy(d);
     int nx = x + dx, ny = y + dy;
     if (!in_bounds(c, nx, ny)) return false;
     uint32_t nc = cell[ny * c.width + nx];
@@ -188,7 +210,7 @@ __device__ __forceinline__ void player_in(const RgState &S, const RgConfig &c, E
     }
     cell[y * W + x] |= C_VISITED;
     for (int d = 0; d < 9; d++) {
-        int cx = x + kDX[d], cy = y + kDY[d];
+        int cx = x + dir_dx(d), cy = y + dir_dy(d);
         if (!in_bounds(c, cx, cy)) continue;
         uint32_t v = cell[cy * W + cx];
         bool diag = d >= 4 && d < 8;
@@ -214,7 +236,7 @@ __device__ __forceinline__ void player_out(const RgState &S, const RgConfig &c, 
         }
     }
     for (int d = 0; d < 9; d++) {
-        int cx = x + kDX[d], cy = y + kDY[d];
+        int cx = x + dir_dx(d), cy = y + dir_dy(d);
         if (!in_bounds(c, cx, cy)) continue;
         uint32_t v = cell[cy * W + cx];
         if ((v & C_SURF_MASK) == S_FLOOR && (v & C_DARK)) cell[cy * W + cx] = v & ~C_VISIBLE;  // Cell::left
@@ -248,12 +270,12 @@ __device__ __forceinline__ bool room_select(const RgState &S, const RgConfig &c,
     int count = 0;
     for (int yy = y0; yy < y1; yy++)
         for (int xx = x0; xx < x1; xx++)
-            if ((E.cell[yy * c.width + xx] & C_MAZE) && POS(xx, yy) != excl) count++;
+            if ((E.lc[yy * c.width + xx] & C_MAZE) && POS(xx, yy) != excl) count++;
     if (count == 0) return false;
     int nth = (int)range64(E.rd, 0, (uint64_t)count);
     for (int yy = y0; yy < y1; yy++)
         for (int xx = x0; xx < x1; xx++)
-            if ((E.cell[yy * c.width + xx] & C_MAZE) && POS(xx, yy) != excl) {
+            if ((E.lc[yy * c.width + xx] & C_MAZE) && POS(xx, yy) != excl) {
                 if (nth == 0) { out = POS(xx, yy); return true; }
                 nth--;
             }
@@ -289,11 +311,11 @@ __device__ __forceinline__ uint32_t gen_attr_corridor(const RgConfig &c, Env &E,
 // one registered corridor cell (floor.rs:87-101)
 __device__ __forceinline__ void register_cell(const RgConfig &c, Env &E, int x, int y, int kind, uint32_t level) {
     uint32_t a = gen_attr_corridor(c, E, kind, level);
-    uint32_t v = E.cell[y * c.width + x];
+    uint32_t v = E.lc[y * c.width + x];
     v = (v & ~C_ATTR_MASK) | a;
     if (kind == S_DOOR) v |= C_DOOR;
     if (!a) v = (v & ~C_SURF_MASK) | (uint32_t)kind;
-    E.cell[y * c.width + x] = (uint16_t)v;
+    E.lc[y * c.width + x] = (uint16_t)v;
 }
 
 // select_start_or_end (passages.rs:143-179).  dir: 0 Up 1 Down 2 Left 3 Right
@@ -318,20 +340,20 @@ __device__ __forceinline__ uint32_t select_door(const RgState &S, const RgConfig
         if (dir < 2) {
             int yy = dir == 1 ? ry1 - 1 : ry0;
             for (int xx = rx0; xx < rx1; xx++)
-                if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.cell[yy * c.width + xx] & C_MAZE)) cnt++;
+                if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.lc[yy * c.width + xx] & C_MAZE)) cnt++;
             if (cnt) {
                 int k = (int)range64(E.rd, 0, (uint64_t)cnt);
                 for (int xx = rx0; xx < rx1; xx++)
-                    if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.cell[yy * c.width + xx] & C_MAZE)) { if (k == 0) return POS(xx, yy); k--; }
+                    if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.lc[yy * c.width + xx] & C_MAZE)) { if (k == 0) return POS(xx, yy); k--; }
             }
         } else {
             int xx = dir == 2 ? rx0 : rx1 - 1;
             for (int yy = ry0; yy < ry1; yy++)
-                if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.cell[yy * c.width + xx] & C_MAZE)) cnt++;
+                if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.lc[yy * c.width + xx] & C_MAZE)) cnt++;
             if (cnt) {
                 int k = (int)range64(E.rd, 0, (uint64_t)cnt);
                 for (int yy = ry0; yy < ry1; yy++)
-                    if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.cell[yy * c.width + xx] & C_MAZE)) { if (k == 0) return POS(xx, yy); k--; }
+                    if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.lc[yy * c.width + xx] & C_MAZE)) { if (k == 0) return POS(xx, yy); k--; }
             }
         }
         if (dir == 1) ry1--; else if (dir == 2) rx0--; else if (dir == 3) rx1--; else ry0--;
@@ -395,25 +417,49 @@ __device__ __forceinline__ int select_candidate(const RgConfig &c, Env &E, int n
     return res;
 }
 
+// Per-slot generator tables in LDS (gen_service): while a level is generated, the room / monster / gold tables, the corridor records and the
+// maze stack are read and written hundreds of times in a dependent chain -- against global memory each access is a round trip (a maze room
+// alone cost ~30 us through its global-memory stack).  Copied out to the env's SoA columns when the level is done.
+#define GEN_STACK_LDS 128
+struct GenTabs {
+    uint32_t room_rect[RG_MAX_ROOMS], mon_w0[RG_MAX_ROOMS], mon_exp[RG_MAX_ROOMS], gold_pos[RG_MAX_ROOMS], gold_amt[RG_MAX_ROOMS];
+    int32_t mon_hp[RG_MAX_ROOMS];
+    uint32_t edge_a[RG_MAX_EDGES], edge_b[RG_MAX_EDGES];
+    uint16_t stack[GEN_STACK_LDS];
+    uint8_t room_meta[RG_MAX_ROOMS];
+};
+#define GEN_TABS_BYTES ((sizeof(GenTabs) + 15) & ~(size_t)15)
+#define GEN_SLOT_BYTES(hw) (((((size_t)(hw)) * 2 + 15) & ~(size_t)15) + GEN_TABS_BYTES)
+
 // dig_maze (maze.rs:38-89) with an explicit stack (the reference recurses; same visiting and draw order)
 __device__ __forceinline__ void dig_maze(const RgState &S, const RgConfig &c, Env &E, int x0, int y0, int x1, int y1) {
-    uint16_t *stk = S.maze_stack + (size_t)E.e * RG_MAZE_STACK;
+    // the DFS never holds more than one entry per maze cell (every other cell of the room in x and y)
+    const bool small = ((x1 - x0 + 1) >> 1) * ((y1 - y0 + 1) >> 1) <= GEN_STACK_LDS;
+    lds_u16 *ls = (lds_u16 *)E.stk_lds;
+    uint16_t *gs = S.maze_stack + (size_t)E.e * RG_MAZE_STACK;
+    const bool in_lds = E.stk_lds && small;
     int W = c.width, sp = 0;
-    E.cell[y0 * W + x0] |= C_MAZE;
-    stk[sp++] = (uint16_t)POS(x0, y0);
+    E.lc[y0 * W + x0] |= C_MAZE;
+    if (in_lds) ls[sp] = (uint16_t)POS(x0, y0); else gs[sp] = (uint16_t)POS(x0, y0);
+    sp++;
     while (sp > 0) {
-        int cx = POS_X(stk[sp - 1]), cy = POS_Y(stk[sp - 1]);
+        const uint32_t top = in_lds ? ls[sp - 1] : gs[sp - 1];
+        int cx = POS_X(top), cy = POS_Y(top);
         int dig = -1, i = 0;
         for (int d = 0; d < 4; d++) {
-            int nx = cx + 2 * kDX[d], ny = cy + 2 * kDY[d];
+            int nx = cx + 2 * dir_dx(d), ny = cy + 2 * dir_dy(d);
             if (nx < x0 || nx >= x1 || ny < y0 || ny >= y1) continue;
-            if (E.cell[ny * W + nx] & C_MAZE) continue;
+            if (E.lc[ny * W + nx] & C_MAZE) continue;
             if (does_happen(E.rd, (uint32_t)i + 1)) dig = d;
             i++;
         }
         if (dig < 0) { sp--; continue; }
-        for (int k = 1; k <= 2; k++) E.cell[(cy + k * kDY[dig]) * W + cx + k * kDX[dig]] |= C_MAZE;
-        if (sp < RG_MAZE_STACK) stk[sp++] = (uint16_t)POS(cx + 2 * kDX[dig], cy + 2 * kDY[dig]);
+        for (int k = 1; k <= 2; k++) E.lc[(cy + k * dir_dy(dig)) * W + cx + k * dir_dx(dig)] |= C_MAZE;
+        if (sp < RG_MAZE_STACK) {
+            const uint16_t nv = (uint16_t)POS(cx + 2 * dir_dx(dig), cy + 2 * dir_dy(dig));
+            if (in_lds) ls[sp] = nv; else gs[sp] = nv;
+            sp++;
+        }
     }
 }
 
@@ -421,13 +467,15 @@ __device__ __forceinline__ void dig_maze(const RgState &S, const RgConfig &c, En
 __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &c, Env &E, Prof &pf) {
     const int W = c.width, H = c.height, HW = W * H, n = E.n, e = E.e;
     const int rnx = c.room_num_x, nrooms = rnx * c.room_num_y;
-    uint16_t *cell = E.cell;
+    lds_u16 *cell = E.lc;
     const uint32_t level = ++E.dlevel;
 
     // fresh Field: Surface::None, no attributes (16-byte stores; the grid is 16-byte aligned)
     {
-        uint4 v; v.x = v.y = v.z = v.w = (S_NONE | (S_NONE << 16));
-        uint4 *p = reinterpret_cast<uint4 *>(cell);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const uint32_t nn = S_NONE | (S_NONE << 16);
+        u32x4 v = {nn, nn, nn, nn};
+        __attribute__((address_space(3))) u32x4 *p = (__attribute__((address_space(3))) u32x4 *)cell;
         int n16 = HW / 8;
         for (int i = 0; i < n16; i++) p[i] = v;
         for (int i = n16 * 8; i < HW; i++) cell[i] = S_NONE;
@@ -633,19 +681,32 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
         bool mine = need && rank < nslots;
         unsigned long long tg0 = pf.p ? __builtin_amdgcn_s_memtime() : 0;
         if (mine) {
-            E.cell = lds_grid + (size_t)rank * HW;
+            uint8_t *slot = reinterpret_cast<uint8_t *>(lds_grid) + (size_t)rank * GEN_SLOT_BYTES(HW);
+            GenTabs *T = reinterpret_cast<GenTabs *>(slot + GEN_SLOT_BYTES(HW) - GEN_TABS_BYTES);
+            E.cell = reinterpret_cast<uint16_t *>(slot);
+            E.lc = (lds_u16 *)E.cell;
             if (is_build) build_prologue(S, E);
-            uint32_t non_empty = gen_level(S, c, E, pf);
-            if (is_build) build_epilogue(S, c, E);
-            place_player(S, c, E, non_empty);
+            // table view of this slot: column 0 of a 1-env SoA
+            RgState L = S;
+            L.room_rect = T->room_rect; L.room_meta = T->room_meta; L.mon_w0 = T->mon_w0; L.mon_hp = T->mon_hp; L.mon_exp = T->mon_exp;
+            L.gold_pos = T->gold_pos; L.gold_amt = T->gold_amt; L.edge_a = T->edge_a; L.edge_b = T->edge_b;
+            L.maze_stack = S.maze_stack + (size_t)E.e * RG_MAZE_STACK;
+            const int real_e = E.e, real_n = E.n, nrooms = c.room_num_x * c.room_num_y;
+            E.e = 0; E.n = 1; E.stk_lds = T->stack;
+            uint32_t non_empty = gen_level(L, c, E, pf);
+            if (is_build) build_epilogue(L, c, E);
+            place_player(L, c, E, non_empty);
+            E.e = real_e; E.n = real_n; E.stk_lds = nullptr;
+            for (int s = 0; s < nrooms; s++) {
+                const size_t g = (size_t)s * real_n + real_e;
+                S.room_rect[g] = T->room_rect[s]; S.room_meta[g] = T->room_meta[s];
+                S.mon_w0[g] = T->mon_w0[s]; S.mon_hp[g] = T->mon_hp[s]; S.mon_exp[g] = T->mon_exp[s];
+                S.gold_pos[g] = T->gold_pos[s]; S.gold_amt[g] = T->gold_amt[s];
+            }
             E.cell = E.gcell;
             need = false;
         }
-        if (pf.p && lane == 0) {  // per-round generation time, by number of concurrently generating lanes
-            unsigned long long dt = __builtin_amdgcn_s_memtime() - tg0;
-            int k = __popcll(m) == 1 ? 20 : 22;
-            atomicMax(&pf.p[k], dt); atomicAdd(&pf.p[32 + k], dt); atomicAdd(&pf.p[32 + k + 1], 1ull);
-        }
+        if (pf.p) pf.rec(__popcll(m) == 1 ? 20 : 22, __builtin_amdgcn_s_memtime() - tg0);  // per-round generation time, by number of generating lanes
         pf.mark(16);
         __syncthreads();
         int served = __popcll(m);
@@ -655,7 +716,7 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
             m &= m - 1;
             int env_s = __shfl(e, src);
             uint16_t *dst = S.cell + (size_t)env_s * HW;
-            const uint16_t *srcp = lds_grid + (size_t)r * HW;
+            const uint16_t *srcp = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(lds_grid) + (size_t)r * GEN_SLOT_BYTES(HW));
             if ((HW & 7) == 0) {
                 uint4 *d4 = reinterpret_cast<uint4 *>(dst);
                 const uint4 *s4 = reinterpret_cast<const uint4 *>(srcp);
@@ -1042,43 +1103,208 @@ __device__ __forceinline__ void player_attack(const RgState &S, const RgConfig &
     } else react |= MSG_MISS_TO;
 }
 
-// actions::move_player + get_item (actions.rs:168-231); returns `done`
-__device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c, Env &E, int d, uint32_t &react) {
+
+// ---------------------------------------------------------------------------------------------
+// the player's turn on a register window.  Every tile the player's own action reads or writes lies in the 5x5 block around
+// the position the action starts from (3x3 of the old cell for can_move / Cell::left / search, 3x3 of the new cell for
+// Cell::approached), except the whole-room updates of enters_room / leaves_room.  Against global memory those ~25 accesses
+// are ~25 dependent round trips (load -> test -> store, one after the other); here they are ONE round of 25 independent
+// loads, register arithmetic with compile-time indices, and a write-back of the cells that changed.  The whole-room updates
+// are recorded as rectangles and applied by the wave (fill_service), mirrored into the window in the reference's order.
+// ---------------------------------------------------------------------------------------------
+struct Win {
+    uint32_t v[25];        // cell (ox + i, oy + j) at index (j + 2) * 5 + (i + 2); 0 outside the grid
+    uint32_t inb, dirty;   // bit k: cell k lies inside the grid / was modified since the load
+    int ox, oy;
+};
+#define WIN_K(i, j) (((j) + 2) * 5 + (i) + 2)
+
+__device__ __forceinline__ void win_load(const RgConfig &c, const uint16_t *cell, Win &w, int ox, int oy) {
+    w.ox = ox; w.oy = oy; w.inb = 0; w.dirty = 0;
+#pragma unroll
+    for (int j = -2; j <= 2; j++)
+#pragma unroll
+        for (int i = -2; i <= 2; i++) {
+            const int x = ox + i, y = oy + j;
+            const bool in = in_bounds(c, x, y);
+            const uint32_t val = cell[in ? y * c.width + x : oy * c.width + ox];  // unconditional load: all 25 are in flight together
+            w.v[WIN_K(i, j)] = in ? val : 0u;
+            if (in) w.inb |= 1u << WIN_K(i, j);
+        }
+}
+__device__ __forceinline__ void win_flush(const RgConfig &c, uint16_t *cell, Win &w) {
+    if (!w.dirty) return;
+#pragma unroll
+    for (int j = -2; j <= 2; j++)
+#pragma unroll
+        for (int i = -2; i <= 2; i++)
+            if ((w.dirty >> WIN_K(i, j)) & 1u) cell[(w.oy + j) * c.width + w.ox + i] = (uint16_t)w.v[WIN_K(i, j)];
+    w.dirty = 0;
+}
+__device__ __forceinline__ uint32_t win_get(const Win &w, int k) {  // run-time index: a select chain, never scratch
+    uint32_t r = 0;
+#pragma unroll
+    for (int t = 0; t < 25; t++) r = (t == k) ? w.v[t] : r;
+    return r;
+}
+__device__ __forceinline__ void win_set(Win &w, int k, uint32_t val) {
+#pragma unroll
+    for (int t = 0; t < 25; t++) w.v[t] = (t == k) ? val : w.v[t];
+    w.dirty |= 1u << k;
+}
+// apply `v = (v & ~clr) | set` to the window cells inside the half-open rectangle, and mark them for write-back (the wave's global
+// fill of the same rectangle works on the pre-step values of these cells)
+__device__ __forceinline__ void win_rect(Win &w, int x0, int y0, int x1, int y1, uint32_t clr, uint32_t set) {
+#pragma unroll
+    for (int j = -2; j <= 2; j++)
+#pragma unroll
+        for (int i = -2; i <= 2; i++) {
+            const int x = w.ox + i, y = w.oy + j;
+            if (x >= x0 && x < x1 && y >= y0 && y < y1 && ((w.inb >> WIN_K(i, j)) & 1u)) {
+                w.v[WIN_K(i, j)] = (w.v[WIN_K(i, j)] & ~clr) | set;
+                w.dirty |= 1u << WIN_K(i, j);
+            }
+        }
+}
+__device__ __forceinline__ uint32_t pack_rect(int x0, int y0, int x1, int y1) { return (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24); }
+
+// Floor::can_move_impl (floor.rs:169-182) for the player standing on the window centre
+__device__ __forceinline__ bool win_can_move(const Win &w, int dx, int dy) {
+    const int k = WIN_K(dx, dy);
+    if (!((w.inb >> k) & 1u)) return false;
+    const uint32_t nc = win_get(w, k);
+    bool res = can_walk(nc) && !(nc & (C_HIDDEN | C_LOCKED));
+    if (dx != 0 && dy != 0) res = res && can_walk(win_get(w, WIN_K(dx, 0))) && can_walk(win_get(w, WIN_K(0, dy)));
+    return res;
+}
+
+// Whole-room updates requested by a lane during its move, served by the wave after the per-lane code
+struct FillReq { uint32_t leave, enter; };  // packed half-open rects, 0 = none: leaves_room clears VISIBLE, enters_room sets DRAWN | VISIBLE
+
+// actions::move_player + get_item (actions.rs:168-231).  Returns `done` (true = a MoveUntil run stops here).
+// The window is centred on the player's position before the move.
+__device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c, Env &E, Win &w, int d, uint32_t &react, FillReq &fr) {
     const int nrooms = c.room_num_x * c.room_num_y;
-    if (!can_move(c, E.cell, E.px, E.py, d, false)) return true;  // Notify(CantMove): no mirror effect
-    int nx = E.px + kDX[d], ny = E.py + kDY[d];
+    const int dx = dir_dx(d), dy = dir_dy(d);
+    if (!win_can_move(w, dx, dy)) return true;  // Notify(CantMove): no mirror effect
+    const int nx = E.px + dx, ny = E.py + dy;
     int ms = mon_find(S, E, nrooms, POS(nx, ny));
     if (ms >= 0) { player_attack(S, c, E, ms, react); return true; }
-    player_out(S, c, E, E.px, E.py);
-    player_in<true>(S, c, E, nx, ny, false);
+    // ---- Floor::player_out at the old cell (field-of-view, floor.rs:201-312) ----
+    if (w.v[WIN_K(0, 0)] & C_DOOR) {  // Floor::leaves_room (floor.rs:249-261)
+        int rid = room_id_of(c, E.px, E.py);
+        if (rid >= 0) {
+            uint8_t meta = S.room_meta[rid * E.n + E.e];
+            if ((meta & RM_VISITED) && (meta & RM_DARK)) {
+                int x0, y0, x1, y1;
+                if ((meta & RM_KIND_MASK) == RK_EMPTY) assigned_area(c, rid, x0, y0, x1, y1);
+                else unpack_rect(S.room_rect[rid * E.n + E.e], x0, y0, x1, y1);
+                if (x1 - x0 > 2 && y1 - y0 > 2) {
+                    fr.leave = pack_rect(x0 + 1, y0 + 1, x1 - 1, y1 - 1);
+                    win_rect(w, x0 + 1, y0 + 1, x1 - 1, y1 - 1, C_VISIBLE, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = -1; j <= 1; j++)
+#pragma unroll
+        for (int i = -1; i <= 1; i++) {  // Cell::left on the 3x3 around the old cell
+            const uint32_t v = w.v[WIN_K(i, j)];
+            if (((w.inb >> WIN_K(i, j)) & 1u) && (v & C_SURF_MASK) == S_FLOOR && (v & C_DARK) && (v & C_VISIBLE)) {
+                w.v[WIN_K(i, j)] = v & ~C_VISIBLE;
+                w.dirty |= 1u << WIN_K(i, j);
+            }
+        }
+    // ---- Floor::player_in at the new cell ----
+    const int nk = WIN_K(dx, dy);
+    uint32_t here = win_get(w, nk);
+    if (here & C_DOOR) {
+        int rid = room_id_of(c, nx, ny);
+        if (rid >= 0) {
+            uint8_t meta = S.room_meta[rid * E.n + E.e];
+            if (!(meta & RM_VISITED)) {  // Floor::enters_room (floor.rs:231-247)
+                S.room_meta[rid * E.n + E.e] = meta | RM_VISITED;
+                if ((meta & RM_KIND_MASK) == RK_NORMAL && !(meta & RM_DARK)) {
+                    int x0, y0, x1, y1;
+                    unpack_rect(S.room_rect[rid * E.n + E.e], x0, y0, x1, y1);
+                    fr.enter = pack_rect(x0, y0, x1, y1);
+                    win_rect(w, x0, y0, x1, y1, 0, C_DRAWN | C_VISIBLE);
+                }
+            }
+            activate_room<true>(S, c, E, rid);
+        }
+        here = win_get(w, nk);
+    }
+    if (!(here & C_VISITED)) win_set(w, nk, here | C_VISITED);
+#pragma unroll
+    for (int j = -2; j <= 2; j++)
+#pragma unroll
+        for (int i = -2; i <= 2; i++) {  // Cell::approached (field.rs:20-26) on the 3x3 around the new cell
+            const int ddx = i - dx, ddy = j - dy;
+            const bool near = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && ((w.inb >> WIN_K(i, j)) & 1u);
+            const uint32_t v = w.v[WIN_K(i, j)];
+            const bool diag = ddx != 0 && ddy != 0;
+            if (near && !(diag && (v & C_SURF_MASK) == S_PASSAGE) && !(v & C_HIDDEN) && (v & (C_DRAWN | C_VISIBLE)) != (C_DRAWN | C_VISIBLE)) {
+                w.v[WIN_K(i, j)] = v | C_DRAWN | C_VISIBLE;
+                w.dirty |= 1u << WIN_K(i, j);
+            }
+        }
     E.px = nx; E.py = ny;
     react |= R_REDRAW;
-    uint32_t v = E.cell[ny * c.width + nx];
+    const uint32_t v = win_get(w, nk);
     if (v & C_GOLD) {  // ItemBox::entry -> Merge into the pack's gold (itembox.rs:30-40)
         for (int s = 0; s < nrooms; s++) {
             uint32_t g = S.gold_pos[s * E.n + E.e];
             if (g == (POS(nx, ny) | 0x10000u)) { E.gold += S.gold_amt[s * E.n + E.e]; S.gold_pos[s * E.n + E.e] = 0; }
         }
-        E.cell[ny * c.width + nx] = (uint16_t)(v & ~C_GOLD);
+        win_set(w, nk, v & ~C_GOLD);
         react |= R_STATUS;
         return true;
     }
     return false;
 }
 
-// Floor::search (floor.rs:349-370)
-__device__ __forceinline__ void do_search(const RgConfig &c, Env &E, uint32_t &react) {
+// the wave applies the whole-room updates of its lanes to the global grids: leaves_room first (clears), then enters_room (sets),
+// 64 cells per round instead of one lane walking the room
+__device__ __forceinline__ void fill_service(const RgState &S, const RgConfig &c, int lane, int e, const FillReq &fr) {
+#pragma unroll
+    for (int kind = 0; kind < 2; kind++) {
+        const uint32_t mine = kind ? fr.enter : fr.leave;
+        uint64_t m = __ballot(mine != 0);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const uint32_t r = (uint32_t)__shfl((int)mine, src);
+            uint16_t *cell = S.cell + (size_t)__shfl(e, src) * S.hw;
+            int x0, y0, x1, y1;
+            unpack_rect(r, x0, y0, x1, y1);
+            const int rw = x1 - x0, area = rw * (y1 - y0);
+            for (int t = lane; t < area; t += WAVE) {
+                const int yy = small_div(t, rw), xx = t - yy * rw;
+                uint16_t *p = cell + (y0 + yy) * c.width + x0 + xx;
+                *p = kind ? (uint16_t)(*p | C_DRAWN | C_VISIBLE) : (uint16_t)(*p & ~C_VISIBLE);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the owner lane's window write-back (and a following fill) must land after these stores
+        }
+    }
+}
+
+// Floor::search (floor.rs:349-370) on the window (centred on the player)
+__device__ __forceinline__ void do_search(const RgConfig &c, Env &E, Win &w, uint32_t &react) {
+#pragma unroll
     for (int d = 0; d < 8; d++) {
-        int x = E.px + kDX[d], y = E.py + kDY[d];
-        if (!in_bounds(c, x, y)) continue;
-        uint32_t v = E.cell[y * c.width + x];
+        const int k = WIN_K(kDXc[d], kDYc[d]);
+        if (!((w.inb >> k) & 1u)) continue;
+        uint32_t v = w.v[k];
+        const uint32_t v_in = v;
         if ((v & C_HIDDEN) && does_happen(E.rd, c.passage_unlock_rate_inv))
             v = (v & ~(C_LOCKED | C_HIDDEN | C_SURF_MASK)) | C_VISIBLE | S_PASSAGE;
         if ((v & C_LOCKED) && does_happen(E.rd, c.door_unlock_rate_inv)) {
             v = (v & ~(C_LOCKED | C_HIDDEN | C_SURF_MASK)) | C_VISIBLE | S_DOOR;
             react |= MSG_SECRET_DOOR;
         }
-        E.cell[y * c.width + x] = (uint16_t)v;
+        if (v != v_in) { w.v[k] = v; w.dirty |= 1u << k; }
     }
     react |= R_REDRAW;
 }
@@ -1141,11 +1367,17 @@ __device__ __forceinline__ bool monsters_prepass(const RgState &S, const RgConfi
 
 // DistCache::make_dist_map lookup (rogue/mod.rs:504-517): FIFO ring of 9 maps keyed by target coord only
 __device__ __forceinline__ bool dist_cache_lookup(const RgState &S, const Env &E, uint32_t key, int &slot) {
-    int len = S.dc_len[E.e], head = S.dc_head[E.e];
-    for (int i = 0; i < len; i++) {
-        int idx = head + i; if (idx >= RG_DIST_SLOTS) idx -= RG_DIST_SLOTS;
-        if (S.dc_key[idx * E.n + E.e] == key) { slot = idx; return true; }
+    const int len = S.dc_len[E.e], head = S.dc_head[E.e];
+    uint32_t keys[RG_DIST_SLOTS];
+#pragma unroll
+    for (int i = 0; i < RG_DIST_SLOTS; i++) keys[i] = S.dc_key[i * E.n + E.e];  // one round of independent loads instead of a dependent scan
+    int hit = -1;
+#pragma unroll
+    for (int i = RG_DIST_SLOTS - 1; i >= 0; i--) {  // FIFO order from `head`; the first match wins (keys are unique anyway)
+        int age = i - head; if (age < 0) age += RG_DIST_SLOTS;
+        if (age < len && keys[i] == key) hit = i;
     }
+    if (hit >= 0) { slot = hit; return true; }
     if (len < RG_DIST_SLOTS) { slot = head + len; if (slot >= RG_DIST_SLOTS) slot -= RG_DIST_SLOTS; S.dc_len[E.e] = (uint8_t)(len + 1); }
     else { slot = head; S.dc_head[E.e] = (uint8_t)(head + 1 >= RG_DIST_SLOTS ? 0 : head + 1); }
     S.dc_key[slot * E.n + E.e] = (uint16_t)key;
@@ -1166,20 +1398,40 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
         int cx = POS_X(w), cy = POS_Y(w);
         uint32_t fin = w & 0xffff;
         bool reach = false;
-        if ((rand_mask >> slot) & 1) {  // Dungeon::move_enemy_randomly
+        const bool random = (rand_mask >> slot) & 1;
+        // one round of independent loads: the 3x3 tiles around the monster (can_move needs the target and, for diagonals, its two
+        // orthogonal neighbours) and, for a chaser, the 3x3 of the dist map; the decision below then runs on registers only
+        uint32_t walk = 0, dv[9];
+#pragma unroll
+        for (int d = 0; d < 9; d++) {
+            const int nx = cx + kDXc[d], ny = cy + kDYc[d];
+            const bool in = in_bounds(c, nx, ny);
+            const int idx = in ? ny * W + nx : cy * W + cx;
+            const uint32_t cv = E.cell[idx];
+            const uint32_t dd = random ? DIST_INF : (uint32_t)dist[idx];
+            dv[d] = in ? dd : DIST_INF;
+            if (in && can_walk(cv)) walk |= 1u << d;
+        }
+        // Floor::can_move_impl for an enemy (floor.rs:169-182): bit d of `cm`
+        uint32_t cm = walk;
+        if (!((walk >> 2) & (walk >> 0) & 1u)) cm &= ~(1u << 4);  // LeftUp needs Left and Up
+        if (!((walk >> 3) & (walk >> 0) & 1u)) cm &= ~(1u << 5);  // RightUp: Right, Up
+        if (!((walk >> 2) & (walk >> 1) & 1u)) cm &= ~(1u << 6);  // LeftDown: Left, Down
+        if (!((walk >> 3) & (walk >> 1) & 1u)) cm &= ~(1u << 7);  // RightDown: Right, Down
+        if (random) {  // Dungeon::move_enemy_randomly
             int d = (int)((rand_dir >> (slot * 4)) & 7);
-            uint32_t np = POS(cx + kDX[d], cy + kDY[d]);
-            if (!blocked_for(S, E, nrooms, np, slot) && can_move(c, E.cell, cx, cy, d, true)) {
+            uint32_t np = POS(cx + dir_dx(d), cy + dir_dy(d));
+            if (!blocked_for(S, E, nrooms, np, slot) && ((cm >> d) & 1u)) {
                 if (np == ppos) reach = true; else fin = np;
             }
         } else {  // Dungeon::move_enemy: greedy step on the (possibly stale) dist map, 9 directions incl. Stay
             uint32_t best = DIST_INF; bool found = false; uint32_t bp = fin;
+#pragma unroll
             for (int d = 0; d < 9; d++) {
-                int nx = cx + kDX[d], ny = cy + kDY[d];
-                uint32_t np = POS(nx, ny);
-                if (blocked_for(S, E, nrooms, np, slot)) continue;
-                uint32_t nd = in_bounds(c, nx, ny) ? dist[ny * W + nx] : DIST_INF;
-                if (nd == 0 && can_move(c, E.cell, cx, cy, d, true)) { reach = true; break; }
+                const uint32_t np = POS(cx + kDXc[d], cy + kDYc[d]);
+                if (reach || blocked_for(S, E, nrooms, np, slot)) continue;
+                const uint32_t nd = dv[d];
+                if (nd == 0 && ((cm >> d) & 1u)) { reach = true; continue; }
                 if (nd != DIST_INF && nd > 0 && (!found || nd < best)) { best = nd; bp = np; found = true; }
             }
             if (!reach && found) fin = bp;
@@ -1230,7 +1482,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
     const int lane = threadIdx.x;
     const int e = blockIdx.x * WAVE + lane;
     const bool valid = e < S.n;
-    Prof pf0; pf0.start(S.prof);
+    Prof pf; pf.start(S.prof);
     Env E;
     uint32_t react = 0, err = 0, old_flags = 0, steps = 0, flags = 0;
     int act = ACT_NOOP, dir = 0;
@@ -1254,11 +1506,14 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
     E.mc = reinterpret_cast<uint32_t *>(g_smem + mc_offset) + lane;
     if (live) for (int s = 0; s < nrooms_k; s++) E.mc[s * WAVE] = S.mon_w0[s * S.n + e];
     // Action::DownStair (actions.rs:27-36): the new level is produced by the generation service below
-    pf0.mark(0);
-    Prof pf; pf.start(S.prof);
+    pf.mark(0);
     bool need_gen = false;
+    Win w;  // the 5x5 tiles around the player: one round of loads serves the whole player action
+    if (live) win_load(c, E.cell, w, E.px, E.py);
+    else { w.inb = 0; w.dirty = 0; w.ox = w.oy = 0; }
+    pf.mark(26);
     if (live && act == ACT_DOWNSTAIR) {
-        if ((E.cell[E.py * c.width + E.px] & C_SURF_MASK) == S_STAIR) {
+        if ((w.v[WIN_K(0, 0)] & C_SURF_MASK) == S_STAIR) {
             need_gen = true;
             react |= R_REDRAW | R_STATUS | R_HIST_STALE;  // Redraw precedes StatusUpdated: history keeps the old level
         } else react |= MSG_NO_DOWNSTAIR;
@@ -1314,6 +1569,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
         while (__any(running)) {
             bool do_turn = false, need_bfs = false;
             uint32_t rand_mask = 0; uint64_t rand_dir = 0; int map_slot = -1;
+            FillReq fr; fr.leave = fr.enter = 0;
             if (running) {
                 switch (act) {  // actions::process_action (actions.rs:16-65)
                 case ACT_DOWNSTAIR:
@@ -1321,37 +1577,45 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
                     break;
                 case ACT_MOVE:
                 case ACT_MOVE_UNTIL: {
-                    bool done = move_player(S, c, E, dir, react);
+                    bool done = move_player(S, c, E, w, dir, react, fr);
                     if (act == ACT_MOVE) { do_turn = true; running = false; break; }
-                    uint32_t v = E.cell[E.py * c.width + E.px];
+                    uint32_t v = win_get(w, WIN_K(E.px - w.ox, E.py - w.oy));
                     uint32_t tile = (v & C_VISIBLE) ? glyph_of(v) : ' ';
                     if (done || (tile != '.' && tile != '#')) running = false;  // MoveUntil stops without after_turn
                     else do_turn = true;
                     break;
                 }
                 case ACT_SEARCH:
-                    do_search(c, E, react);
+                    do_search(c, E, w, react);
                     do_turn = true; running = false;
                     break;
                 }
-                if (do_turn) {  // actions::after_turn (actions.rs:67-80)
-                    turn_passed(c, E, react);
-                    if (E.mon_active > 0 && monsters_prepass(S, c, E, rand_mask, rand_dir))
-                        need_bfs = !dist_cache_lookup(S, E, POS(E.px, E.py), map_slot);
-                }
             }
+            pf.mark(28);
+            if (do_turn) turn_passed(c, E, react);  // actions::after_turn (actions.rs:67-80)
+            pf.mark(29);
+            bool need_map = false;
+            if (do_turn && E.mon_active > 0) need_map = monsters_prepass(S, c, E, rand_mask, rand_dir);
+            pf.mark(30);
+            if (need_map) need_bfs = !dist_cache_lookup(S, E, POS(E.px, E.py), map_slot);
             pf.mark(3);
+            // whole-room reveals / hides by the wave, then the lanes' changed window cells (the final word on those cells); both before any
+            // monster or BFS read of the grid
+            fill_service(S, c, lane, e, fr);
+            win_flush(c, E.cell, w);
+            pf.mark(27);
             uint64_t m = __ballot(need_bfs);
             if (m) {  // serve the requesting lanes with the whole wave, several maps per round
                 unsigned long long tb0 = pf.p ? __builtin_amdgcn_s_memtime() : 0;
                 bfs_service(S, c, lds_grid, m, e, E.px, E.py, map_slot, lane);
-                if (pf.p && lane == 0) { unsigned long long dt = __builtin_amdgcn_s_memtime() - tb0; atomicMax(&pf.p[24], dt); atomicAdd(&pf.p[32 + 24], dt); atomicAdd(&pf.p[32 + 25], (unsigned long long)__popcll(m)); }
+                if (pf.p) { pf.rec(24, __builtin_amdgcn_s_memtime() - tb0); pf.rec(25, (unsigned long long)__popcll(m)); }
             }
             pf.mark(4);
             if (do_turn && E.mon_active > 0) ui_dead = monsters_move(S, c, E, rand_mask, rand_dir, map_slot, react);  // `ui` of the LAST after_turn wins
             else if (do_turn) ui_dead = false;
             pf.mark(5);
             if (++iter > RG_MAX_W + RG_MAX_H) running = false;
+            if (running) win_load(c, E.cell, w, E.px, E.py);  // a MoveUntil run continues from the new cell
         }
         if (live) {
             // GameStateImpl::react's reaction loop (state_impls.rs:56-78)
@@ -1366,11 +1630,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
         }
     }
     pf.mark(6);
-    if (pf0.p && lane == 0) {  // histogram of whole-wave durations: 16 buckets of 38400 ticks (16 us @ 2.4 GHz) in prof[64..79]
-        unsigned long long tot = __builtin_amdgcn_s_memtime() - pf0.t0;
-        int b = (int)(tot / 38400ull); if (b > 15) b = 15;
-        atomicAdd(&pf0.p[64 + b], 1ull);
-    }
+    pf.finish();
     if (!valid) return;
     if (err) {
         S.flags[e] = (old_flags & ~RG_FLAG_ERR_MASK) | err;
@@ -1400,7 +1660,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 static int gen_slots(int hw, int budget_bytes) {
-    int n = budget_bytes / (hw * 2);
+    int n = budget_bytes / (int)GEN_SLOT_BYTES(hw);
     return n < 1 ? 1 : (n > WAVE ? WAVE : n);
 }
 static size_t bfs_bytes(const RgConfig *c) {
@@ -1410,13 +1670,14 @@ static size_t bfs_bytes(const RgConfig *c) {
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
     int ns = gen_slots(hw, 64 * 1024);
-    size_t smem = (size_t)ns * hw * 2;
+    size_t smem = (size_t)ns * GEN_SLOT_BYTES(hw);
     hipLaunchKernelGGL(k_build, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *c, ns);
 }
 void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, int use_spares, hipStream_t st) {
     int hw = c->width * c->height;
-    int ns = gen_slots(hw, 8 * 1024);  // inline generation is rare (descents, spare misses): a small LDS footprint keeps k_regen co-resident
-    size_t smem = (size_t)ns * hw * 2;
+    static const int step_kb = getenv("RG_GEN_LDS_KB") ? atoi(getenv("RG_GEN_LDS_KB")) : 8;
+    int ns = gen_slots(hw, step_kb * 1024);  // inline generation is rare (descents, spare misses): a small LDS footprint keeps k_regen co-resident
+    size_t smem = (size_t)ns * GEN_SLOT_BYTES(hw);
     if (bfs_bytes(c) > smem) smem = bfs_bytes(c);
     smem = (smem + 15) & ~(size_t)15;
     int mc_offset = (int)smem;
@@ -1425,8 +1686,9 @@ void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint
 }
 void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
-    int ns = gen_slots(hw, 8 * 1024);  // ~0.4 refills per wave and step; fewer than 4 slots costs spare misses, more buys nothing
-    size_t smem = (size_t)ns * hw * 2;
+    static const int regen_kb = getenv("RG_REGEN_LDS_KB") ? atoi(getenv("RG_REGEN_LDS_KB")) : 8;
+    int ns = gen_slots(hw, regen_kb * 1024);  // ~0.4 refills per wave and step; fewer than 4 slots costs spare misses, more buys nothing
+    size_t smem = (size_t)ns * GEN_SLOT_BYTES(hw);
     hipLaunchKernelGGL(k_regen, dim3((SP->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *SP, *c, ns);
 }
 }

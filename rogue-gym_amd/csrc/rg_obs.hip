@@ -194,7 +194,8 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
     extern __shared__ __align__(16) uint8_t smem[];
     float *lutf = reinterpret_cast<float *>(smem);        // glyph -> gray value (KIND 0)
     uint8_t *luts = smem + 512;                            // glyph -> symbol id
-    uint8_t *envs = smem + 512 + 128;                      // epb x {HW staged screen bytes, ObsTabs}
+    uint8_t *mtile = smem + 512 + 128;                     // monster type -> glyph (RgConfig::mon[].tile: indexed per lane, so not from the kernarg segment)
+    uint8_t *envs = smem + 512 + 128 + 64;                 // epb x {HW staged screen bytes, ObsTabs}
     const int tid = threadIdx.x, W = c.width, H = c.height, HW = W * H, n = S.n, Q8 = HW >> 3;
     const int nrooms = c.room_num_x * c.room_num_y;
     const int symbols = c.symbols;
@@ -203,6 +204,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
         luts[g] = (uint8_t)sy;
         lutf[g] = (float)(uint8_t)sy / (float)(uint8_t)symbols;  // python/src/lib.rs:84 (same single division)
     }
+    for (int g = tid; g < RG_MAX_ENEMY_KINDS + 6; g += blockDim.x) mtile[g] = c.mon[g].tile;
     const int le = tid / tpe, lt = tid - le * tpe;
     const int base_planes = KIND ? symbols : 1;
     const int nplanes = base_planes + __popc(sflag) + (with_hist ? 1 : 0);
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                         }
                     }
                 }
-                if (show && (scr[y * W + x] & 0x80u)) scr[y * W + x] = (uint8_t)(0x80u | c.mon[(w >> 16) & 0xff].tile);
+                if (show && (scr[y * W + x] & 0x80u)) scr[y * W + x] = (uint8_t)(0x80u | mtile[(w >> 16) & 0xff]);
             }
         }
         lds_barrier();
@@ -390,7 +392,7 @@ int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, 
     int tpe = q8 >= OBS_THREADS ? OBS_THREADS : ((q8 + 63) / 64) * 64;  // threads per env: a whole number of waves
     if (tpe > OBS_THREADS) tpe = OBS_THREADS;
     const int bthreads = tpe, epb = 1;  // one env per block: no cross-env barrier coupling (4 envs per 256-thread block measured 10-20 % slower)
-    size_t smem = 512 + 128 + (size_t)epb * OBS_ENV_BYTES(hw);
+    size_t smem = 512 + 128 + 64 + (size_t)epb * OBS_ENV_BYTES(hw);
     int blocks = (S->n + epb - 1) / epb;
     // persistent grid: launching one tiny workgroup per env is dispatch-rate bound (65 536 one-wave blocks: 71 us; 16 384 looping blocks: 51 us)
     { const char *ev = getenv("RG_OBS_BLOCKS"); int cap = ev ? atoi(ev) : (bthreads <= 64 ? 16384 : 8192); if (blocks > cap) blocks = cap; }

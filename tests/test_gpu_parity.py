@@ -162,6 +162,20 @@ def test_inline_generation_path_without_spares(goldens, monkeypatch):
     lockstep(goldens["configs"]["mini"], list(range(256)), rand_keys(rng, ALL_KEYS, 256, 200), max_steps=60, check_every=1, internal_every=40)
 
 
+@pytest.mark.parametrize("period", [1, 9])
+def test_descents_many_and_few_lanes_per_wave(goldens, period):
+    """The DDQN key log (data/learned/ddqn-minidungeon) takes seed 5 down a level.  Every `period`-th env plays seed 5, the others play
+    other seeds with the same keys: period 1 = every lane of a wave descends on the same step (generation rounds over the LDS slots),
+    period 9 = a handful per wave."""
+    cfg = goldens["configs"]["ddqn"]
+    n = 192
+    seeds = [5 if i % period == 0 else 1000 + i for i in range(n)]
+    keys = [np.full(n, ord(ch), np.uint8) for ch in goldens["ddqn_keys"][:400]]
+    hip, oracles = lockstep(cfg, seeds, keys, max_steps=1000, check_every=4, internal_every=50)
+    levels = [int(o.status_arr()[0]) for o in oracles]
+    assert max(levels) >= 2, "the log must descend at least once within 400 keys"
+
+
 def test_spares_survive_reseeding(goldens):
     """rg_seed invalidates the pre-generated spares: after seed() + reset() and further auto-resets the envs follow the new seeds."""
     cfg = goldens["configs"]["mini"]

@@ -50,11 +50,23 @@ if __name__ == "__main__":
         run("mini 11-act max_steps=1e6", G["configs"]["mini"], A11, max_steps=1000000)
         run("mini no-enemy 11-act", dict(G["configs"]["mini"], enemies={"enemies": []}), A11, resets=3)
         run("mini no-enemy max_steps=1e6", dict(G["configs"]["mini"], enemies={"enemies": []}), A11, max_steps=1000000)
+    if "nodesc" in which:
+        run("mini 11-act", G["configs"]["mini"], A11)
+        run("mini 10-act (no >)", G["configs"]["mini"], b".hjklnbuys")
+        run("mini 10-act (no >) no-enemy", dict(G["configs"]["mini"], enemies={"enemies": []}), b".hjklnbuys")
+        run("mini 10-act (no >) max_steps=1e6", G["configs"]["mini"], b".hjklnbuys", max_steps=1000000)
     if "all" in which or "default" in which:
         run("default 11-act n=32768", G["configs"]["default"], A11, n=32768, resets=2)
 
 
-def prof(name, cfg, keys_table, n=65536, steps=200, max_steps=1000, do_reset=False):
+PHASES = {0: "load", 26: "window load", 1: "pre-gen/post-loop", 2: "gen_service", 28: "player action", 29: "turn_passed", 30: "mon prepass", 3: "dist lookup",
+          27: "fill+flush", 4: "bfs", 5: "monsters", 6: "tail"}
+GEN_PHASES = {8: "g.clear", 9: "g.rooms", 10: "g.paint", 11: "g.passages", 12: "g.corridors", 13: "g.gold", 14: "g.stair", 15: "g.monsters", 16: "g.place+rest"}
+TICK_US = 1.0 / 2350.0  # s_memtime ticks at the shader clock (~2.35 GHz under this load; calibrated against the HIP-event kernel duration)
+
+
+def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=False):
+    """Per-wave phase trace of k_step (or k_build with do_reset): rows of (phase, ticks) records, aggregated here."""
     cfgs = [json.dumps(dict(cfg, seed=i)) for i in range(n)]
     h = inner._Handle(cfgs, max_steps, True)
     L = h.L
@@ -63,37 +75,64 @@ def prof(name, cfg, keys_table, n=65536, steps=200, max_steps=1000, do_reset=Fal
     table = torch.tensor(list(keys_table), dtype=torch.uint8, device=dev)
     gen = torch.Generator(device=dev).manual_seed(0)
     keys = table[torch.randint(0, len(keys_table), (64, n), generator=gen, device=dev)].contiguous()
-    for t in range(100):
+    for t in range(150):
         L.rg_step(h.h, C.c_void_p(keys[t % 64].data_ptr()), 1)
-    L.rg_prof(h.h, 1, None)
-    if do_reset:
-        L.rg_reset(h.h); steps = 1
-    else:
-        for t in range(steps):
-            L.rg_step(h.h, C.c_void_p(keys[t % 64].data_ptr()), 1)
-    out = (C.c_ulonglong * 128)()
-    L.rg_prof(h.h, 0, out)
     nw = (n + 63) // 64
-    names = {0: "load", 1: "pre-gen", 2: "gen_service", 3: "player+prepass", 4: "bfs", 5: "monsters", 6: "tail", 8: "g.clear", 9: "g.rooms", 10: "g.paint",
-             11: "g.passages", 12: "g.corridors", 13: "g.gold", 14: "g.stair", 15: "g.monsters", 16: "g.place+rest", 17: "g.copyout"}
-    print(name)
-    for i in sorted(names):
-        if out[32 + i]:
-            print("   %-16s max %8.1f us (over all launches)   avg/wave/launch %8.2f us" % (names[i], out[i] / 100.0, out[32 + i] / 100.0 / nw / steps))
-    ngen = out[32 + 21] + out[32 + 23]
-    if ngen:
-        print("   per-generation averages (us, ticks/2400): " + "  ".join("%s %.1f" % (names[i][2:], out[32 + i] / ngen / 2400.0) for i in range(8, 16))
-              + "  | place+copy %.1f" % ((out[32 + 20] + out[32 + 22]) / ngen / 2400.0 - sum(out[32 + i] for i in range(9, 16)) / ngen / 2400.0))
+    buf = np.zeros((nw, 64), np.uint64)
+    L.rg_prof(h.h, 1, None)
+    sums, maxs, totals, counts = {}, {}, [], {}
+    L.rg_timing_enable(h.h, 1)
+    for t in range(1 if do_reset else launches):
+        if do_reset:
+            L.rg_reset(h.h)
+        else:
+            L.rg_step(h.h, C.c_void_p(keys[t % 64].data_ptr()), 1)
+        L.rg_prof(h.h, 1, buf.ctypes.data_as(C.c_void_p))
+        k = buf[:, 0].astype(np.int64)
+        totals.append(buf[:, 63].astype(np.float64))
+        rec = buf[:, 1:62]
+        valid = np.arange(61)[None, :] < k[:, None]
+        ph = (rec >> np.uint64(48)).astype(np.int64)
+        val = (rec & np.uint64((1 << 48) - 1)).astype(np.float64)
+        for pid in np.unique(ph[valid]):
+            sel = valid & (ph == pid)
+            per_wave = (val * sel).sum(axis=1)
+            sums[pid] = sums.get(pid, 0.0) + per_wave.sum()
+            maxs[pid] = max(maxs.get(pid, 0.0), per_wave.max())
+            counts[pid] = counts.get(pid, 0) + int(sel.sum())
+    ms = (C.c_double * 4)()
+    cnt = (C.c_uint64 * 4)()
+    L.rg_timing_read(h.h, ms, cnt)
+    nl = len(totals)
+    tot = np.stack(totals)
+    kidx = 3 if do_reset else 0
+    print("%s: kernel (HIP events) %.1f us; slowest wave avg %.1f us, mean wave %.1f us" %
+          (name, ms[kidx] / max(cnt[kidx], 1) * 1e3, tot.max(axis=1).mean() * TICK_US, tot.mean() * TICK_US))
+    names = GEN_PHASES if do_reset else PHASES
+    for pid, nm in names.items():
+        if pid in sums:
+            print("   %-18s avg/wave %7.2f us   max wave %7.2f us" % (nm, sums[pid] / nw / nl * TICK_US, maxs[pid] * TICK_US))
     if not do_reset:
-        print("   wave-duration histogram (16 us buckets, waves per launch): " + " ".join("%.0f" % (out[64 + b] / steps) for b in range(16)))
-    for nm, k in (("gen (1 lane)", 20), ("gen (>1 lanes)", 22), ("bfs", 24)):
-        if out[32 + k + 1]:
-            print("   %-16s count/launch %.1f  avg %.1f ticks  max %.1f ticks" % (nm, out[32 + k + 1] / steps, out[32 + k] / out[32 + k + 1], out[k]))
+        hist = np.histogram(tot * TICK_US, bins=np.arange(0, 260, 10))[0] / nl
+        print("   wave-duration histogram (10 us buckets, waves per launch): " + " ".join("%.0f" % v for v in hist))
+        # which phase makes the slowest waves slow: phase sums over the slowest 1 % of waves of the last launch
+        for nm, pid in (("gen (1 lane)", 20), ("gen (>1 lanes)", 22), ("bfs service", 24)):
+            if pid in sums:
+                print("   %-16s calls/launch %.1f  avg %.1f us" % (nm, counts[pid] / nl, sums[pid] / counts[pid] * TICK_US))
+        if 25 in sums:
+            print("   dist maps/launch %.1f" % (sums[25] / nl))
+        order = np.argsort(-buf[:, 63].astype(np.float64))[:3]
+        for wv in order:  # the slowest waves of the last launch, record by record
+            kk = int(buf[wv, 0])
+            recs = ["%s=%.1f" % (PHASES.get(int(r >> np.uint64(48)), str(int(r >> np.uint64(48)))), float(r & np.uint64((1 << 48) - 1)) * TICK_US) for r in buf[wv, 1:1 + kk]]
+            print("   slow wave %d: total %.1f us: %s" % (wv, float(buf[wv, 63]) * TICK_US, " ".join(recs)))
     h.close()
 
 
 if __name__ == "__main__" and "prof" in sys.argv[1:]:
     prof("k_step mini 11-act", G["configs"]["mini"], b".hjklnbuy>s")
+    prof("k_step mini 10-act (no >)", G["configs"]["mini"], b".hjklnbuys")
+    prof("k_step mini 10-act (no >) no-enemy", dict(G["configs"]["mini"], enemies={"enemies": []}), b".hjklnbuys")
     prof("k_build mini", G["configs"]["mini"], b".", do_reset=True)
 
 
