@@ -19,6 +19,12 @@
 // ---------------------------------------------------------------------------------------------
 struct Rng { uint32_t x, y, z, w; };
 
+// Wave-uniform values.  Level generation runs with the whole wave working on ONE env (gen_service): every lane holds the same scalars, so the
+// compiler keeps the RNG, the loop counters and the decisions on the scalar unit.  A value that comes back from memory is uniform in fact but
+// not provably so; uni() tells the compiler.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+
 __device__ __forceinline__ void rng_seed(Rng &r, uint64_t lo, uint64_t hi) {
     r.x = (uint32_t)lo; r.y = (uint32_t)(lo >> 32); r.z = (uint32_t)hi; r.w = (uint32_t)(hi >> 32);
     if ((r.x | r.y | r.z | r.w) == 0) r.x = r.y = r.z = r.w = 0x0BAD5EEDu;
@@ -118,28 +124,13 @@ struct Env {
     uint32_t *mc;       // k_step: this lane's column of the wave's LDS monster cache (word s at mc[s * WAVE]); write-through
 };
 
-// Floor::can_move_impl (floor.rs:169-182)
-__device__ __forceinline__ bool can_move(const RgConfig &c, const uint16_t *cell, int x, int y, int d, bool is_enemy) {
-    int dx = dir_dx(d), dy = dir_dy(d);
-    int nx = x + dx, ny = y + dy;
-    if (!in_bounds(c, nx, ny)) return false;
-    uint32_t nc = cell[ny * c.width + nx];
-    bool res = can_walk(nc);
-    if (!is_enemy) res = res && !(nc & (C_HIDDEN | C_LOCKED));
-    if (dx != 0 && dy != 0) {
-        res = res && can_walk(cell[y * c.width + nx]);
-        res = res && can_walk(cell[ny * c.width + x]);
-    }
-    return res;
-}
-
 // ---------------------------------------------------------------------------------------------
 // monsters table helpers
 // ---------------------------------------------------------------------------------------------
 // Monster word 0 accessors.  MC = true (the turn code of k_step): read from the wave's LDS cache, loaded once per launch --
 // the monster phases re-read the table dozens of times (ordering, blocking tests for 9 directions, overwrite checks), and
 // against global memory every pass is another round of VMEM instructions and waits.  Stores go to both.
-template <bool MC> __device__ __forceinline__ uint32_t mon_rd(const RgState &S, const Env &E, int s) { return MC ? E.mc[s * WAVE] : S.mon_w0[s * E.n + E.e]; }
+template <bool MC> __device__ __forceinline__ uint32_t mon_rd(const RgState &S, const Env &E, int s) { return MC ? E.mc[s * WAVE] : uni(S.mon_w0[s * E.n + E.e]); }  // MC = false: generation (wave-uniform)
 template <bool MC> __device__ __forceinline__ void mon_wr(const RgState &S, const Env &E, int s, uint32_t w) {
     S.mon_w0[s * E.n + E.e] = w;
     if (MC) E.mc[s * WAVE] = w;
@@ -185,76 +176,92 @@ __device__ __forceinline__ void activate_room(const RgState &S, const RgConfig &
 }
 
 // ---------------------------------------------------------------------------------------------
-// field-of-view (floor.rs:201-312)
+// field-of-view at level entry (floor.rs:201-312).  The per-step form lives in move_player (register window).
 // ---------------------------------------------------------------------------------------------
-template <bool MC>
-__device__ __forceinline__ void player_in(const RgState &S, const RgConfig &c, Env &E, int x, int y, bool init) {
-    uint16_t *cell = E.cell;
+// Floor::player_in(cd, init = true) on the LDS staging grid, wave-uniform (called from place_player)
+__device__ __forceinline__ void player_in_init(const RgState &S, const RgConfig &c, Env &E, int x, int y) {
+    lds_u16 *cell = E.lc;
     int W = c.width;
-    uint32_t here = cell[y * W + x];
-    if (init || (here & C_DOOR)) {
-        int rid = room_id_of(c, x, y);
-        if (rid >= 0) {
-            uint8_t meta = S.room_meta[rid * E.n + E.e];
-            if (!(meta & RM_VISITED)) {  // Floor::enters_room (floor.rs:231-247)
-                S.room_meta[rid * E.n + E.e] = meta | RM_VISITED;
-                if ((meta & RM_KIND_MASK) == RK_NORMAL && !(meta & RM_DARK)) {
-                    int x0, y0, x1, y1;
-                    unpack_rect(S.room_rect[rid * E.n + E.e], x0, y0, x1, y1);
-                    for (int yy = y0; yy < y1; yy++)
-                        for (int xx = x0; xx < x1; xx++) cell[yy * W + xx] |= C_DRAWN | C_VISIBLE;
+    int rid = room_id_of(c, x, y);
+    if (rid >= 0) {
+        uint32_t meta = uni(S.room_meta[rid * E.n + E.e]);
+        if (!(meta & RM_VISITED)) {  // Floor::enters_room (floor.rs:231-247)
+            S.room_meta[rid * E.n + E.e] = (uint8_t)(meta | RM_VISITED);
+            if ((meta & RM_KIND_MASK) == RK_NORMAL && !(meta & RM_DARK)) {
+                int x0, y0, x1, y1;
+                unpack_rect(uni(S.room_rect[rid * E.n + E.e]), x0, y0, x1, y1);
+                const int rw = x1 - x0, area = rw * (y1 - y0);
+                for (int t = threadIdx.x; t < area; t += WAVE) {  // one cell per lane
+                    const int yy = small_div(t, rw), xx = t - yy * rw;
+                    cell[(y0 + yy) * W + x0 + xx] |= C_DRAWN | C_VISIBLE;
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
             }
-            activate_room<MC>(S, c, E, rid);
         }
+        activate_room<false>(S, c, E, rid);
     }
     cell[y * W + x] |= C_VISITED;
     for (int d = 0; d < 9; d++) {
         int cx = x + dir_dx(d), cy = y + dir_dy(d);
         if (!in_bounds(c, cx, cy)) continue;
-        uint32_t v = cell[cy * W + cx];
+        uint32_t v = uni(cell[cy * W + cx]);
         bool diag = d >= 4 && d < 8;
         if (diag && (v & C_SURF_MASK) == S_PASSAGE) continue;
         if (v & C_HIDDEN) continue;  // Cell::approached (field.rs:20-26)
-        cell[cy * W + cx] = v | C_DRAWN | C_VISIBLE;
-    }
-}
-__device__ __forceinline__ void player_out(const RgState &S, const RgConfig &c, Env &E, int x, int y) {
-    uint16_t *cell = E.cell;
-    int W = c.width;
-    if (cell[y * W + x] & C_DOOR) {  // Floor::leaves_room (floor.rs:249-261)
-        int rid = room_id_of(c, x, y);
-        if (rid >= 0) {
-            uint8_t meta = S.room_meta[rid * E.n + E.e];
-            if ((meta & RM_VISITED) && (meta & RM_DARK)) {
-                int x0, y0, x1, y1;
-                if ((meta & RM_KIND_MASK) == RK_EMPTY) assigned_area(c, rid, x0, y0, x1, y1);
-                else unpack_rect(S.room_rect[rid * E.n + E.e], x0, y0, x1, y1);
-                for (int yy = y0 + 1; yy < y1 - 1; yy++)
-                    for (int xx = x0 + 1; xx < x1 - 1; xx++) cell[yy * W + xx] &= ~C_VISIBLE;
-            }
-        }
-    }
-    for (int d = 0; d < 9; d++) {
-        int cx = x + dir_dx(d), cy = y + dir_dy(d);
-        if (!in_bounds(c, cx, cy)) continue;
-        uint32_t v = cell[cy * W + cx];
-        if ((v & C_SURF_MASK) == S_FLOOR && (v & C_DARK)) cell[cy * W + cx] = v & ~C_VISIBLE;  // Cell::left
+        cell[cy * W + cx] = (uint16_t)(v | C_DRAWN | C_VISIBLE);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // generator (rogue/rooms.rs, maze.rs, passages.rs, floor.rs, rogue/mod.rs:434-481)
 // ---------------------------------------------------------------------------------------------
+// Lane-parallel tile tests for the wave-uniform generator: the cells of a rectangle in row-major order, 64 per round.
+// Bit t of the result: cell base + t has one of `bits` set and is not `excl`.
+__device__ __forceinline__ uint64_t rect_ballot(const RgConfig &c, const Env &E, int x0, int y0, int rw, int area, int base, uint32_t bits, uint32_t excl) {
+    const int t = base + (int)threadIdx.x;
+    bool in = false;
+    if (t < area) {
+        const int yy = small_div(t, rw), xx = t - yy * rw;
+        in = (E.lc[(y0 + yy) * c.width + x0 + xx] & bits) && POS(x0 + xx, y0 + yy) != excl;
+    }
+    return __ballot(in);
+}
+// position of the nth (0-based) set bit of a ballot mask (nth < popcount)
+__device__ __forceinline__ int nth_set64(uint64_t m, int nth) {
+    const int lane = threadIdx.x;
+    const bool mine = ((m >> lane) & 1ull) && __popcll(m & ((1ull << lane) - 1ull)) == nth;
+    return __ffsll((long long)__ballot(mine)) - 1;
+}
+// nth cell (row-major) of the rectangle with one of `bits` set, skipping `excl`; count must have come from the same test
+__device__ __forceinline__ uint32_t rect_nth(const RgConfig &c, const Env &E, int x0, int y0, int rw, int area, uint32_t bits, uint32_t excl, int nth) {
+    for (int base = 0; base < area; base += WAVE) {
+        const uint64_t m = rect_ballot(c, E, x0, y0, rw, area, base, bits, excl);
+        const int cnt = __popcll(m);
+        if (nth < cnt) {
+            const int t = base + nth_set64(m, nth);
+            const int yy = small_div(t, rw);
+            return POS(x0 + t - yy * rw, y0 + yy);
+        }
+        nth -= cnt;
+    }
+    return POS(x0, y0);
+}
+__device__ __forceinline__ int rect_count(const RgConfig &c, const Env &E, int x0, int y0, int rw, int area, uint32_t bits, uint32_t excl) {
+    int count = 0;
+    for (int base = 0; base < area; base += WAVE) count += __popcll(rect_ballot(c, E, x0, y0, rw, area, base, bits, excl));
+    return count;
+}
+
 // free-cell selection.  The reference keeps a FenwickSet per room; only `nth` over "members minus a
 // handful of filled cells" is ever observed during level creation, so the set is
 // implicit: interior cells (Normal) or C_MAZE cells (Maze) in row-major order, minus `excl`.
 __device__ __forceinline__ bool room_select(const RgState &S, const RgConfig &c, Env &E, int rid, uint32_t excl /* pos or ~0u */, uint32_t &out) {
-    uint8_t meta = S.room_meta[rid * E.n + E.e];
+    uint32_t meta = uni(S.room_meta[rid * E.n + E.e]);
     int kind = meta & RM_KIND_MASK;
     if (kind == RK_EMPTY) return false;
     int x0, y0, x1, y1;
-    unpack_rect(S.room_rect[rid * E.n + E.e], x0, y0, x1, y1);
+    unpack_rect(uni(S.room_rect[rid * E.n + E.e]), x0, y0, x1, y1);
     if (kind == RK_NORMAL) {
         int iw = x1 - x0 - 2, ih = y1 - y0 - 2;
         int count = iw * ih;
@@ -267,19 +274,12 @@ __device__ __forceinline__ bool room_select(const RgState &S, const RgConfig &c,
         out = POS(x0 + 1 + (nth - qy * iw), y0 + 1 + qy);
         return true;
     }
-    int count = 0;
-    for (int yy = y0; yy < y1; yy++)
-        for (int xx = x0; xx < x1; xx++)
-            if ((E.lc[yy * c.width + xx] & C_MAZE) && POS(xx, yy) != excl) count++;
+    const int rw = x1 - x0, area = rw * (y1 - y0);  // Maze: the dug cells of the room, counted and picked 64 cells per round
+    const int count = rect_count(c, E, x0, y0, rw, area, C_MAZE, excl);
     if (count == 0) return false;
-    int nth = (int)range64(E.rd, 0, (uint64_t)count);
-    for (int yy = y0; yy < y1; yy++)
-        for (int xx = x0; xx < x1; xx++)
-            if ((E.lc[yy * c.width + xx] & C_MAZE) && POS(xx, yy) != excl) {
-                if (nth == 0) { out = POS(xx, yy); return true; }
-                nth--;
-            }
-    return false;
+    const int nth = (int)range64(E.rd, 0, (uint64_t)count);
+    out = rect_nth(c, E, x0, y0, rw, area, C_MAZE, excl, nth);
+    return true;
 }
 // nth set bit of a small mask
 __device__ __forceinline__ int nth_bit(uint32_t m, int nth) {
@@ -292,8 +292,8 @@ __device__ __forceinline__ bool floor_select(const RgState &S, const RgConfig &c
     while (cand) {
         int idx = nth_bit(cand, (int)range64(E.rd, 0, (uint64_t)__popc(cand)));
         uint32_t excl = ~0u;
-        if (mode == 0) { uint32_t g = S.gold_pos[idx * E.n + E.e]; if (g & 0x10000u) excl = g & 0xffff; }
-        else { uint32_t w = S.mon_w0[idx * E.n + E.e]; if ((w >> 24) & MF_ALIVE) excl = w & 0xffff; }
+        if (mode == 0) { uint32_t g = uni(S.gold_pos[idx * E.n + E.e]); if (g & 0x10000u) excl = g & 0xffff; }
+        else { uint32_t w = uni(S.mon_w0[idx * E.n + E.e]); if ((w >> 24) & MF_ALIVE) excl = w & 0xffff; }
         if (room_select(S, c, E, idx, excl, out)) return true;
         cand &= ~(1u << idx);
     }
@@ -311,7 +311,7 @@ __device__ __forceinline__ uint32_t gen_attr_corridor(const RgConfig &c, Env &E,
 // one registered corridor cell (floor.rs:87-101)
 __device__ __forceinline__ void register_cell(const RgConfig &c, Env &E, int x, int y, int kind, uint32_t level) {
     uint32_t a = gen_attr_corridor(c, E, kind, level);
-    uint32_t v = E.lc[y * c.width + x];
+    uint32_t v = uni(E.lc[y * c.width + x]);
     v = (v & ~C_ATTR_MASK) | a;
     if (kind == S_DOOR) v |= C_DOOR;
     if (!a) v = (v & ~C_SURF_MASK) | (uint32_t)kind;
@@ -320,10 +320,10 @@ __device__ __forceinline__ void register_cell(const RgConfig &c, Env &E, int x, 
 
 // select_start_or_end (passages.rs:143-179).  dir: 0 Up 1 Down 2 Left 3 Right
 __device__ __forceinline__ uint32_t select_door(const RgState &S, const RgConfig &c, Env &E, int rid, int dir) {
-    uint8_t meta = S.room_meta[rid * E.n + E.e];
+    uint32_t meta = uni(S.room_meta[rid * E.n + E.e]);
     int kind = meta & RM_KIND_MASK;
     int x0, y0, x1, y1;
-    unpack_rect(S.room_rect[rid * E.n + E.e], x0, y0, x1, y1);
+    unpack_rect(uni(S.room_rect[rid * E.n + E.e]), x0, y0, x1, y1);
     if (kind == RK_EMPTY) return POS(x0, y0);
     if (kind == RK_NORMAL) {  // edges(range, dir, inclusive): the wall without its corners; SliceRandom::choose = 64-bit draw
         if (dir < 2) {
@@ -336,25 +336,22 @@ __device__ __forceinline__ uint32_t select_door(const RgState &S, const RgConfig
     // Maze: shrink the probe rectangle from the facing side until its edge holds maze cells
     int rx0 = x0, ry0 = y0, rx1 = x1, ry1 = y1;
     for (int guard = 0; guard < 256 && rx0 < rx1 && ry0 < ry1; guard++) {
-        int cnt = 0;
+        // the facing edge of the probe rectangle, clipped to the room: a 1-cell-thick rectangle scanned by the lanes
+        int lx0, ly0, lrw, larea;
         if (dir < 2) {
-            int yy = dir == 1 ? ry1 - 1 : ry0;
-            for (int xx = rx0; xx < rx1; xx++)
-                if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.lc[yy * c.width + xx] & C_MAZE)) cnt++;
-            if (cnt) {
-                int k = (int)range64(E.rd, 0, (uint64_t)cnt);
-                for (int xx = rx0; xx < rx1; xx++)
-                    if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.lc[yy * c.width + xx] & C_MAZE)) { if (k == 0) return POS(xx, yy); k--; }
-            }
+            const int yy = dir == 1 ? ry1 - 1 : ry0;
+            lx0 = rx0 > x0 ? rx0 : x0; ly0 = yy;
+            const int lx1 = rx1 < x1 ? rx1 : x1;
+            lrw = lx1 - lx0; larea = (yy >= y0 && yy < y1 && lrw > 0) ? lrw : 0;
         } else {
-            int xx = dir == 2 ? rx0 : rx1 - 1;
-            for (int yy = ry0; yy < ry1; yy++)
-                if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.lc[yy * c.width + xx] & C_MAZE)) cnt++;
-            if (cnt) {
-                int k = (int)range64(E.rd, 0, (uint64_t)cnt);
-                for (int yy = ry0; yy < ry1; yy++)
-                    if (xx >= x0 && xx < x1 && yy >= y0 && yy < y1 && (E.lc[yy * c.width + xx] & C_MAZE)) { if (k == 0) return POS(xx, yy); k--; }
-            }
+            const int xx = dir == 2 ? rx0 : rx1 - 1;
+            lx0 = xx; ly0 = ry0 > y0 ? ry0 : y0;
+            const int ly1 = ry1 < y1 ? ry1 : y1;
+            lrw = 1; larea = (xx >= x0 && xx < x1 && ly1 > ly0) ? ly1 - ly0 : 0;
+        }
+        if (larea > 0) {
+            const int cnt = rect_count(c, E, lx0, ly0, lrw, larea, C_MAZE, ~0u);
+            if (cnt) return rect_nth(c, E, lx0, ly0, lrw, larea, C_MAZE, ~0u, (int)range64(E.rd, 0, (uint64_t)cnt));
         }
         if (dir == 1) ry1--; else if (dir == 2) rx0--; else if (dir == 3) rx1--; else ry0--;
     }
@@ -367,8 +364,8 @@ __device__ __forceinline__ void connect_rooms(const RgState &S, const RgConfig &
     if (dir == 0 || dir == 2) { int t = r1; r1 = r2; r2 = t; dir ^= 1; }
     uint32_t s = select_door(S, c, E, r1, dir);
     uint32_t t = select_door(S, c, E, r2, dir ^ 1);
-    int k1 = (S.room_meta[r1 * E.n + E.e] & RM_KIND_MASK) == RK_NORMAL;
-    int k2 = (S.room_meta[r2 * E.n + E.e] & RM_KIND_MASK) == RK_NORMAL;
+    int k1 = (uni(S.room_meta[r1 * E.n + E.e]) & RM_KIND_MASK) == RK_NORMAL;
+    int k2 = (uni(S.room_meta[r2 * E.n + E.e]) & RM_KIND_MASK) == RK_NORMAL;
     int bend;
     if (dir == 1) bend = (int)range32(E.rd, (uint32_t)(POS_Y(s) + 1), (uint32_t)POS_Y(t));
     else bend = (int)range32(E.rd, (uint32_t)(POS_X(s) + 1), (uint32_t)POS_X(t));
@@ -443,13 +440,19 @@ __device__ __forceinline__ void dig_maze(const RgState &S, const RgConfig &c, En
     if (in_lds) ls[sp] = (uint16_t)POS(x0, y0); else gs[sp] = (uint16_t)POS(x0, y0);
     sp++;
     while (sp > 0) {
-        const uint32_t top = in_lds ? ls[sp - 1] : gs[sp - 1];
+        const uint32_t top = uni(in_lds ? ls[sp - 1] : gs[sp - 1]);
         int cx = POS_X(top), cy = POS_Y(top);
+        // the four candidate cells tested by lanes 0..3 at once
+        uint32_t cand;
+        {
+            const int d = (int)threadIdx.x & 3;
+            const int nx = cx + 2 * dir_dx(d), ny = cy + 2 * dir_dy(d);
+            const bool ok = threadIdx.x < 4 && !(nx < x0 || nx >= x1 || ny < y0 || ny >= y1) && !(E.lc[ny * W + nx] & C_MAZE);
+            cand = (uint32_t)__ballot(ok) & 0xfu;
+        }
         int dig = -1, i = 0;
         for (int d = 0; d < 4; d++) {
-            int nx = cx + 2 * dir_dx(d), ny = cy + 2 * dir_dy(d);
-            if (nx < x0 || nx >= x1 || ny < y0 || ny >= y1) continue;
-            if (E.lc[ny * W + nx] & C_MAZE) continue;
+            if (!((cand >> d) & 1u)) continue;
             if (does_happen(E.rd, (uint32_t)i + 1)) dig = d;
             i++;
         }
@@ -477,8 +480,8 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
         u32x4 v = {nn, nn, nn, nn};
         __attribute__((address_space(3))) u32x4 *p = (__attribute__((address_space(3))) u32x4 *)cell;
         int n16 = HW / 8;
-        for (int i = 0; i < n16; i++) p[i] = v;
-        for (int i = n16 * 8; i < HW; i++) cell[i] = S_NONE;
+        for (int i = threadIdx.x; i < n16; i += WAVE) p[i] = v;
+        for (int i = n16 * 8 + threadIdx.x; i < HW; i += WAVE) cell[i] = S_NONE;
     }
     for (int s = 0; s < nrooms; s++) {  // remove_enemies + fresh Floor::items
         S.mon_w0[s * n + e] = 0;
@@ -531,26 +534,30 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
     pf.mark(9);
     // ---- paint rooms in id order (floor.rs:61-71; Room::draw rooms.rs:58-82) ----
     for (int i = 0; i < nrooms; i++) {
-        uint8_t meta = S.room_meta[i * n + e];
+        uint32_t meta = uni(S.room_meta[i * n + e]);
         int kind = meta & RM_KIND_MASK;
         if (kind == RK_EMPTY) continue;
         int x0, y0, x1, y1;
-        unpack_rect(S.room_rect[i * n + e], x0, y0, x1, y1);
+        unpack_rect(uni(S.room_rect[i * n + e]), x0, y0, x1, y1);
         if (kind == RK_NORMAL) {
-            uint16_t fl = (uint16_t)(S_FLOOR | ((meta & RM_DARK) ? C_DARK : 0));
-            for (int x = x0; x < x1; x++) { cell[y0 * W + x] = S_WALLX; cell[(y1 - 1) * W + x] = S_WALLX; }
-            for (int y = y0 + 1; y < y1 - 1; y++) {
-                cell[y * W + x0] = S_WALLY; cell[y * W + x1 - 1] = S_WALLY;
-                for (int x = x0 + 1; x < x1 - 1; x++) cell[y * W + x] = fl;
+            const uint16_t fl = (uint16_t)(S_FLOOR | ((meta & RM_DARK) ? C_DARK : 0));
+            const int rw = x1 - x0, rh = y1 - y0, area = rw * rh;
+            for (int t = threadIdx.x; t < area; t += WAVE) {  // one cell per lane: top / bottom walls (corners included), side walls, floor
+                const int yy = small_div(t, rw), xx = t - yy * rw;
+                cell[(y0 + yy) * W + x0 + xx] = (yy == 0 || yy == rh - 1) ? (uint16_t)S_WALLX : ((xx == 0 || xx == rw - 1) ? (uint16_t)S_WALLY : fl);
             }
         } else {  // maze cells in ascending range index; each draws gen_attr (Passage)
-            for (int y = y0; y < y1; y++)
-                for (int x = x0; x < x1; x++) {
-                    uint32_t v = cell[y * W + x];
-                    if (!(v & C_MAZE)) continue;
-                    uint32_t a = gen_attr_corridor(c, E, S_PASSAGE, level);
-                    cell[y * W + x] = (uint16_t)(C_MAZE | S_PASSAGE | a);
+            const int rw = x1 - x0, area = rw * (y1 - y0);
+            for (int base = 0; base < area; base += WAVE) {
+                uint64_t mm = rect_ballot(c, E, x0, y0, rw, area, base, C_MAZE, ~0u);
+                while (mm) {
+                    const int t = base + __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    const int yy = small_div(t, rw), xx = t - yy * rw;
+                    const uint32_t a = gen_attr_corridor(c, E, S_PASSAGE, level);
+                    cell[(y0 + yy) * W + x0 + xx] = (uint16_t)(C_MAZE | S_PASSAGE | a);
                 }
+            }
         }
     }
     pf.mark(10);
@@ -584,7 +591,7 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
         }
     }
     pf.mark(11);
-    for (int k = 0; k < n_edges; k++) paint_corridor(c, E, S.edge_a[k * n + e], S.edge_b[k * n + e], level);
+    for (int k = 0; k < n_edges; k++) paint_corridor(c, E, uni(S.edge_a[k * n + e]), uni(S.edge_b[k * n + e]), level);
 
     const uint32_t non_empty = (nrooms >= 32 ? 0xffffffffu : ((1u << nrooms) - 1u)) & ~empty_mask;
     pf.mark(12);
@@ -604,7 +611,7 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
     {
         uint32_t pos;
         if (floor_select(S, c, E, non_empty, 0, pos)) {
-            uint32_t v = cell[POS_Y(pos) * W + POS_X(pos)];
+            uint32_t v = uni(cell[POS_Y(pos) * W + POS_X(pos)]);
             cell[POS_Y(pos) * W + POS_X(pos)] = (uint16_t)((v & ~C_SURF_MASK) | S_STAIR);
         }
     }
@@ -616,7 +623,7 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
         for (int i = 0; i < nrooms; i++) {
             uint32_t pos;
             if (!room_select(S, c, E, i, ~0u, pos)) continue;
-            bool has_gold = S.room_meta[i * n + e] & RM_HAS_GOLD;
+            bool has_gold = uni(S.room_meta[i * n + e]) & RM_HAS_GOLD;
             if (!parcent(E.re, has_gold ? c.appear_rate_gold : c.appear_rate_nogold)) continue;
             uint32_t len = (uint32_t)c.n_enemies;
             uint32_t idx = range32(E.re, mn, mx);
@@ -635,8 +642,7 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
     }
     pf.mark(15);
     if (!c.hide_dungeon)
-        for (int y = 1; y < H - 1; y++)
-            for (int x = 0; x < W; x++) cell[y * W + x] |= C_VISIBLE;
+        for (int i = W + (int)threadIdx.x; i < (H - 1) * W; i += WAVE) cell[i] |= C_VISIBLE;  // rows 1..H-2
     return non_empty;
 }
 
@@ -645,7 +651,7 @@ __device__ __forceinline__ void place_player(const RgState &S, const RgConfig &c
     uint32_t pos = 0;
     floor_select(S, c, E, non_empty, 1, pos);
     E.px = POS_X(pos); E.py = POS_Y(pos);
-    player_in<false>(S, c, E, E.px, E.py, true);
+    player_in_init(S, c, E, E.px, E.py);
 }
 
 // GameConfig::build (core/src/lib.rs:193-228), split around the level generator
@@ -666,57 +672,69 @@ __device__ __forceinline__ void build_epilogue(const RgState &S, const RgConfig 
     E.food = c.hunger_time; E.quiet = 0; E.gold = 0;
 }
 
-// Level generation service.  Generating a level is a long chain of data-dependent, RNG-ordered tile
-// reads/writes; against global memory every one of them costs an HBM/L2 round trip with nothing to
-// hide it (one wave per SIMD).  So the lanes that need a new level (descent, auto-reset, build) stage
-// their grid in LDS: up to `nslots` lanes generate concurrently, each on its own LDS copy, then the whole
-// wave streams the finished grids to HBM with 16-byte stores.  is_build: GameConfig::build, else
+// Level generation service.  Generating a level is one long RNG-ordered chain of decisions and tile reads/writes with no parallelism across
+// the steps of one level and very little in common between two levels (lanes generating side by side diverge almost everywhere).  So the wave
+// generates ONE level at a time, all 64 lanes working on the same env: the scalars are wave-uniform (scalar unit: RNG, loop control,
+// decisions), the grid and the generator's tables live in LDS, and the bulk tile work (clear, room paint, reveals, copy-out) is spread
+// over the lanes.  Requests of several lanes are served one after the other.  is_build: GameConfig::build, else
 // Dungeon::new_level (rogue/mod.rs:434-481) followed by actions::new_level's player placement.
+__device__ __forceinline__ void env_from_lane(Env &U, const Env &E, int src) {
+    U.e = (int)lane_get((uint32_t)E.e, src); U.n = E.n;
+    uint32_t *d = reinterpret_cast<uint32_t *>(&U.rd);
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(&E.rd);
+#pragma unroll
+    for (int i = 0; i < 12; i++) d[i] = lane_get(q[i], src);  // rd, ri, re
+    U.px = (int)lane_get((uint32_t)E.px, src); U.py = (int)lane_get((uint32_t)E.py, src);
+    U.hp = (int)lane_get((uint32_t)E.hp, src); U.hpmax = (int)lane_get((uint32_t)E.hpmax, src); U.plvl = (int)lane_get((uint32_t)E.plvl, src);
+    U.exp = lane_get(E.exp, src); U.food = lane_get(E.food, src); U.quiet = lane_get(E.quiet, src); U.gold = lane_get(E.gold, src);
+    U.dlevel = lane_get(E.dlevel, src); U.mon_alive = lane_get(E.mon_alive, src); U.mon_active = lane_get(E.mon_active, src);
+}
+__device__ __forceinline__ void env_to_lane(Env &E, const Env &U) {  // the generated env's scalars back into its own lane
+    E.rd = U.rd; E.ri = U.ri; E.re = U.re;
+    E.px = U.px; E.py = U.py; E.hp = U.hp; E.hpmax = U.hpmax; E.plvl = U.plvl;
+    E.exp = U.exp; E.food = U.food; E.quiet = U.quiet; E.gold = U.gold; E.dlevel = U.dlevel; E.mon_alive = U.mon_alive; E.mon_active = U.mon_active;
+}
+static_assert(sizeof(Rng) == 16, "Rng is 4 words");
+
 __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c, Env &E, int lane, int e, bool need, bool is_build,
-                                            uint16_t *lds_grid, int nslots, Prof &pf) {
-    const int HW = c.width * c.height;
+                                            uint16_t *lds_grid, Prof &pf) {
+    const int HW = c.width * c.height, nrooms = c.room_num_x * c.room_num_y;
+    uint8_t *slot = reinterpret_cast<uint8_t *>(lds_grid);
+    GenTabs *T = reinterpret_cast<GenTabs *>(slot + GEN_SLOT_BYTES(HW) - GEN_TABS_BYTES);
     uint64_t m = __ballot(need);
     while (m) {
-        int rank = __popcll(m & ((1ull << lane) - 1ull));
-        bool mine = need && rank < nslots;
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
         unsigned long long tg0 = pf.p ? __builtin_amdgcn_s_memtime() : 0;
-        if (mine) {
-            uint8_t *slot = reinterpret_cast<uint8_t *>(lds_grid) + (size_t)rank * GEN_SLOT_BYTES(HW);
-            GenTabs *T = reinterpret_cast<GenTabs *>(slot + GEN_SLOT_BYTES(HW) - GEN_TABS_BYTES);
-            E.cell = reinterpret_cast<uint16_t *>(slot);
-            E.lc = (lds_u16 *)E.cell;
-            if (is_build) build_prologue(S, E);
-            // table view of this slot: column 0 of a 1-env SoA
-            RgState L = S;
-            L.room_rect = T->room_rect; L.room_meta = T->room_meta; L.mon_w0 = T->mon_w0; L.mon_hp = T->mon_hp; L.mon_exp = T->mon_exp;
-            L.gold_pos = T->gold_pos; L.gold_amt = T->gold_amt; L.edge_a = T->edge_a; L.edge_b = T->edge_b;
-            L.maze_stack = S.maze_stack + (size_t)E.e * RG_MAZE_STACK;
-            const int real_e = E.e, real_n = E.n, nrooms = c.room_num_x * c.room_num_y;
-            E.e = 0; E.n = 1; E.stk_lds = T->stack;
-            uint32_t non_empty = gen_level(L, c, E, pf);
-            if (is_build) build_epilogue(L, c, E);
-            place_player(L, c, E, non_empty);
-            E.e = real_e; E.n = real_n; E.stk_lds = nullptr;
-            for (int s = 0; s < nrooms; s++) {
-                const size_t g = (size_t)s * real_n + real_e;
-                S.room_rect[g] = T->room_rect[s]; S.room_meta[g] = T->room_meta[s];
-                S.mon_w0[g] = T->mon_w0[s]; S.mon_hp[g] = T->mon_hp[s]; S.mon_exp[g] = T->mon_exp[s];
-                S.gold_pos[g] = T->gold_pos[s]; S.gold_amt[g] = T->gold_amt[s];
-            }
-            E.cell = E.gcell;
-            need = false;
-        }
-        if (pf.p) pf.rec(__popcll(m) == 1 ? 20 : 22, __builtin_amdgcn_s_memtime() - tg0);  // per-round generation time, by number of generating lanes
-        pf.mark(16);
+        Env U;
+        env_from_lane(U, E, src);
+        const int real_e = U.e, real_n = U.n;
+        U.cell = U.gcell = reinterpret_cast<uint16_t *>(slot);
+        U.lc = (lds_u16 *)U.cell;
+        U.stk_lds = T->stack; U.mc = nullptr;
+        if (is_build) build_prologue(S, U);
+        // table view: column 0 of a 1-env SoA in LDS
+        RgState L = S;
+        L.room_rect = T->room_rect; L.room_meta = T->room_meta; L.mon_w0 = T->mon_w0; L.mon_hp = T->mon_hp; L.mon_exp = T->mon_exp;
+        L.gold_pos = T->gold_pos; L.gold_amt = T->gold_amt; L.edge_a = T->edge_a; L.edge_b = T->edge_b;
+        L.maze_stack = S.maze_stack + (size_t)real_e * RG_MAZE_STACK;
+        U.e = 0; U.n = 1;
+        uint32_t non_empty = gen_level(L, c, U, pf);
+        if (is_build) build_epilogue(L, c, U);
+        place_player(L, c, U, non_empty);
+        U.e = real_e; U.n = real_n;
+        if (lane == src) { env_to_lane(E, U); need = false; }
         __syncthreads();
-        int served = __popcll(m);
-        if (served > nslots) served = nslots;
-        for (int r = 0; r < served; r++) {
-            int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            int env_s = __shfl(e, src);
-            uint16_t *dst = S.cell + (size_t)env_s * HW;
-            const uint16_t *srcp = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(lds_grid) + (size_t)r * GEN_SLOT_BYTES(HW));
+        // tables: one room slot per lane; grid: 16 bytes per lane
+        if (lane < nrooms) {
+            const size_t g = (size_t)lane * real_n + real_e;
+            S.room_rect[g] = T->room_rect[lane]; S.room_meta[g] = T->room_meta[lane];
+            S.mon_w0[g] = T->mon_w0[lane]; S.mon_hp[g] = T->mon_hp[lane]; S.mon_exp[g] = T->mon_exp[lane];
+            S.gold_pos[g] = T->gold_pos[lane]; S.gold_amt[g] = T->gold_amt[lane];
+        }
+        {
+            uint16_t *dst = S.cell + (size_t)real_e * HW;
+            const uint16_t *srcp = reinterpret_cast<const uint16_t *>(slot);
             if ((HW & 7) == 0) {
                 uint4 *d4 = reinterpret_cast<uint4 *>(dst);
                 const uint4 *s4 = reinterpret_cast<const uint4 *>(srcp);
@@ -724,8 +742,11 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
             } else
                 for (int i = lane; i < HW; i += WAVE) dst[i] = srcp[i];
         }
+        if (pf.p) pf.rec(20, __builtin_amdgcn_s_memtime() - tg0);
+        pf.mark(16);
         __syncthreads();
     }
+    (void)e;
 }
 
 // RunTime::player_status (core/src/lib.rs:345-356, player.rs:107-118) -> mirror
@@ -767,14 +788,14 @@ __device__ __forceinline__ void store_env(const RgState &S, const Env &E) {
 // ---------------------------------------------------------------------------------------------
 extern __shared__ __align__(16) uint8_t g_smem[];
 
-__global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c, int nslots) {
+__global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     const int lane = threadIdx.x;
     const int e = blockIdx.x * WAVE + lane;
     const bool valid = e < S.n;
     Env E;
     E.e = valid ? e : 0; E.n = S.n; E.cell = E.gcell = S.cell + (size_t)E.e * S.hw;
     Prof pf; pf.start(S.prof);
-    gen_service(S, c, E, lane, e, valid, true, reinterpret_cast<uint16_t *>(g_smem), nslots, pf);
+    gen_service(S, c, E, lane, e, valid, true, reinterpret_cast<uint16_t *>(g_smem), pf);
     if (!valid) return;
     store_env(S, E);
     write_status(S, c, E);
@@ -794,7 +815,7 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c, int nslot
 // one generation per consumed spare, overlapped with the following steps; k_step's reset then is a copy.
 // SP is an RgState whose core pointers address the spare arrays.  Hand-off per env through sp_ready with
 // agent-scope release/acquire (the consumer kernel runs concurrently on another stream).
-__global__ void __launch_bounds__(WAVE) k_regen(RgState SP, RgConfig c, int nslots) {
+__global__ void __launch_bounds__(WAVE) k_regen(RgState SP, RgConfig c) {
     const int lane = threadIdx.x;
     const int e = blockIdx.x * WAVE + lane;
     const bool valid = e < SP.n;
@@ -805,7 +826,7 @@ __global__ void __launch_bounds__(WAVE) k_regen(RgState SP, RgConfig c, int nslo
     Env E;
     E.e = valid ? e : 0; E.n = SP.n; E.cell = E.gcell = SP.cell + (size_t)E.e * SP.hw;
     Prof pf; pf.start(nullptr);
-    gen_service(SP, c, E, lane, e, claim, true, reinterpret_cast<uint16_t *>(g_smem), nslots, pf);
+    gen_service(SP, c, E, lane, e, claim, true, reinterpret_cast<uint16_t *>(g_smem), pf);
     if (claim) store_env(SP, E);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1475,8 +1496,8 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
 // ---------------------------------------------------------------------------------------------
 // k_step: one key for every env
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c, const uint8_t *__restrict__ keys, uint32_t *__restrict__ err_any, int nslots,
-                                               int use_spares, int mc_offset) {
+__global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c, const uint8_t *__restrict__ keys, uint32_t *__restrict__ err_any, int use_spares,
+                                               int mc_offset) {
     __builtin_amdgcn_s_setprio(3);  // issue-bound kernel: win VALU arbitration against the co-resident background k_regen waves
     uint16_t *lds_grid = reinterpret_cast<uint16_t *>(g_smem);
     const int lane = threadIdx.x;
@@ -1558,7 +1579,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
             }
         }
         const bool regenerated = need_gen && pass == 0;
-        gen_service(S, c, E, lane, e, need_gen, pass == 1, lds_grid, nslots, pf);
+        gen_service(S, c, E, lane, e, need_gen, pass == 1, lds_grid, pf);
         if (regenerated) for (int s = 0; s < nrooms_k; s++) E.mc[s * WAVE] = S.mon_w0[s * S.n + e];  // descended: reload this lane's cache column (after a reset nothing reads it again)
         pf.mark(2);
         need_gen = false;
@@ -1659,36 +1680,27 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
 // host-callable launchers (used by rg_api.cpp)
 // ---------------------------------------------------------------------------------------------
 extern "C" {
-static int gen_slots(int hw, int budget_bytes) {
-    int n = budget_bytes / (int)GEN_SLOT_BYTES(hw);
-    return n < 1 ? 1 : (n > WAVE ? WAVE : n);
-}
 static size_t bfs_bytes(const RgConfig *c) {
     int rows = c->height <= 16 ? 16 : (c->height <= 32 ? 32 : 64);
     return (size_t)(WAVE / rows) * c->width * c->height * 2;
 }
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
-    int ns = gen_slots(hw, 64 * 1024);
-    size_t smem = (size_t)ns * GEN_SLOT_BYTES(hw);
-    hipLaunchKernelGGL(k_build, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *c, ns);
+    size_t smem = GEN_SLOT_BYTES(hw);  // one level at a time per wave: one staging grid + the generator's tables
+    hipLaunchKernelGGL(k_build, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *c);
 }
 void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, int use_spares, hipStream_t st) {
     int hw = c->width * c->height;
-    static const int step_kb = getenv("RG_GEN_LDS_KB") ? atoi(getenv("RG_GEN_LDS_KB")) : 8;
-    int ns = gen_slots(hw, step_kb * 1024);  // inline generation is rare (descents, spare misses): a small LDS footprint keeps k_regen co-resident
-    size_t smem = (size_t)ns * GEN_SLOT_BYTES(hw);
+    size_t smem = GEN_SLOT_BYTES(hw);
     if (bfs_bytes(c) > smem) smem = bfs_bytes(c);
     smem = (smem + 15) & ~(size_t)15;
     int mc_offset = (int)smem;
     smem += (size_t)c->room_num_x * c->room_num_y * WAVE * 4;  // LDS monster cache
-    hipLaunchKernelGGL(k_step, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *SP, *c, keys, err_any, ns, use_spares, mc_offset);
+    hipLaunchKernelGGL(k_step, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset);
 }
 void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
-    static const int regen_kb = getenv("RG_REGEN_LDS_KB") ? atoi(getenv("RG_REGEN_LDS_KB")) : 8;
-    int ns = gen_slots(hw, regen_kb * 1024);  // ~0.4 refills per wave and step; fewer than 4 slots costs spare misses, more buys nothing
-    size_t smem = (size_t)ns * GEN_SLOT_BYTES(hw);
-    hipLaunchKernelGGL(k_regen, dim3((SP->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *SP, *c, ns);
+    size_t smem = GEN_SLOT_BYTES(hw);
+    hipLaunchKernelGGL(k_regen, dim3((SP->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *SP, *c);
 }
 }
