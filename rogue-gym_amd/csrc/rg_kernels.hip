@@ -308,16 +308,6 @@ __device__ __forceinline__ uint32_t gen_attr_corridor(const RgConfig &c, Env &E,
     }
     return 0;
 }
-// one registered corridor cell (floor.rs:87-101)
-__device__ __forceinline__ void register_cell(const RgConfig &c, Env &E, int x, int y, int kind, uint32_t level) {
-    uint32_t a = gen_attr_corridor(c, E, kind, level);
-    uint32_t v = uni(E.lc[y * c.width + x]);
-    v = (v & ~C_ATTR_MASK) | a;
-    if (kind == S_DOOR) v |= C_DOOR;
-    if (!a) v = (v & ~C_SURF_MASK) | (uint32_t)kind;
-    E.lc[y * c.width + x] = (uint16_t)v;
-}
-
 // select_start_or_end (passages.rs:143-179).  dir: 0 Up 1 Down 2 Left 3 Right
 __device__ __forceinline__ uint32_t select_door(const RgState &S, const RgConfig &c, Env &E, int rid, int dir) {
     uint32_t meta = uni(S.room_meta[rid * E.n + E.e]);
@@ -375,23 +365,50 @@ __device__ __forceinline__ void connect_rooms(const RgState &S, const RgConfig &
         n_edges++;
     }
 }
-// replay one recorded corridor in registration order (passages.rs:98-132 + floor.rs:87-101)
+// replay one recorded corridor in registration order (passages.rs:98-132 + floor.rs:87-101): start door, end door, then the three legs.
+// The cells of one corridor are distinct, so the lanes fetch them all up front (cell i in lane i), the gen_attr draws run in
+// registration order on the scalar unit, and the lanes write their cells back together (register_cell's update rule).
 __device__ __forceinline__ void paint_corridor(const RgConfig &c, Env &E, uint32_t a, uint32_t b, uint32_t level) {
-    int sx = POS_X(a), sy = POS_Y(a), ex = POS_X(a >> 16), ey = POS_Y(a >> 16);
-    int bend = b & 0xff;
-    bool down = (b >> 8) & 1;
-    register_cell(c, E, sx, sy, ((b >> 9) & 1) ? S_DOOR : S_PASSAGE, level);
-    register_cell(c, E, ex, ey, ((b >> 10) & 1) ? S_DOOR : S_PASSAGE, level);
-    int dx = down ? 0 : 1, dy = down ? 1 : 0;
-    int tsx = down ? sx : bend, tsy = down ? bend : sy;
-    int tex = down ? ex : bend, tey = down ? bend : ey;
-    int tdx = down ? (sx < ex ? 1 : -1) : 0, tdy = down ? 0 : (sy < ey ? 1 : -1);
-    int x = sx + dx, y = sy + dy;
-    while (!(x == tsx && y == tsy)) { register_cell(c, E, x, y, S_PASSAGE, level); x += dx; y += dy; }
-    x = tsx; y = tsy;
-    while (!(x == tex && y == tey)) { register_cell(c, E, x, y, S_PASSAGE, level); x += tdx; y += tdy; }
-    x = tex; y = tey;
-    while (!(x == ex && y == ey)) { register_cell(c, E, x, y, S_PASSAGE, level); x += dx; y += dy; }
+    const int W = c.width, lane = threadIdx.x;
+    const int sx = POS_X(a), sy = POS_Y(a), ex = POS_X(a >> 16), ey = POS_Y(a >> 16);
+    const int bend = b & 0xff;
+    const bool down = (b >> 8) & 1;
+    const int kind_s = ((b >> 9) & 1) ? S_DOOR : S_PASSAGE, kind_e = ((b >> 10) & 1) ? S_DOOR : S_PASSAGE;
+    const int dx = down ? 0 : 1, dy = down ? 1 : 0;
+    const int tsx = down ? sx : bend, tsy = down ? bend : sy;
+    const int tex = down ? ex : bend, tey = down ? bend : ey;
+    const int tdx = down ? (sx < ex ? 1 : -1) : 0, tdy = down ? 0 : (sy < ey ? 1 : -1);
+    const int n1 = (down ? bend - sy : bend - sx) - 1;                        // start + 1 .. turn - 1
+    const int n2 = down ? (ex > sx ? ex - sx : sx - ex) : (ey > sy ? ey - sy : sy - ey);  // along the turn, its far end excluded
+    const int n3 = down ? ey - bend : ex - bend;                              // turn end .. end - 1
+    const int total = 2 + n1 + n2 + n3;
+    for (int base = 0; base < total; base += WAVE) {
+        const int i = base + lane;
+        int x = sx, y = sy;
+        if (i == 1) { x = ex; y = ey; }
+        else if (i >= 2) {
+            int k = i - 2;
+            if (k < n1) { x = sx + dx * (k + 1); y = sy + dy * (k + 1); }
+            else if ((k -= n1) < n2) { x = tsx + tdx * k; y = tsy + tdy * k; }
+            else { k -= n2; x = tex + dx * k; y = tey + dy * k; }
+        }
+        const bool mine = i < total;
+        uint32_t v = mine ? (uint32_t)E.lc[y * W + x] : 0u;
+        uint32_t attr = 0;
+        const int cnt = total - base < WAVE ? total - base : WAVE;
+        for (int j = 0; j < cnt; j++) {
+            const int kind = base + j == 0 ? kind_s : (base + j == 1 ? kind_e : S_PASSAGE);
+            const uint32_t at = gen_attr_corridor(c, E, kind, level);
+            if (lane == j) attr = at;
+        }
+        if (mine) {
+            const int kind = i == 0 ? kind_s : (i == 1 ? kind_e : S_PASSAGE);
+            v = (v & ~C_ATTR_MASK) | attr;
+            if (kind == S_DOOR) v |= C_DOOR;
+            if (!attr) v = (v & ~C_SURF_MASK) | (uint32_t)kind;
+            E.lc[y * W + x] = (uint16_t)v;
+        }
+    }
 }
 
 // select_candidate (passages.rs:69-82): reservoir over grid-neighbour rooms in ascending id
@@ -430,21 +447,26 @@ struct GenTabs {
 
 // dig_maze (maze.rs:38-89) with an explicit stack (the reference recurses; same visiting and draw order)
 __device__ __forceinline__ void dig_maze(const RgState &S, const RgConfig &c, Env &E, int x0, int y0, int x1, int y1) {
-    // the DFS never holds more than one entry per maze cell (every other cell of the room in x and y)
-    const bool small = ((x1 - x0 + 1) >> 1) * ((y1 - y0 + 1) >> 1) <= GEN_STACK_LDS;
+    // maze nodes = every other cell of the room in x and y; the DFS holds at most one stack entry per node
+    const int mw = (x1 - x0 + 1) >> 1, mh = (y1 - y0 + 1) >> 1;
     lds_u16 *ls = (lds_u16 *)E.stk_lds;
     uint16_t *gs = S.maze_stack + (size_t)E.e * RG_MAZE_STACK;
-    const bool in_lds = E.stk_lds && small;
-    int W = c.width, sp = 0;
-    E.lc[y0 * W + x0] |= C_MAZE;
-    if (in_lds) ls[sp] = (uint16_t)POS(x0, y0); else gs[sp] = (uint16_t)POS(x0, y0);
-    sp++;
-    while (sp > 0) {
-        const uint32_t top = uni(in_lds ? ls[sp - 1] : gs[sp - 1]);
-        int cx = POS_X(top), cy = POS_Y(top);
-        // the four candidate cells tested by lanes 0..3 at once
-        uint32_t cand;
-        {
+    const bool in_lds = E.stk_lds && mw * mh <= GEN_STACK_LDS;
+    const bool bitmap = mw * mh <= 64;  // dug nodes as a 64-bit scalar mask: the neighbour tests never touch memory
+    const int W = c.width;
+    const uint16_t dug = (uint16_t)(S_NONE | C_MAZE);  // the room's area is untouched (fresh Field) until its maze is painted
+    E.lc[y0 * W + x0] = dug;
+    uint64_t seen = 1ull;
+    int cx = x0, cy = y0, sp = 1;  // sp counts the current cell as the reference's recursion depth does
+    for (;;) {
+        uint32_t cand = 0;
+        if (bitmap) {
+            const int ix = (cx - x0) >> 1, iy = (cy - y0) >> 1;
+            if (iy > 0 && !((seen >> ((iy - 1) * mw + ix)) & 1ull)) cand |= 1u;        // Up
+            if (iy + 1 < mh && !((seen >> ((iy + 1) * mw + ix)) & 1ull)) cand |= 2u;  // Down
+            if (ix > 0 && !((seen >> (iy * mw + ix - 1)) & 1ull)) cand |= 4u;          // Left
+            if (ix + 1 < mw && !((seen >> (iy * mw + ix + 1)) & 1ull)) cand |= 8u;    // Right
+        } else {  // the four candidate cells tested by lanes 0..3 at once
             const int d = (int)threadIdx.x & 3;
             const int nx = cx + 2 * dir_dx(d), ny = cy + 2 * dir_dy(d);
             const bool ok = threadIdx.x < 4 && !(nx < x0 || nx >= x1 || ny < y0 || ny >= y1) && !(E.lc[ny * W + nx] & C_MAZE);
@@ -456,12 +478,21 @@ __device__ __forceinline__ void dig_maze(const RgState &S, const RgConfig &c, En
             if (does_happen(E.rd, (uint32_t)i + 1)) dig = d;
             i++;
         }
-        if (dig < 0) { sp--; continue; }
-        for (int k = 1; k <= 2; k++) E.lc[(cy + k * dir_dy(dig)) * W + cx + k * dir_dx(dig)] |= C_MAZE;
-        if (sp < RG_MAZE_STACK) {
-            const uint16_t nv = (uint16_t)POS(cx + 2 * dir_dx(dig), cy + 2 * dir_dy(dig));
-            if (in_lds) ls[sp] = nv; else gs[sp] = nv;
+        if (dig < 0) {  // dead end: back to the parent
+            if (--sp == 0) break;
+            const uint32_t top = uni(in_lds ? ls[sp - 1] : gs[sp - 1]);
+            cx = POS_X(top); cy = POS_Y(top);
+            continue;
+        }
+        const int ddx = dir_dx(dig), ddy = dir_dy(dig);
+        E.lc[(cy + ddy) * W + cx + ddx] = dug;
+        E.lc[(cy + 2 * ddy) * W + cx + 2 * ddx] = dug;
+        if (bitmap) seen |= 1ull << ((((cy + 2 * ddy) - y0) >> 1) * mw + (((cx + 2 * ddx) - x0) >> 1));
+        if (sp < RG_MAZE_STACK) {  // descend: the current cell goes on the stack
+            const uint16_t cur = (uint16_t)POS(cx, cy);
+            if (in_lds) ls[sp - 1] = cur; else gs[sp - 1] = cur;
             sp++;
+            cx += 2 * ddx; cy += 2 * ddy;
         }
     }
 }
@@ -788,10 +819,13 @@ __device__ __forceinline__ void store_env(const RgState &S, const Env &E) {
 // ---------------------------------------------------------------------------------------------
 extern __shared__ __align__(16) uint8_t g_smem[];
 
+// BUILD_EPB envs per wave: a wave generates its levels one after the other, so fewer envs per wave = more waves per SIMD to overlap the
+// generator's latencies (create / rg_reset only; not on the step path)
+#define BUILD_EPB 16
 __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     const int lane = threadIdx.x;
-    const int e = blockIdx.x * WAVE + lane;
-    const bool valid = e < S.n;
+    const int e = blockIdx.x * BUILD_EPB + lane;
+    const bool valid = lane < BUILD_EPB && e < S.n;
     Env E;
     E.e = valid ? e : 0; E.n = S.n; E.cell = E.gcell = S.cell + (size_t)E.e * S.hw;
     Prof pf; pf.start(S.prof);
@@ -1687,7 +1721,7 @@ static size_t bfs_bytes(const RgConfig *c) {
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw);  // one level at a time per wave: one staging grid + the generator's tables
-    hipLaunchKernelGGL(k_build, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *c);
+    hipLaunchKernelGGL(k_build, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), smem, st, *S, *c);
 }
 void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, int use_spares, hipStream_t st) {
     int hw = c->width * c->height;
