@@ -373,7 +373,7 @@ done:
 int rg_prof(rg_t *h, int enable, unsigned long long *out) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    const size_t words = (size_t)((h->S.n + 63) / 64) * 64;
+    const size_t words = (size_t)((h->S.n + 15) / 16) * 64;  // k_step runs 16..64 envs per wave
     if (out && h->S.prof) HIPCHK(h, hipMemcpy(out, h->S.prof, words * 8, hipMemcpyDeviceToHost));
     if (enable && !h->S.prof) { if (!dev_alloc(h, &h->S.prof, words)) return 1; }
     if (h->S.prof) HIPCHK(h, hipMemset(h->S.prof, 0, words * 8));

@@ -1531,12 +1531,12 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
 // k_step: one key for every env
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c, const uint8_t *__restrict__ keys, uint32_t *__restrict__ err_any, int use_spares,
-                                               int mc_offset) {
+                                               int mc_offset, int epw) {
     __builtin_amdgcn_s_setprio(3);  // issue-bound kernel: win VALU arbitration against the co-resident background k_regen waves
     uint16_t *lds_grid = reinterpret_cast<uint16_t *>(g_smem);
     const int lane = threadIdx.x;
-    const int e = blockIdx.x * WAVE + lane;
-    const bool valid = e < S.n;
+    const int e = blockIdx.x * epw + lane;  // epw envs per wave (64, or fewer when the batch would leave SIMDs without a wave)
+    const bool valid = lane < epw && e < S.n;
     Prof pf; pf.start(S.prof);
     Env E;
     uint32_t react = 0, err = 0, old_flags = 0, steps = 0, flags = 0;
@@ -1730,7 +1730,13 @@ void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint
     smem = (smem + 15) & ~(size_t)15;
     int mc_offset = (int)smem;
     smem += (size_t)c->room_num_x * c->room_num_y * WAVE * 4;  // LDS monster cache
-    hipLaunchKernelGGL(k_step, dim3((S->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset);
+    // envs per wave: the register footprint allows one step wave per SIMD (1024 on the chip); a batch below 64 x 1024 envs is spread over more,
+    // emptier waves (less divergence per wave, no idle SIMDs).  More waves than SIMDs never pays: a wave's cost is the union of its lanes' paths.
+    static const int epw_env = getenv("ROGUE_GYM_HIP_EPW") ? atoi(getenv("ROGUE_GYM_HIP_EPW")) : 0;
+    int epw = WAVE;
+    while (epw > 16 && (S->n + epw - 1) / epw < 1024) epw >>= 1;
+    if (epw_env == 16 || epw_env == 32 || epw_env == 64) epw = epw_env;
+    hipLaunchKernelGGL(k_step, dim3((S->n + epw - 1) / epw), dim3(WAVE), smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset, epw);
 }
 void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;

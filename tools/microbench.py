@@ -78,7 +78,7 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
     for t in range(150):
         L.rg_step(h.h, C.c_void_p(keys[t % 64].data_ptr()), 1)
     nw = (n + 63) // 64
-    buf = np.zeros((nw, 64), np.uint64)
+    buf = np.zeros(((n + 15) // 16, 64), np.uint64)  # rg_prof copies one row per 16 envs (the smallest envs-per-wave)
     L.rg_prof(h.h, 1, None)
     sums, maxs, totals, counts = {}, {}, [], {}
     L.rg_timing_enable(h.h, 1)
@@ -88,9 +88,10 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
         else:
             L.rg_step(h.h, C.c_void_p(keys[t % 64].data_ptr()), 1)
         L.rg_prof(h.h, 1, buf.ctypes.data_as(C.c_void_p))
-        k = buf[:, 0].astype(np.int64)
-        totals.append(buf[:, 63].astype(np.float64))
-        rec = buf[:, 1:62]
+        buf_used = buf[:nw] if not do_reset else buf
+        k = buf_used[:, 0].astype(np.int64)
+        totals.append(buf_used[:, 63].astype(np.float64))
+        rec = buf_used[:, 1:62]
         valid = np.arange(61)[None, :] < k[:, None]
         ph = (rec >> np.uint64(48)).astype(np.int64)
         val = (rec & np.uint64((1 << 48) - 1)).astype(np.float64)
