@@ -176,6 +176,38 @@ def test_descents_many_and_few_lanes_per_wave(goldens, period):
     assert max(levels) >= 2, "the log must descend at least once within 400 keys"
 
 
+GEOMETRIES = [
+    # width, height, room_num_x, room_num_y  -- which code paths the shape selects
+    (40, 20, 2, 2),    # 32 < W <= 64: one 64-bit mask per row; H = 20: 32-row BFS groups (2 maps per round)
+    (50, 21, 3, 2),    # H*W = 1050 is not a multiple of 8: unfused k_render + scalar encode, scalar grid copies
+    (96, 32, 4, 3),    # 64 < W <= 128: two mask words per row; 12 rooms
+    (160, 48, 4, 4),   # the reference's maximum screen (core/src/lib.rs:134-140): three mask words, 64-row BFS, 16 rooms
+    (64, 16, 4, 1),    # a single row of rooms
+    (32, 48, 1, 3),    # narrowest x tallest screen: a single column of rooms
+]
+
+
+@pytest.mark.parametrize("w,h,rx,ry", GEOMETRIES)
+def test_lockstep_other_geometries(goldens, w, h, rx, ry):
+    """Screen sizes and room grids other than the two benchmark configs: first screens, lock-step play with every key,
+    internal state and both observation encoders."""
+    cfg = {"width": w, "height": h, "dungeon": {"style": "rogue", "room_num_x": rx, "room_num_y": ry, "min_room_size": {"x": 4, "y": 4}}}
+    n = 96
+    rng = np.random.RandomState(w * 1000 + h)
+    hip, oracles = lockstep(cfg, list(range(500, 500 + n)), rand_keys(rng, ALL_KEYS, n, 160), max_steps=90, check_every=1, internal_every=40)
+    for kind in (0, 1):
+        for flag, with_hist in ((0, False), (0x1ff, True)):
+            got = hip.obs(kind, flag, with_hist)
+            for i in (0, n // 2, n - 1):
+                o = oracles[i]
+                try:
+                    exp = o.symbol_image(flag, with_hist) if kind else o.gray_image(flag, with_hist)
+                except RuntimeError:  # symbol image with a 'Z' on screen errors in the reference
+                    continue
+                assert np.array_equal(got[i], exp), (kind, flag, with_hist, i)
+    hip.h.L.rg_sync(hip.h.h)  # drain a possible tile-error flag
+
+
 def test_spares_survive_reseeding(goldens):
     """rg_seed invalidates the pre-generated spares: after seed() + reset() and further auto-resets the envs follow the new seeds."""
     cfg = goldens["configs"]["mini"]
