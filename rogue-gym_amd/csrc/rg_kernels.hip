@@ -39,11 +39,9 @@ __device__ __forceinline__ uint32_t rng_u32(Rng &r) {
 __device__ __forceinline__ uint32_t range32(Rng &r, uint32_t low, uint32_t high) {
     uint32_t range = high - low;
     uint32_t zone = (range << __clz((int)range)) - 1u;
-    for (;;) {
-        uint32_t v = rng_u32(r);
-        uint32_t lo = v * range;
-        if (lo <= zone) return low + __umulhi(v, range);
-    }
+    uint32_t v = rng_u32(r);
+    while (__builtin_expect(v * range > zone, 0)) v = rng_u32(r);  // rejections are rare: straight-line code on the accepted path
+    return low + __umulhi(v, range);
 }
 // usize / i64 call sites: next_u64 = two next_u32 (low word first), 128-bit product.
 // Every 64-bit call site of the engine has range < 2^32 (room counts, cell counts, dice), so the 128-bit product
@@ -54,14 +52,13 @@ __device__ __forceinline__ uint64_t range64(Rng &r, uint64_t low, uint64_t high)
     if ((range >> 32) == 0) {
         uint32_t rg = (uint32_t)range;
         uint32_t top = rg << __clz((int)rg);  // zone = (top << 32) - 1
-        for (;;) {
-            uint32_t l = rng_u32(r), h = rng_u32(r);
-            uint32_t p0_hi = __umulhi(l, rg);
-            uint32_t p1_lo = h * rg, p1_hi = __umulhi(h, rg);
-            uint32_t mid = p0_hi + p1_lo;          // bits 32..63 of the low half of the product
-            uint32_t carry = mid < p0_hi ? 1u : 0u;
-            if (mid < top) return low + (uint64_t)(p1_hi + carry);
-        }
+        uint32_t l, h, p0_hi, mid;
+        do {
+            l = rng_u32(r); h = rng_u32(r);
+            p0_hi = __umulhi(l, rg);
+            mid = p0_hi + h * rg;                  // bits 32..63 of the low half of the product
+        } while (__builtin_expect(!(mid < top), 0));
+        return low + (uint64_t)(__umulhi(h, rg) + (mid < p0_hi ? 1u : 0u));
     }
     uint64_t zone = (range << __clzll((long long)range)) - 1ull;
     for (;;) {
