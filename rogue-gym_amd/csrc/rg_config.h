@@ -3,7 +3,7 @@
 #include <cstdint>
 #include <string>
 
-#define RG_MAX_ROOMS 16     // room_num_x * room_num_y (reference default 3x3; no limit there)
+#define RG_MAX_ROOMS 32     // room_num_x * room_num_y (reference default 3x3; no limit there; 32 = the width of the room bitmasks)
 #define RG_MAX_ENEMY_KINDS 26
 #define RG_MAX_W 160        // core/src/lib.rs:134-140
 #define RG_MAX_H 48

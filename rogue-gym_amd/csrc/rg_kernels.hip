@@ -1395,9 +1395,9 @@ __device__ __forceinline__ int next_pending(const RgState &S, const Env &E, int 
 
 // EnemyHandler::move_actives, RNG part (enemies.rs:399-404, rogue/mod.rs:383): the per-monster draws do not
 // depend on positions, so they are taken first (same per-stream order) to learn whether a dist map is needed.
-__device__ __forceinline__ bool monsters_prepass(const RgState &S, const RgConfig &c, Env &E, uint32_t &rand_mask, uint64_t &rand_dir) {
+__device__ __forceinline__ bool monsters_prepass(const RgState &S, const RgConfig &c, Env &E, uint32_t &rand_mask, uint64_t (&rand_dir)[2]) {
     const int nrooms = c.room_num_x * c.room_num_y;
-    rand_mask = 0; rand_dir = 0;
+    rand_mask = 0; rand_dir[0] = rand_dir[1] = 0;  // 4 bits per monster slot, 16 slots per word
     for (int s = 0; s < nrooms; s++) {  // the taken map: every active monster is pending
         uint32_t w = mon_rd<true>(S, E, s);
         if (((w >> 24) & (MF_ALIVE | MF_ACTIVE)) == (MF_ALIVE | MF_ACTIVE)) E.mc[s * WAVE] = w | ((uint32_t)MF_PENDING << 24);  // PENDING lives in the cache only
@@ -1411,7 +1411,8 @@ __device__ __forceinline__ bool monsters_prepass(const RgState &S, const RgConfi
         else if (!does_happen(E.re, 5) && (attr & EA_CONFUSED)) rnd = true;
         if (rnd) {
             rand_mask |= 1u << slot;
-            rand_dir |= range64(E.rd, 0, 8) << (slot * 4);
+            const uint64_t dbits = range64(E.rd, 0, 8) << ((slot & 15) * 4);
+            if (slot < 16) rand_dir[0] |= dbits; else rand_dir[1] |= dbits;
         } else need_map = true;
     }
     return need_map;
@@ -1438,7 +1439,7 @@ __device__ __forceinline__ bool dist_cache_lookup(const RgState &S, const Env &E
 
 // EnemyHandler::move_actives moves + actions::move_active_enemies attacks
 // (enemies.rs:366-424, rogue/mod.rs:339-397, actions.rs:82-119, fight.rs:41-72)
-__device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &c, Env &E, uint32_t rand_mask, uint64_t rand_dir, int map_slot, uint32_t &react) {
+__device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &c, Env &E, uint32_t rand_mask, const uint64_t (&rand_dir)[2], int map_slot, uint32_t &react) {
     const int nrooms = c.room_num_x * c.room_num_y, W = c.width, e = E.e;
     const uint16_t *dist = S.dc_map + ((size_t)e * RG_DIST_SLOTS + (map_slot < 0 ? 0 : map_slot)) * S.hw;
     const uint32_t ppos = POS(E.px, E.py);
@@ -1471,7 +1472,7 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
         if (!((walk >> 2) & (walk >> 1) & 1u)) cm &= ~(1u << 6);  // LeftDown: Left, Down
         if (!((walk >> 3) & (walk >> 1) & 1u)) cm &= ~(1u << 7);  // RightDown: Right, Down
         if (random) {  // Dungeon::move_enemy_randomly
-            int d = (int)((rand_dir >> (slot * 4)) & 7);
+            int d = (int)(((slot < 16 ? rand_dir[0] : rand_dir[1]) >> ((slot & 15) * 4)) & 7);
             uint32_t np = POS(cx + dir_dx(d), cy + dir_dy(d));
             if (!blocked_for(S, E, nrooms, np, slot) && ((cm >> d) & 1u)) {
                 if (np == ppos) reach = true; else fin = np;
@@ -1488,7 +1489,7 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
             }
             if (!reach && found) fin = bp;
         }
-        if (reach) { att_list |= (uint64_t)slot << (4 * n_att); n_att++; }
+        if (reach && n_att < 12) { att_list |= (uint64_t)slot << (5 * n_att); n_att++; }  // at most 8 monsters are adjacent to the player
         if (fin == (w & 0xffff)) {
             // BTreeMap::insert on its own key replaces a monster that already moved onto this cell
             for (int s = 0; s < nrooms; s++) {
@@ -1503,7 +1504,7 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
     bool did_hit = false;
     uint32_t lev_add = lev_add_of(c, E.dlevel);
     for (int i = 0; i < n_att; i++) {
-        int s = (int)((att_list >> (4 * i)) & 15);
+        int s = (int)((att_list >> (5 * i)) & 31);
         uint32_t type = (mon_rd<true>(S, E, s) >> 16) & 0xff;
         uint32_t rate = attack_rate((int64_t)c.mon[type].level + lev_add, 4 /* ring mail 3 + 1 */, 0 /* hit_prob_plus(10) */);
         int sum = 0; bool hit = false;
@@ -1620,7 +1621,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
         int iter = 0;
         while (__any(running)) {
             bool do_turn = false, need_bfs = false;
-            uint32_t rand_mask = 0; uint64_t rand_dir = 0; int map_slot = -1;
+            uint32_t rand_mask = 0; uint64_t rand_dir[2] = {0, 0}; int map_slot = -1;
             FillReq fr; fr.leave = fr.enter = 0;
             if (running) {
                 switch (act) {  // actions::process_action (actions.rs:16-65)

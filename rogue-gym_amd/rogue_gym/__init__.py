@@ -1,5 +1,5 @@
 """MI355X-native drop-in for the reference `rogue_gym` package (python/rogue_gym/__init__.py)."""
-from .envs import (DungeonType, FirstFloorEnv, HipVecRogueEnv, ImageSetting, ParallelRogueEnv, PlayerState, RogueEnv, StairRewardEnv, StairRewardParallel,
+from .envs import (DungeonType, FirstFloorEnv, HipVecRogueEnv, HipVecStairReward, ImageSetting, ParallelRogueEnv, PlayerState, RogueEnv, StairRewardEnv, StairRewardParallel,
                    StatusFlag)
 from . import envs  # noqa: F401
 

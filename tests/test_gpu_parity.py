@@ -184,6 +184,7 @@ GEOMETRIES = [
     (160, 48, 4, 4),   # the reference's maximum screen (core/src/lib.rs:134-140): three mask words, 64-row BFS, 16 rooms
     (64, 16, 4, 1),    # a single row of rooms
     (32, 48, 1, 3),    # narrowest x tallest screen: a single column of rooms
+    (160, 48, 6, 5),   # 30 rooms (the stepper's limit is 32; the reference has none)
 ]
 
 

@@ -176,3 +176,26 @@ def test_hip_vec_env_tensor_path(goldens):
     for i in range(0, n, 37):
         assert np.array_equal(host[i], states[i].gray_image())
     venv.check_errors()
+
+
+def test_hip_vec_stair_reward_matches_parallel_wrapper(goldens):
+    """HipVecStairReward (device tensors) == StairRewardParallel (python/rogue_gym/envs/wrappers.py:45-64) on the DDQN key log, which
+    takes seed 5 down the stairs at step 19."""
+    import torch
+
+    e = _envs()
+    n = 64
+    cfgs = [dict(goldens["configs"]["ddqn"], seed=5 if i % 4 == 0 else 100 + i) for i in range(n)]
+    venv = e.HipVecStairReward(cfgs, max_steps=200, stair_reward=50.0)
+    penv = e.StairRewardParallel(cfgs, max_steps=200, stair_reward=50.0)
+    total = torch.zeros(n)
+    total_ref = [0.0] * n
+    for ch in goldens["ddqn_keys"][:120]:
+        keys = torch.full((n,), ord(ch), dtype=torch.uint8, device=venv.device)
+        _, rew, done = venv.step_keys(keys)
+        _, rewards, dones, _ = penv.step(ch * n)
+        assert rew.cpu().tolist() == [float(r) for r in rewards]
+        assert done.cpu().tolist() == dones
+        total += rew.cpu()
+        total_ref = [a + b for a, b in zip(total_ref, rewards)]
+    assert max(total_ref) >= 50.0  # the stair bonus was paid at least once
