@@ -994,64 +994,86 @@ __device__ __forceinline__ void bfs_rows(const RgState &S, const RgConfig &c, ui
     (void)grp_lane0;
 }
 
-// W <= 32 (the mini dungeon): a row is one 32-bit mask, the level step is ~25 scalar-width VALU ops + 2 DPP moves
-__device__ __forceinline__ void bfs_rows_w32(const RgState &S, const RgConfig &c, uint16_t *lds_dist, bool active, int env, int tx, int ty, int slot, int row,
-                                             int rows_pow2) {
-    const int W = c.width, H = c.height, HW = W * H;
+// W == 32 (the narrowest screen, the mini dungeon): a row is one 32-bit mask and the level step is ~25 VALU ops + 2 DPP moves.  Distances
+// are not written per newly reached cell (a per-lane loop over the new bits cost more than the level step itself): each row keeps the
+// distance of its 32 cells as BIT-PLANES (plane b = cells whose distance has bit b set).  Levels are taken 8 at a time, so the three low
+// planes are updated with compile-time knowledge of the level's low bits and the eight high planes once per block with the OR of the
+// block's new cells (distances < 2048 = every cell of a 32 x 64 grid).  At the end each lane expands its row to 32 u16 and stores its
+// 64 bytes straight into the env's DistCache slot -- no LDS staging.
+__device__ __forceinline__ void bfs_rows_w32(const RgState &S, const RgConfig &c, bool active, int env, int tx, int ty, int slot, int row) {
+    const int W = 32, H = c.height, HW = W * H;
     const uint16_t *cell = S.cell + (size_t)env * HW;
     const bool row_ok = active && row < H;
-    uint32_t wk = 0, vis = 0, fr = 0;
-    if (row_ok) {
-        const uint16_t *rowp = cell + row * W;
-        if ((W & 7) == 0) {
-            const uint4 *r4 = reinterpret_cast<const uint4 *>(rowp);
-            for (int j = 0; j < W / 8; j++) {
-                uint4 v = r4[j];
-                uint32_t q[4] = {v.x, v.y, v.z, v.w};
-                uint32_t bits = 0;
+    uint32_t wk = 0;
+    if (row_ok) {  // walkable mask of my row (Surface::can_walk, rogue/mod.rs:175-182)
+        const uint4 *r4 = reinterpret_cast<const uint4 *>(cell + row * W);
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    bits |= (uint32_t)can_walk(q[t] & 0xffff) << (2 * t);
-                    bits |= (uint32_t)can_walk(q[t] >> 16) << (2 * t + 1);
-                }
-                wk |= bits << (j * 8);
+        for (int j = 0; j < 4; j++) {
+            uint4 v = r4[j];
+            uint32_t q[4] = {v.x, v.y, v.z, v.w};
+            uint32_t bits = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                bits |= (uint32_t)can_walk(q[t] & 0xffff) << (2 * t);
+                bits |= (uint32_t)can_walk(q[t] >> 16) << (2 * t + 1);
             }
-        } else
-            for (int x = 0; x < W; x++) wk |= (uint32_t)can_walk(rowp[x]) << x;
+            wk |= bits << (j * 8);
+        }
     }
     const bool up_ok = row > 0, dn_ok = row + 1 < H;
     const uint32_t wu = up_ok ? wave_shr1(wk) : 0u, wd = dn_ok ? wave_shl1(wk) : 0u;
-    if (active) for (int i = row; i < HW; i += rows_pow2) lds_dist[i] = DIST_INF;
-    if (row_ok && row == ty) { fr = 1u << tx; vis = fr; }
-    __syncthreads();
-    if (row_ok && row == ty) lds_dist[ty * W + tx] = 0;
-    for (uint32_t level = 1; level < (uint32_t)HW; level++) {
-        uint32_t fu = wave_shr1(fr), fd = wave_shl1(fr);
-        fu = up_ok ? fu : 0u; fd = dn_ok ? fd : 0u;
-        const uint32_t au = fu & wk, ad = fd & wk;
-        const uint32_t tgt = (fr << 1) | (fr >> 1) | fu | fd | (((au << 1) | (au >> 1)) & wu) | (((ad << 1) | (ad >> 1)) & wd);
-        uint32_t nw = tgt & wk & ~vis;
-        vis |= nw;
-        fr = nw;
-        const bool any = nw != 0;
-        while (nw) {
-            int bit = __ffs((int)nw) - 1;
-            nw &= nw - 1;
-            lds_dist[row * W + bit] = (uint16_t)level;
+    uint32_t vis = 0, fr = 0;
+    uint32_t inject = (row_ok && row == ty) ? 1u << tx : 0u;  // level 0: the target cell itself, walkable or not
+    uint32_t p0 = 0, p1 = 0, p2 = 0, ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t blk = 0;
+    for (;; blk++) {  // levels 8 * blk .. 8 * blk + 7
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t fu = wave_shr1(fr), fd = wave_shl1(fr);
+            fu = up_ok ? fu : 0u; fd = dn_ok ? fd : 0u;
+            const uint32_t au = fu & wk, ad = fd & wk;
+            // Left/Right | Down/Up | diagonals: source (x-+1, y-+1) needs walk(x, y-+1) and walk(x-+1, y)
+            const uint32_t tgt = (fr << 1) | (fr >> 1) | fu | fd | (((au << 1) | (au >> 1)) & wu) | (((ad << 1) | (ad >> 1)) & wd);
+            const uint32_t nw = (tgt & wk & ~vis) | inject;
+            inject = 0;
+            vis |= nw;
+            fr = nw;
+            if (j & 1) p0 |= nw;
+            if (j & 2) p1 |= nw;
+            if (j & 4) p2 |= nw;
+            acc |= nw;
         }
-        if (!__any(any)) break;
+#pragma unroll
+        for (int b = 0; b < 8; b++)
+            if ((blk >> b) & 1u) ph[b] |= acc;  // wave-uniform condition
+        if (!__any(fr != 0) || blk == 255u) break;
     }
-    __syncthreads();
-    if (active) {
-        uint16_t *out = S.dc_map + ((size_t)env * RG_DIST_SLOTS + slot) * HW;
-        if ((HW & 7) == 0) {
-            uint4 *o4 = reinterpret_cast<uint4 *>(out);
-            const uint4 *s4 = reinterpret_cast<const uint4 *>(lds_dist);
-            for (int i = row; i < HW / 8; i += rows_pow2) o4[i] = s4[i];
-        } else
-            for (int i = row; i < HW; i += rows_pow2) out[i] = lds_dist[i];
+    if (row_ok) {  // expand my row: cell x -> u16 distance, 0xFFFF where the cell was never reached
+        const int nhi = 32 - __clz((int)blk);  // high planes in use (wave-uniform)
+        const uint32_t unv = ~vis;
+        uint32_t out[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            uint32_t lo = 0, hi = 0;
+            const int x = 2 * j;
+            lo |= ((p0 >> x) & 1u) | (((p1 >> x) & 1u) << 1) | (((p2 >> x) & 1u) << 2);
+            hi |= ((p0 >> (x + 1)) & 1u) | (((p1 >> (x + 1)) & 1u) << 1) | (((p2 >> (x + 1)) & 1u) << 2);
+#pragma unroll
+            for (int b = 0; b < 8; b++)
+                if (b < nhi) {
+                    lo |= ((ph[b] >> x) & 1u) << (3 + b);
+                    hi |= ((ph[b] >> (x + 1)) & 1u) << (3 + b);
+                }
+            if ((unv >> x) & 1u) lo = 0xFFFFu;
+            if ((unv >> (x + 1)) & 1u) hi = 0xFFFFu;
+            out[j] = lo | (hi << 16);
+        }
+        uint4 *o4 = reinterpret_cast<uint4 *>(S.dc_map + ((size_t)env * RG_DIST_SLOTS + slot) * HW + row * W);
+#pragma unroll
+        for (int j = 0; j < 4; j++) o4[j] = make_uint4(out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]);
     }
-    __syncthreads();
+    __syncthreads();  // the requesting lanes read their maps right after (monsters_move): the stores of the other lanes must have landed
 }
 
 // serve every lane of `need` (ballot mask): G requests per round
@@ -1071,7 +1093,7 @@ __device__ __forceinline__ void bfs_service(const RgState &S, const RgConfig &c,
         const int s = active ? src : 0;
         int env_s = __shfl(e, s), tx = __shfl(px, s), ty = __shfl(py, s), sl = __shfl(map_slot, s);
         uint16_t *ld = lds + (size_t)grp * HW;
-        if (c.width <= 32) bfs_rows_w32(S, c, ld, active, env_s, tx, ty, sl, row, rows_pow2);
+        if (c.width <= 32) bfs_rows_w32(S, c, active, env_s, tx, ty, sl, row);
         else if (c.width <= 64) bfs_rows<1, false>(S, c, ld, active, env_s, tx, ty, sl, row, grp * rows_pow2, rows_pow2);
         else if (c.width <= 128) bfs_rows<2, false>(S, c, ld, active, env_s, tx, ty, sl, row, grp * rows_pow2, rows_pow2);
         else bfs_rows<3, false>(S, c, ld, active, env_s, tx, ty, sl, row, grp * rows_pow2, rows_pow2);
