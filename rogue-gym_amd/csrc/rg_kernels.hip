@@ -907,16 +907,22 @@ template <int WW, bool NARROW, bool UP> __device__ __forceinline__ RowBits<WW> r
     return r;
 }
 
-// one round: group g of the wave computes the dist map of request (env, tx, ty, slot) given per lane (uniform per group)
+// one round: group g of the wave computes the dist map of request (env, tx, ty, slot) given per lane (uniform per group).
+// Distances are kept as bit-planes per row (plane b = the cells whose distance has bit b set): writing a u16 per newly reached cell inside
+// the level loop (a per-lane loop over the new bits) cost several times the level step itself.  Levels are taken 8 at a time: the three low
+// planes are updated with compile-time knowledge of the level's low bits, the ten high planes once per block with the OR of the block's
+// new cells (distances < 8192 >= every cell of the largest grid).  At the end every lane expands its row and stores it straight into the env's
+// DistCache slot.
 template <int WW, bool NARROW>
-__device__ __forceinline__ void bfs_rows(const RgState &S, const RgConfig &c, uint16_t *lds_dist /* this group's HW u16 */, bool active, int env, int tx, int ty,
-                                         int slot, int row, int grp_lane0, int rows_pow2) {
-    const int W = c.width, H = c.height, HW = W * H;
+__device__ __forceinline__ void bfs_rows(const RgState &S, const RgConfig &c, uint64_t *lds_hi /* [10][WW][64] high planes */, bool active, int env, int tx, int ty,
+                                         int slot, int row) {
+    const int W = c.width, H = c.height, HW = W * H, lane = threadIdx.x;
     const uint16_t *cell = S.cell + (size_t)env * HW;
     const bool row_ok = active && row < H;
-    RowBits<WW> wk, vis, fr;
+    RowBits<WW> wk, vis, fr, inject, p0, p1, p2;  // the ten high planes live in LDS (60 registers for the widest grid otherwise: the step kernel
+                                                  // must stay small enough for a k_regen wave to share its SIMD)
 #pragma unroll
-    for (int k = 0; k < WW; k++) wk.w[k] = vis.w[k] = fr.w[k] = 0ull;
+    for (int k = 0; k < WW; k++) wk.w[k] = vis.w[k] = fr.w[k] = inject.w[k] = p0.w[k] = p1.w[k] = p2.w[k] = 0ull;
     if (row_ok) {  // walkable mask of my row (Surface::can_walk, rogue/mod.rs:175-182)
         const uint16_t *rowp = cell + row * W;
         if ((W & 7) == 0) {
@@ -937,61 +943,102 @@ __device__ __forceinline__ void bfs_rows(const RgState &S, const RgConfig &c, ui
             }
         } else {
             for (int x = 0; x < W; x++) {
-                uint64_t b = (uint64_t)can_walk(rowp[x]) << (x & 63);
+                uint64_t bb = (uint64_t)can_walk(rowp[x]) << (x & 63);
 #pragma unroll
                 for (int k = 0; k < WW; k++)
-                    if ((x >> 6) == k) wk.w[k] |= b;
+                    if ((x >> 6) == k) wk.w[k] |= bb;
             }
         }
     }
     const bool up_ok = row > 0, dn_ok = row + 1 < H;
     const RowBits<WW> wu = rb_neighbour<WW, NARROW, true>(wk, up_ok);    // walkable mask of row y-1
     const RowBits<WW> wd = rb_neighbour<WW, NARROW, false>(wk, dn_ok);   // and of row y+1
-    if (active) for (int i = row; i < HW; i += rows_pow2) lds_dist[i] = DIST_INF;
-    if (row_ok && row == ty) {
+    if (row_ok && row == ty) {  // level 0: the target cell itself, walkable or not
 #pragma unroll
         for (int k = 0; k < WW; k++)
-            if ((tx >> 6) == k) { fr.w[k] = 1ull << (tx & 63); vis.w[k] = fr.w[k]; }
+            if ((tx >> 6) == k) inject.w[k] = 1ull << (tx & 63);
     }
-    __syncthreads();
-    if (row_ok && row == ty) lds_dist[ty * W + tx] = 0;
-    for (uint32_t level = 1; level < (uint32_t)HW; level++) {
-        const RowBits<WW> fu = rb_neighbour<WW, NARROW, true>(fr, up_ok);
-        const RowBits<WW> fd = rb_neighbour<WW, NARROW, false>(fr, dn_ok);
-        RowBits<WW> au, ad;  // neighbour-row frontier restricted to cells whose vertical step lands on a walkable cell of my row
+    uint32_t blk = 0;
+    for (;; blk++) {  // levels 8 * blk .. 8 * blk + 7
+        RowBits<WW> acc;
 #pragma unroll
-        for (int k = 0; k < WW; k++) { au.w[k] = fu.w[k] & wk.w[k]; ad.w[k] = fd.w[k] & wk.w[k]; }
-        const RowBits<WW> sl = rb_shl1<WW>(fr), sr = rb_shr1<WW>(fr);
-        const RowBits<WW> aul = rb_shl1<WW>(au), aur = rb_shr1<WW>(au), adl = rb_shl1<WW>(ad), adr = rb_shr1<WW>(ad);
-        bool any = false;
+        for (int k = 0; k < WW; k++) acc.w[k] = 0ull;
 #pragma unroll
-        for (int k = 0; k < WW; k++) {
-            // Left/Right | Down/Up | diagonals: source (x-+1, y-+1) needs walk(x, y-+1) and walk(x-+1, y)
-            uint64_t tgt = sl.w[k] | sr.w[k] | fu.w[k] | fd.w[k] | ((aul.w[k] | aur.w[k]) & wu.w[k]) | ((adl.w[k] | adr.w[k]) & wd.w[k]);
-            uint64_t nw = tgt & wk.w[k] & ~vis.w[k];
-            vis.w[k] |= nw;
-            fr.w[k] = nw;
-            any = any || nw != 0;
-            while (nw) {
-                int bit = __ffsll((long long)nw) - 1;
-                nw &= nw - 1;
-                lds_dist[row * W + k * 64 + bit] = (uint16_t)level;
+        for (int j = 0; j < 8; j++) {
+            const RowBits<WW> fu = rb_neighbour<WW, NARROW, true>(fr, up_ok);
+            const RowBits<WW> fd = rb_neighbour<WW, NARROW, false>(fr, dn_ok);
+            RowBits<WW> au, ad;  // neighbour-row frontier restricted to cells whose vertical step lands on a walkable cell of my row
+#pragma unroll
+            for (int k = 0; k < WW; k++) { au.w[k] = fu.w[k] & wk.w[k]; ad.w[k] = fd.w[k] & wk.w[k]; }
+            const RowBits<WW> sl = rb_shl1<WW>(fr), sr = rb_shr1<WW>(fr);
+            const RowBits<WW> aul = rb_shl1<WW>(au), aur = rb_shr1<WW>(au), adl = rb_shl1<WW>(ad), adr = rb_shr1<WW>(ad);
+#pragma unroll
+            for (int k = 0; k < WW; k++) {
+                // Left/Right | Down/Up | diagonals: source (x-+1, y-+1) needs walk(x, y-+1) and walk(x-+1, y)
+                const uint64_t tgt = sl.w[k] | sr.w[k] | fu.w[k] | fd.w[k] | ((aul.w[k] | aur.w[k]) & wu.w[k]) | ((adl.w[k] | adr.w[k]) & wd.w[k]);
+                const uint64_t nw = (tgt & wk.w[k] & ~vis.w[k]) | inject.w[k];
+                inject.w[k] = 0ull;
+                vis.w[k] |= nw;
+                fr.w[k] = nw;
+                if (j & 1) p0.w[k] |= nw;
+                if (j & 2) p1.w[k] |= nw;
+                if (j & 4) p2.w[k] |= nw;
+                acc.w[k] |= nw;
             }
         }
-        if (!__any(any)) break;
+#pragma unroll
+        for (int b = 0; b < 10; b++)
+            if ((blk >> b) & 1u) {  // wave-uniform condition; the first block with bit b set (blk == 1 << b) initialises the plane
+#pragma unroll
+                for (int k = 0; k < WW; k++) {
+                    uint64_t *q = &lds_hi[(b * WW + k) * WAVE + lane];
+                    *q = blk == (1u << b) ? acc.w[k] : (*q | acc.w[k]);
+                }
+            }
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < WW; k++) any = any || fr.w[k] != 0ull;
+        if (!__any(any) || blk == 1023u) break;
     }
-    __syncthreads();
-    if (active) {
-        uint16_t *out = S.dc_map + ((size_t)env * RG_DIST_SLOTS + slot) * HW;
-        if ((HW & 7) == 0) {
-            uint4 *o4 = reinterpret_cast<uint4 *>(out);
-            const uint4 *s4 = reinterpret_cast<const uint4 *>(lds_dist);
-            for (int i = row; i < HW / 8; i += rows_pow2) o4[i] = s4[i];
-        } else
-            for (int i = row; i < HW; i += rows_pow2) out[i] = lds_dist[i];
+    if (row_ok) {  // expand my row: cell x -> u16 distance, 0xFFFF where the cell was never reached
+        const int nhi = 32 - __clz((int)blk);  // high planes in use (wave-uniform)
+        uint16_t *out = S.dc_map + ((size_t)env * RG_DIST_SLOTS + slot) * HW + row * W;
+        const bool vec = (W & 7) == 0;
+#pragma unroll
+        for (int k = 0; k < WW; k++) {
+            const int xw = k * 64;
+            if (xw >= W) break;
+            uint64_t hp[10];  // this word's high planes back from LDS, once
+#pragma unroll
+            for (int b = 0; b < 10; b++) hp[b] = b < nhi ? lds_hi[(b * WW + k) * WAVE + lane] : 0ull;
+            for (int g8 = 0; g8 < 8 && xw + g8 * 8 < W; g8++) {  // 8 cells = one 16-byte store
+                uint32_t d[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int sh = g8 * 8 + 2 * q;
+                    const uint32_t a0 = (uint32_t)(p0.w[k] >> sh), a1 = (uint32_t)(p1.w[k] >> sh), a2 = (uint32_t)(p2.w[k] >> sh);
+                    uint32_t lo = (a0 & 1u) | ((a1 & 1u) << 1) | ((a2 & 1u) << 2);
+                    uint32_t hi = ((a0 >> 1) & 1u) | (((a1 >> 1) & 1u) << 1) | (((a2 >> 1) & 1u) << 2);
+#pragma unroll
+                    for (int b = 0; b < 10; b++)
+                        if (b < nhi) {
+                            const uint32_t ab = (uint32_t)(hp[b] >> sh);
+                            lo |= (ab & 1u) << (3 + b);
+                            hi |= ((ab >> 1) & 1u) << (3 + b);
+                        }
+                    const uint32_t un = ~(uint32_t)(vis.w[k] >> sh);
+                    if (un & 1u) lo = 0xFFFFu;
+                    if (un & 2u) hi = 0xFFFFu;
+                    d[q] = lo | (hi << 16);
+                }
+                const int x = xw + g8 * 8;
+                if (vec) *reinterpret_cast<uint4 *>(out + x) = make_uint4(d[0], d[1], d[2], d[3]);
+                else
+                    for (int t = 0; t < 8 && x + t < W; t++) out[x + t] = (uint16_t)(d[t >> 1] >> ((t & 1) * 16));
+            }
+        }
     }
-    __syncthreads();
-    (void)grp_lane0;
+    __syncthreads();  // the requesting lanes read their maps right after (monsters_move): the stores of the other lanes must have landed
 }
 
 // W == 32 (the narrowest screen, the mini dungeon): a row is one 32-bit mask and the level step is ~25 VALU ops + 2 DPP moves.  Distances
@@ -1076,9 +1123,12 @@ __device__ __forceinline__ void bfs_rows_w32(const RgState &S, const RgConfig &c
     __syncthreads();  // the requesting lanes read their maps right after (monsters_move): the stores of the other lanes must have landed
 }
 
-// serve every lane of `need` (ballot mask): G requests per round
-__device__ __forceinline__ void bfs_service(const RgState &S, const RgConfig &c, uint16_t *lds, uint64_t need, int e, int px, int py, int map_slot, int lane) {
-    const int H = c.height, HW = c.width * H;
+// serve every lane of `need` (ballot mask): G requests per round.  BW = width class of the grid (0: W = 32, else 64-bit words per row): the
+// step kernel is instantiated per class, so a narrow grid does not pay the register footprint of the wide-row BFS (above 384 registers a
+// k_regen wave no longer fits beside a step wave on the SIMD).
+template <int BW>
+__device__ __forceinline__ void bfs_service(const RgState &S, const RgConfig &c, uint64_t *lds, uint64_t need, int e, int px, int py, int map_slot, int lane) {
+    const int H = c.height;
     const int rows_pow2 = H <= 16 ? 16 : (H <= 32 ? 32 : 64);
     const int G = WAVE / rows_pow2;
     const int grp = lane / rows_pow2, row = lane - grp * rows_pow2;
@@ -1092,11 +1142,8 @@ __device__ __forceinline__ void bfs_service(const RgState &S, const RgConfig &c,
         const bool active = src >= 0;
         const int s = active ? src : 0;
         int env_s = __shfl(e, s), tx = __shfl(px, s), ty = __shfl(py, s), sl = __shfl(map_slot, s);
-        uint16_t *ld = lds + (size_t)grp * HW;
-        if (c.width <= 32) bfs_rows_w32(S, c, active, env_s, tx, ty, sl, row);
-        else if (c.width <= 64) bfs_rows<1, false>(S, c, ld, active, env_s, tx, ty, sl, row, grp * rows_pow2, rows_pow2);
-        else if (c.width <= 128) bfs_rows<2, false>(S, c, ld, active, env_s, tx, ty, sl, row, grp * rows_pow2, rows_pow2);
-        else bfs_rows<3, false>(S, c, ld, active, env_s, tx, ty, sl, row, grp * rows_pow2, rows_pow2);
+        if constexpr (BW == 0) bfs_rows_w32(S, c, active, env_s, tx, ty, sl, row);
+        else bfs_rows<BW, false>(S, c, lds, active, env_s, tx, ty, sl, row);
     }
 }
 
@@ -1550,6 +1597,7 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
 // ---------------------------------------------------------------------------------------------
 // k_step: one key for every env
 // ---------------------------------------------------------------------------------------------
+template <int BW>
 __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c, const uint8_t *__restrict__ keys, uint32_t *__restrict__ err_any, int use_spares,
                                                int mc_offset, int epw) {
     __builtin_amdgcn_s_setprio(3);  // issue-bound kernel: win VALU arbitration against the co-resident background k_regen waves
@@ -1682,7 +1730,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
             uint64_t m = __ballot(need_bfs);
             if (m) {  // serve the requesting lanes with the whole wave, several maps per round
                 unsigned long long tb0 = pf.p ? __builtin_amdgcn_s_memtime() : 0;
-                bfs_service(S, c, lds_grid, m, e, E.px, E.py, map_slot, lane);
+                bfs_service<BW>(S, c, reinterpret_cast<uint64_t *>(lds_grid), m, e, E.px, E.py, map_slot, lane);
                 if (pf.p) { pf.rec(24, __builtin_amdgcn_s_memtime() - tb0); pf.rec(25, (unsigned long long)__popcll(m)); }
             }
             pf.mark(4);
@@ -1734,10 +1782,6 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
 // host-callable launchers (used by rg_api.cpp)
 // ---------------------------------------------------------------------------------------------
 extern "C" {
-static size_t bfs_bytes(const RgConfig *c) {
-    int rows = c->height <= 16 ? 16 : (c->height <= 32 ? 32 : 64);
-    return (size_t)(WAVE / rows) * c->width * c->height * 2;
-}
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw);  // one level at a time per wave: one staging grid + the generator's tables
@@ -1745,8 +1789,9 @@ void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
 }
 void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, int use_spares, hipStream_t st) {
     int hw = c->width * c->height;
-    size_t smem = GEN_SLOT_BYTES(hw);
-    if (bfs_bytes(c) > smem) smem = bfs_bytes(c);
+    size_t smem = GEN_SLOT_BYTES(hw);  // the generator's staging grid + tables (inline descents, spare misses), shared with ...
+    const size_t bfs_hi = c->width <= 32 ? 0 : (size_t)10 * ((c->width + 63) / 64) * WAVE * 8;  // ... the BFS high distance planes
+    if (bfs_hi > smem) smem = bfs_hi;
     smem = (smem + 15) & ~(size_t)15;
     int mc_offset = (int)smem;
     smem += (size_t)c->room_num_x * c->room_num_y * WAVE * 4;  // LDS monster cache
@@ -1756,7 +1801,11 @@ void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint
     int epw = WAVE;
     while (epw > 16 && (S->n + epw - 1) / epw < 1024) epw >>= 1;
     if (epw_env == 16 || epw_env == 32 || epw_env == 64) epw = epw_env;
-    hipLaunchKernelGGL(k_step, dim3((S->n + epw - 1) / epw), dim3(WAVE), smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset, epw);
+    const dim3 grid((S->n + epw - 1) / epw), block(WAVE);
+    if (c->width <= 32) hipLaunchKernelGGL(k_step<0>, grid, block, smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset, epw);
+    else if (c->width <= 64) hipLaunchKernelGGL(k_step<1>, grid, block, smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset, epw);
+    else if (c->width <= 128) hipLaunchKernelGGL(k_step<2>, grid, block, smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset, epw);
+    else hipLaunchKernelGGL(k_step<3>, grid, block, smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset, epw);
 }
 void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;

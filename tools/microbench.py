@@ -77,10 +77,11 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
     keys = table[torch.randint(0, len(keys_table), (64, n), generator=gen, device=dev)].contiguous()
     for t in range(150):
         L.rg_step(h.h, C.c_void_p(keys[t % 64].data_ptr()), 1)
-    nw = (n + 63) // 64
+    nw = (n + 15) // 16  # rows: one per wave of the launch (16..64 envs per wave); unused rows stay zero
     buf = np.zeros(((n + 15) // 16, 64), np.uint64)  # rg_prof copies one row per 16 envs (the smallest envs-per-wave)
     L.rg_prof(h.h, 1, None)
     sums, maxs, totals, counts = {}, {}, [], {}
+    n_waves = 0
     L.rg_timing_enable(h.h, 1)
     for t in range(1 if do_reset else launches):
         if do_reset:
@@ -88,7 +89,8 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
         else:
             L.rg_step(h.h, C.c_void_p(keys[t % 64].data_ptr()), 1)
         L.rg_prof(h.h, 1, buf.ctypes.data_as(C.c_void_p))
-        buf_used = buf[:nw] if not do_reset else buf
+        buf_used = buf[buf[:, 63] > 0]
+        n_waves = max(n_waves, len(buf_used))
         k = buf_used[:, 0].astype(np.int64)
         totals.append(buf_used[:, 63].astype(np.float64))
         rec = buf_used[:, 1:62]
@@ -105,14 +107,14 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
     cnt = (C.c_uint64 * 4)()
     L.rg_timing_read(h.h, ms, cnt)
     nl = len(totals)
-    tot = np.stack(totals)
+    tot = np.concatenate(totals)
     kidx = 3 if do_reset else 0
     print("%s: kernel (HIP events) %.1f us; slowest wave avg %.1f us, mean wave %.1f us" %
-          (name, ms[kidx] / max(cnt[kidx], 1) * 1e3, tot.max(axis=1).mean() * TICK_US, tot.mean() * TICK_US))
+          (name, ms[kidx] / max(cnt[kidx], 1) * 1e3, np.mean([t.max() for t in totals]) * TICK_US, tot.mean() * TICK_US))
     names = GEN_PHASES if do_reset else PHASES
     for pid, nm in names.items():
         if pid in sums:
-            print("   %-18s avg/wave %7.2f us   max wave %7.2f us" % (nm, sums[pid] / nw / nl * TICK_US, maxs[pid] * TICK_US))
+            print("   %-18s avg/wave %7.2f us   max wave %7.2f us" % (nm, sums[pid] / max(n_waves, 1) / nl * TICK_US, maxs[pid] * TICK_US))
     if not do_reset:
         hist = np.histogram(tot * TICK_US, bins=np.arange(0, 260, 10))[0] / nl
         print("   wave-duration histogram (10 us buckets, waves per launch): " + " ".join("%.0f" % v for v in hist))
@@ -122,12 +124,16 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
                 print("   %-16s calls/launch %.1f  avg %.1f us" % (nm, counts[pid] / nl, sums[pid] / counts[pid] * TICK_US))
         if 25 in sums:
             print("   dist maps/launch %.1f" % (sums[25] / nl))
-        order = np.argsort(-buf[:, 63].astype(np.float64))[:3]
+        order = np.argsort(-buf[:, 63].astype(np.float64))[:3]  # rows of the last launch
         for wv in order:  # the slowest waves of the last launch, record by record
             kk = int(buf[wv, 0])
             recs = ["%s=%.1f" % (PHASES.get(int(r >> np.uint64(48)), str(int(r >> np.uint64(48)))), float(r & np.uint64((1 << 48) - 1)) * TICK_US) for r in buf[wv, 1:1 + kk]]
             print("   slow wave %d: total %.1f us: %s" % (wv, float(buf[wv, 63]) * TICK_US, " ".join(recs)))
     h.close()
+
+
+if __name__ == "__main__" and "profd" in sys.argv[1:]:
+    prof("k_step default 80x24 11-act, 32768 envs", G["configs"]["default"], b".hjklnbuy>s", n=32768)
 
 
 if __name__ == "__main__" and "prof" in sys.argv[1:]:
