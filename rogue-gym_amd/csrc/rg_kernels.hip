@@ -69,6 +69,16 @@ __device__ __forceinline__ uint64_t range64(Rng &r, uint64_t low, uint64_t high)
     }
 }
 __device__ __forceinline__ bool does_happen(Rng &r, uint32_t p_inv) { return range32(r, 0, p_inv) == 0; }
+// Reservoir choice among n <= 4 candidates taken in order: candidate i replaces the pick when does_happen(i + 1) (maze.rs:73, passages.rs:79).
+// Unrolled so that every range is a compile-time constant (zone and multiply fold away).  Returns the index of the pick (n >= 1).
+__device__ __forceinline__ int reservoir4(Rng &r, int n) {
+    int pick = 0;
+    (void)does_happen(r, 1);  // i = 0 always wins but still consumes its draws
+    if (n > 1 && does_happen(r, 2)) pick = 1;
+    if (n > 2 && does_happen(r, 3)) pick = 2;
+    if (n > 3 && does_happen(r, 4)) pick = 3;
+    return pick;
+}
 __device__ __forceinline__ bool parcent(Rng &r, uint32_t p) { return range32(r, 1, 101) <= p; }
 
 // Direction -> (dx, dy) as immediates (a __constant__ table indexed per lane is a memory load); same order as kDX / kDY
@@ -408,23 +418,26 @@ __device__ __forceinline__ void paint_corridor(const RgConfig &c, Env &E, uint32
     }
 }
 
-// select_candidate (passages.rs:69-82): reservoir over grid-neighbour rooms in ascending id
+// select_candidate (passages.rs:69-82): reservoir over the grid-neighbour rooms not in `excl_mask`, in ascending id = Up, Left, Right, Down
 __device__ __forceinline__ int select_candidate(const RgConfig &c, Env &E, int nrooms, int node, uint32_t excl_mask, int &dir_out) {
-    int rnx = c.room_num_x, rny = c.room_num_y;
-    int ny0 = small_div(node, rnx), nx0 = node - ny0 * rnx, res = -1, i = 0;
-    for (int id = 0, ox = 0, oy = 0; id < nrooms; id++, ox++) {
-        if (ox == rnx) { ox = 0; oy++; }
-        if ((excl_mask >> id) & 1) continue;
-        int d;
-        if (ox == nx0 && oy == ny0 - 1) d = 0;
-        else if (ox == nx0 && oy == ny0 + 1) d = 1;
-        else if (oy == ny0 && ox == nx0 - 1) d = 2;
-        else if (oy == ny0 && ox == nx0 + 1) d = 3;
-        else continue;
-        (void)rny;
-        if (does_happen(E.rd, (uint32_t)i + 1)) { res = id; dir_out = d; }
-        i++;
-    }
+    const int rnx = c.room_num_x, rny = c.room_num_y;
+    const int ny0 = small_div(node, rnx), nx0 = node - ny0 * rnx;
+    // candidate slots in ascending room id; direction codes 0 Up 1 Down 2 Left 3 Right
+    const int ids[4] = {node - rnx, node - 1, node + 1, node + rnx};
+    const bool ok[4] = {ny0 > 0, nx0 > 0, nx0 + 1 < rnx, ny0 + 1 < rny};
+    const int dirs[4] = {0, 2, 3, 1};
+    uint32_t cand = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (ok[k] && !((excl_mask >> ids[k]) & 1u)) cand |= 1u << k;
+    if (!cand) return -1;
+    const int k = nth_bit(cand, reservoir4(E.rd, __popc(cand)));
+    int res = ids[0];
+    dir_out = dirs[0];
+#pragma unroll
+    for (int t = 1; t < 4; t++)
+        if (k == t) { res = ids[t]; dir_out = dirs[t]; }
+    (void)nrooms;
     return res;
 }
 
@@ -454,6 +467,7 @@ __device__ __forceinline__ void dig_maze(const RgState &S, const RgConfig &c, En
     const uint16_t dug = (uint16_t)(S_NONE | C_MAZE);  // the room's area is untouched (fresh Field) until its maze is painted
     E.lc[y0 * W + x0] = dug;
     uint64_t seen = 1ull;
+    int stk_v = 0;
     int cx = x0, cy = y0, sp = 1;  // sp counts the current cell as the reference's recursion depth does
     for (;;) {
         uint32_t cand = 0;
@@ -469,15 +483,11 @@ __device__ __forceinline__ void dig_maze(const RgState &S, const RgConfig &c, En
             const bool ok = threadIdx.x < 4 && !(nx < x0 || nx >= x1 || ny < y0 || ny >= y1) && !(E.lc[ny * W + nx] & C_MAZE);
             cand = (uint32_t)__ballot(ok) & 0xfu;
         }
-        int dig = -1, i = 0;
-        for (int d = 0; d < 4; d++) {
-            if (!((cand >> d) & 1u)) continue;
-            if (does_happen(E.rd, (uint32_t)i + 1)) dig = d;
-            i++;
-        }
+        int dig = -1;
+        if (cand) dig = nth_bit(cand, reservoir4(E.rd, __popc(cand)));  // candidates in direction order Up, Down, Left, Right
         if (dig < 0) {  // dead end: back to the parent
             if (--sp == 0) break;
-            const uint32_t top = uni(in_lds ? ls[sp - 1] : gs[sp - 1]);
+            const uint32_t top = bitmap ? (uint32_t)__builtin_amdgcn_readlane(stk_v, sp - 1) : uni(in_lds ? ls[sp - 1] : gs[sp - 1]);
             cx = POS_X(top); cy = POS_Y(top);
             continue;
         }
@@ -487,7 +497,9 @@ __device__ __forceinline__ void dig_maze(const RgState &S, const RgConfig &c, En
         if (bitmap) seen |= 1ull << ((((cy + 2 * ddy) - y0) >> 1) * mw + (((cx + 2 * ddx) - x0) >> 1));
         if (sp < RG_MAZE_STACK) {  // descend: the current cell goes on the stack
             const uint16_t cur = (uint16_t)POS(cx, cy);
-            if (in_lds) ls[sp - 1] = cur; else gs[sp - 1] = cur;
+            if (bitmap) stk_v = (int)threadIdx.x == sp - 1 ? (int)cur : stk_v;  // <= 64 nodes: the stack is one VGPR, entry i in lane i
+            else if (in_lds) ls[sp - 1] = cur;
+            else gs[sp - 1] = cur;
             sp++;
             cx += 2 * ddx; cy += 2 * ddy;
         }
