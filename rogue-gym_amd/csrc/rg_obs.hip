@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RgState S, RgConfig c
             for (int i = tid; i < HW / 4; i += RENDER_THREADS) d4[i] = s4[i];
         } else
             for (int i = tid; i < HW; i += RENDER_THREADS) scr[i] = s_scr[i];
-        if (tid == 0) S.flags[e] = fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE);
+        if (tid == 0) S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG)) | ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u);
         __syncthreads();
     }
     (void)s_cell_at;
@@ -348,7 +348,9 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                 }
             }
             if (KIND == 1 && bad) { atomicOr(&S.flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
-            if (redraw && lt == 0) S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE)) | (KIND == 1 && bad ? RG_FLAG_ERR_TILE : 0);
+            if (redraw && lt == 0)  // a stale Redraw leaves the history mirror one level behind (k_step refreshes it before the next descent)
+                S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG)) | ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u) |
+                             (KIND == 1 && bad ? RG_FLAG_ERR_TILE : 0);
         }
     }
 }
