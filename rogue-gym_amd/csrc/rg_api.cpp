@@ -15,9 +15,8 @@
 
 extern "C" {
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st);
-void rgk_step(const RgState *S, const RgState *SP, const RgState *SN, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, int use_spares, int use_next,
-              hipStream_t st);
-void rgk_regen(const RgState *S, const RgState *SP, const RgState *SN, const RgConfig *c, int use_next, hipStream_t st);
+void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, int use_spares, hipStream_t st);
+void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st);
 void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st);
 void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, int symbols,
                 uint32_t sflag, int with_hist, int kind, float *out, hipStream_t st);
@@ -29,8 +28,6 @@ struct rg_handle {
     RgConfig cfg;
     RgState S;
     RgState SP;                  // spare view: core pointers address the pre-generated next level-1 state (k_regen)
-    RgState SN;                  // speculation view: the pre-generated NEXT LEVEL of envs standing on the stairs (k_regen)
-    bool spec = false;
     bool spares = false;
     uint64_t step_count = 0;
     hipStream_t side = nullptr;  // stream of the background generator (high priority: a low-priority queue starves behind the back-to-back step kernels)
@@ -170,9 +167,8 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
               dev_alloc(h, &S.dc_map, h->cfg.n_enemies > 0 ? n * RG_DIST_SLOTS * hw : 16) && dev_alloc(h, &S.dc_key, RG_DIST_SLOTS * n) &&
               dev_alloc(h, &S.dc_head, n) && dev_alloc(h, &S.dc_len, n) && dev_alloc(h, &S.status, n * 10) &&
               dev_alloc(h, &h->d_err, 4) && dev_alloc(h, &h->d_keys, n);
-    ok = ok && dev_alloc(h, &S.sp_ready, n) && dev_alloc(h, &S.sn_req, n) && dev_alloc(h, &S.sn_ready, n) && dev_alloc(h, &S.sn_tag, 13 * n);
+    ok = ok && dev_alloc(h, &S.sp_ready, n);
     h->SP = S;
-    h->SN = S;
     h->spares = auto_reset != 0 && getenv("ROGUE_GYM_HIP_NO_SPARES") == nullptr;
     if (ok && h->spares) {
         RgState &P = h->SP;
@@ -183,17 +179,6 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
              dev_alloc(h, &P.mon_cnt, n) && dev_alloc(h, &P.gold_pos, RG_MAX_ROOMS * n) && dev_alloc(h, &P.gold_amt, RG_MAX_ROOMS * n) &&
              dev_alloc(h, &P.edge_a, RG_MAX_EDGES * n) && dev_alloc(h, &P.edge_b, RG_MAX_EDGES * n) && dev_alloc(h, &P.maze_stack, RG_MAZE_STACK * n);
         P.prof = nullptr;
-        h->spec = getenv("ROGUE_GYM_HIP_NO_SPEC") == nullptr;
-        if (ok && h->spec) {  // next-level speculation: only what Dungeon::new_level + the player placement produce
-            RgState &N = h->SN;
-            ok = dev_alloc(h, &N.cell, n * hw) && dev_alloc(h, &N.p_pos, n) && dev_alloc(h, &N.dlevel, n) && dev_alloc(h, &N.rng, 12 * n) &&
-                 dev_alloc(h, &N.room_rect, RG_MAX_ROOMS * n) && dev_alloc(h, &N.room_meta, RG_MAX_ROOMS * n) &&
-                 dev_alloc(h, &N.mon_w0, RG_MAX_ROOMS * n) && dev_alloc(h, &N.mon_hp, RG_MAX_ROOMS * n) && dev_alloc(h, &N.mon_exp, RG_MAX_ROOMS * n) &&
-                 dev_alloc(h, &N.mon_cnt, n) && dev_alloc(h, &N.gold_pos, RG_MAX_ROOMS * n) && dev_alloc(h, &N.gold_amt, RG_MAX_ROOMS * n);
-            N.maze_stack = P.maze_stack;  // a k_regen wave serves its envs' two kinds of request one after the other
-            N.edge_a = P.edge_a; N.edge_b = P.edge_b;
-            N.prof = nullptr;
-        }
         int lo = 0, hi = 0;
         if (ok && (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, getenv("ROGUE_GYM_HIP_SIDE_LOWPRIO") ? lo : hi) != hipSuccess ||
                    hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_regen, hipEventDisableTiming) != hipSuccess)) {
@@ -210,7 +195,7 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
     if (e != hipSuccess) { g_create_err = std::string("k_build: ") + hipGetErrorString(e); free_all(h); delete h; return 1; }
     h->render_pending = true;
     if (h->spares) {  // first spares: generated in the background right away
-        rgk_regen(&h->S, &h->SP, &h->SN, &h->cfg, h->spec ? 1 : 0, h->side);
+        rgk_regen(&h->SP, &h->cfg, h->side);
         (void)hipEventRecord(h->ev_regen, h->side);
     }
     *out = h;
@@ -279,7 +264,7 @@ int rg_step(rg_t *h, const uint8_t *keys, int keys_on_device) {
         HIPCHK(h, hipMemcpyAsync(h->d_keys, keys, (size_t)h->S.n, hipMemcpyHostToDevice, h->stream));
         dk = h->d_keys;
     }
-    { TimedLaunch t(h, 0); rgk_step(&h->S, &h->SP, &h->SN, &h->cfg, dk, h->d_err, h->spares ? 1 : 0, h->spec ? 1 : 0, h->stream); }
+    { TimedLaunch t(h, 0); rgk_step(&h->S, &h->SP, &h->cfg, dk, h->d_err, h->spares ? 1 : 0, h->stream); }
     HIPCHK(h, hipGetLastError());
     static int regen_every = getenv("ROGUE_GYM_HIP_REGEN_EVERY") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_EVERY")) : 1;
     if (h->spares && (++h->step_count % (uint64_t)(regen_every < 1 ? 1 : regen_every)) == 0) {
@@ -287,7 +272,7 @@ int rg_step(rg_t *h, const uint8_t *keys, int keys_on_device) {
         // the GPU, so polling an event here would be meaningless); a launch that finds nothing to do costs ~10 us, concurrently.
         HIPCHK(h, hipEventRecord(h->ev_step, h->stream));
         HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_step, 0));
-        rgk_regen(&h->S, &h->SP, &h->SN, &h->cfg, h->spec ? 1 : 0, h->side);
+        rgk_regen(&h->SP, &h->cfg, h->side);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipEventRecord(h->ev_regen, h->side));
     }

@@ -858,54 +858,22 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
 // one generation per consumed spare, overlapped with the following steps; k_step's reset then is a copy.
 // SP is an RgState whose core pointers address the spare arrays.  Hand-off per env through sp_ready with
 // agent-scope release/acquire (the consumer kernel runs concurrently on another stream).
-__global__ void __launch_bounds__(WAVE) k_regen(RgState S, RgState SP, RgState SN, RgConfig c, int use_next) {
+__global__ void __launch_bounds__(WAVE) k_regen(RgState SP, RgConfig c) {
     const int lane = threadIdx.x;
     const int e = blockIdx.x * WAVE + lane;
     const bool valid = e < SP.n;
-    bool claim = false, want_next = false;
+    bool claim = false;
     if (valid && __hip_atomic_load(&SP.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
         claim = atomicCAS(&SP.sp_ready[e], 0u, 2u) == 0u;
-    if (valid && use_next && __hip_atomic_load(&S.sn_req[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) {
-        __hip_atomic_store(&S.sn_req[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t cur = __hip_atomic_load(&S.sn_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur <= 1u) want_next = atomicCAS(&S.sn_ready[e], cur, 2u) == cur;  // not while the step kernel is copying it (3) or another launch writes it (2)
-    }
-    if (!__any(claim || want_next)) return;
-    Prof pf; pf.start(nullptr);
+    if (!__any(claim)) return;
     Env E;
     E.e = valid ? e : 0; E.n = SP.n; E.cell = E.gcell = SP.cell + (size_t)E.e * SP.hw;
-    if (__any(claim)) {  // the next level-1 state of envs whose spare was consumed (auto-reset)
-        gen_service(SP, c, E, lane, e, claim, true, reinterpret_cast<uint16_t *>(g_smem), pf);
-        if (claim) store_env(SP, E);
-    }
-    uint32_t tag[13];
-    if (__any(want_next)) {  // the next level of envs standing on the stairs: Dungeon::new_level from the env's current RNG states / level.
-        // The live state may be rewritten by the concurrent step kernel while it is read here; a torn read only yields a tag that never matches.
-        const int n = S.n;
-        if (want_next) {
-#pragma unroll
-            for (int k = 0; k < 12; k++) tag[k] = S.rng[k * n + e];
-            tag[12] = S.dlevel[e];
-            E.rd = {tag[0], tag[1], tag[2], tag[3]}; E.ri = {tag[4], tag[5], tag[6], tag[7]}; E.re = {tag[8], tag[9], tag[10], tag[11]};
-            E.dlevel = tag[12];
-            E.px = E.py = 0; E.mon_alive = E.mon_active = 0;
-        }
-        gen_service(SN, c, E, lane, e, want_next, false, reinterpret_cast<uint16_t *>(g_smem), pf);
-        if (want_next) {
-            SN.rng[0 * n + e] = E.rd.x; SN.rng[1 * n + e] = E.rd.y; SN.rng[2 * n + e] = E.rd.z; SN.rng[3 * n + e] = E.rd.w;
-            SN.rng[4 * n + e] = E.ri.x; SN.rng[5 * n + e] = E.ri.y; SN.rng[6 * n + e] = E.ri.z; SN.rng[7 * n + e] = E.ri.w;
-            SN.rng[8 * n + e] = E.re.x; SN.rng[9 * n + e] = E.re.y; SN.rng[10 * n + e] = E.re.z; SN.rng[11 * n + e] = E.re.w;
-            SN.p_pos[e] = (uint16_t)POS(E.px, E.py);
-            SN.dlevel[e] = E.dlevel;
-            SN.mon_cnt[e] = E.mon_alive | (E.mon_active << 8);
-#pragma unroll
-            for (int k = 0; k < 13; k++) S.sn_tag[k * n + e] = tag[k];
-        }
-    }
+    Prof pf; pf.start(nullptr);
+    gen_service(SP, c, E, lane, e, claim, true, reinterpret_cast<uint16_t *>(g_smem), pf);
+    if (claim) store_env(SP, E);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (claim) __hip_atomic_store(&SP.sp_ready[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (want_next) __hip_atomic_store(&S.sn_ready[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1642,8 +1610,8 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
 // k_step: one key for every env
 // ---------------------------------------------------------------------------------------------
 template <int BW>
-__global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgState SN, RgConfig c, const uint8_t *__restrict__ keys, uint32_t *__restrict__ err_any, int use_spares,
-                                               int mc_offset, int epw, int use_next) {
+__global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c, const uint8_t *__restrict__ keys, uint32_t *__restrict__ err_any, int use_spares,
+                                               int mc_offset, int epw) {
     __builtin_amdgcn_s_setprio(3);  // issue-bound kernel: win VALU arbitration against the co-resident background k_regen waves
     uint16_t *lds_grid = reinterpret_cast<uint16_t *>(g_smem);
     const int lane = threadIdx.x;
@@ -1701,46 +1669,22 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgState SN
     for (int pass = 0; pass < 2; ++pass) {
         // pass 0: levels for descending lanes; pass 1: rebuilds for terminal lanes (ThreadConductor auto-reset)
         pf.mark(1);
-        // take the pre-generated level when it is ready (k_regen) -- pass 1: the spare level-1 state of a terminal env; pass 0: the speculated
-        // next level of a descending env, valid only if it was generated from exactly the RNG states / level the env has now -- otherwise
-        // generate inline below
-        if (pass == 1 ? use_spares : use_next) {
-            const RgState &X = pass == 1 ? SP : SN;
+        if (pass == 1 && use_spares) {
+            // take the pre-generated spare level when it is ready (k_regen); otherwise generate inline below
             bool take = false;
-            if (need_gen && pass == 1 && __hip_atomic_load(&S.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) take = true;
-            // a speculated level is re-generated whenever its env ends a step on the stairs: own it (1 -> 3) before looking at it
-            if (need_gen && pass == 0 && __hip_atomic_load(&S.sn_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) take = atomicCAS(&S.sn_ready[e], 1u, 3u) == 1u;
+            if (need_gen && __hip_atomic_load(&S.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) take = true;
             uint64_t tm = __ballot(take);
             if (tm) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 const int HW = S.hw, n = S.n, nrooms = c.room_num_x * c.room_num_y;
-                if (take && pass == 0) {  // the 13 input words must still be the env's
-                    uint32_t t[13];
-#pragma unroll
-                    for (int k = 0; k < 13; k++) t[k] = S.sn_tag[k * n + e];
-                    take = t[0] == E.rd.x && t[1] == E.rd.y && t[2] == E.rd.z && t[3] == E.rd.w && t[4] == E.ri.x && t[5] == E.ri.y && t[6] == E.ri.z &&
-                           t[7] == E.ri.w && t[8] == E.re.x && t[9] == E.re.y && t[10] == E.re.z && t[11] == E.re.w && t[12] == E.dlevel;
-                    if (!take) __hip_atomic_store(&S.sn_ready[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // generated from other inputs: useless
-                }
-                tm = __ballot(take);
                 if (take) {
-                    if (pass == 1) {
-                        uint16_t *gc = E.gcell;
-                        load_env(SP, E, e);
-                        E.cell = E.gcell = gc;
-                    } else {  // Dungeon::new_level leaves the player's own scalars alone
-                        E.rd = {SN.rng[0 * n + e], SN.rng[1 * n + e], SN.rng[2 * n + e], SN.rng[3 * n + e]};
-                        E.ri = {SN.rng[4 * n + e], SN.rng[5 * n + e], SN.rng[6 * n + e], SN.rng[7 * n + e]};
-                        E.re = {SN.rng[8 * n + e], SN.rng[9 * n + e], SN.rng[10 * n + e], SN.rng[11 * n + e]};
-                        const uint32_t pp = SN.p_pos[e], mcnt = SN.mon_cnt[e];
-                        E.px = POS_X(pp); E.py = POS_Y(pp);
-                        E.dlevel = SN.dlevel[e];
-                        E.mon_alive = mcnt & 0xff; E.mon_active = (mcnt >> 8) & 0xff;
-                    }
+                    uint16_t *gc = E.gcell;
+                    load_env(SP, E, e);
+                    E.cell = E.gcell = gc;
                     for (int sl = 0; sl < nrooms; sl++) {
-                        S.room_rect[sl * n + e] = X.room_rect[sl * n + e]; S.room_meta[sl * n + e] = X.room_meta[sl * n + e];
-                        S.mon_w0[sl * n + e] = X.mon_w0[sl * n + e]; S.mon_hp[sl * n + e] = X.mon_hp[sl * n + e]; S.mon_exp[sl * n + e] = X.mon_exp[sl * n + e];
-                        S.gold_pos[sl * n + e] = X.gold_pos[sl * n + e]; S.gold_amt[sl * n + e] = X.gold_amt[sl * n + e];
+                        S.room_rect[sl * n + e] = SP.room_rect[sl * n + e]; S.room_meta[sl * n + e] = SP.room_meta[sl * n + e];
+                        S.mon_w0[sl * n + e] = SP.mon_w0[sl * n + e]; S.mon_hp[sl * n + e] = SP.mon_hp[sl * n + e]; S.mon_exp[sl * n + e] = SP.mon_exp[sl * n + e];
+                        S.gold_pos[sl * n + e] = SP.gold_pos[sl * n + e]; S.gold_amt[sl * n + e] = SP.gold_amt[sl * n + e];
                     }
                     need_gen = false;
                 }
@@ -1749,7 +1693,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgState SN
                     int src = __ffsll((long long)mm) - 1;
                     mm &= mm - 1;
                     int env_s = __shfl(e, src);
-                    const uint16_t *sp = X.cell + (size_t)env_s * HW;
+                    const uint16_t *sp = SP.cell + (size_t)env_s * HW;
                     uint16_t *dp = S.cell + (size_t)env_s * HW;
                     if ((HW & 7) == 0) {
                         for (int i = lane; i < HW / 8; i += WAVE) reinterpret_cast<uint4 *>(dp)[i] = reinterpret_cast<const uint4 *>(sp)[i];
@@ -1757,10 +1701,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgState SN
                         for (int i = lane; i < HW; i += WAVE) dp[i] = sp[i];
                 }
                 __syncthreads();
-                if (take) {  // consumed
-                    if (pass == 1) __hip_atomic_store(&S.sp_ready[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // k_regen refills it
-                    else __hip_atomic_store(&S.sn_ready[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                if (take) __hip_atomic_store(&S.sp_ready[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // consumed: k_regen refills it
             }
         }
         const bool regenerated = descends && pass == 0;
@@ -1855,10 +1796,6 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgState SN
     }
     if (terminal) flags |= RG_FLAG_TERMINAL;
     store_env(S, E);
-    if (use_next && !terminal && !descends) {  // standing on the stairs: have the next level generated ahead of a '>' (k_regen)
-        const uint32_t here = win_get(w, WIN_K(E.px - w.ox, E.py - w.oy));
-        if ((here & C_SURF_MASK) == S_STAIR) __hip_atomic_store(&S.sn_req[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     S.steps[e] = steps;
     S.flags[e] = flags;
     S.done[e] = terminal ? 1 : 0;
@@ -1875,8 +1812,7 @@ void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
     size_t smem = GEN_SLOT_BYTES(hw);  // one level at a time per wave: one staging grid + the generator's tables
     hipLaunchKernelGGL(k_build, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), smem, st, *S, *c);
 }
-void rgk_step(const RgState *S, const RgState *SP, const RgState *SN, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, int use_spares, int use_next,
-              hipStream_t st) {
+void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, int use_spares, hipStream_t st) {
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw);  // the generator's staging grid + tables (inline descents, spare misses), shared with ...
     const size_t bfs_hi = c->width <= 32 ? 0 : (size_t)10 * ((c->width + 63) / 64) * WAVE * 8;  // ... the BFS high distance planes
@@ -1891,14 +1827,14 @@ void rgk_step(const RgState *S, const RgState *SP, const RgState *SN, const RgCo
     while (epw > 16 && (S->n + epw - 1) / epw < 1024) epw >>= 1;
     if (epw_env == 16 || epw_env == 32 || epw_env == 64) epw = epw_env;
     const dim3 grid((S->n + epw - 1) / epw), block(WAVE);
-    if (c->width <= 32) hipLaunchKernelGGL(k_step<0>, grid, block, smem, st, *S, *SP, *SN, *c, keys, err_any, use_spares, mc_offset, epw, use_next);
-    else if (c->width <= 64) hipLaunchKernelGGL(k_step<1>, grid, block, smem, st, *S, *SP, *SN, *c, keys, err_any, use_spares, mc_offset, epw, use_next);
-    else if (c->width <= 128) hipLaunchKernelGGL(k_step<2>, grid, block, smem, st, *S, *SP, *SN, *c, keys, err_any, use_spares, mc_offset, epw, use_next);
-    else hipLaunchKernelGGL(k_step<3>, grid, block, smem, st, *S, *SP, *SN, *c, keys, err_any, use_spares, mc_offset, epw, use_next);
+    if (c->width <= 32) hipLaunchKernelGGL(k_step<0>, grid, block, smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset, epw);
+    else if (c->width <= 64) hipLaunchKernelGGL(k_step<1>, grid, block, smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset, epw);
+    else if (c->width <= 128) hipLaunchKernelGGL(k_step<2>, grid, block, smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset, epw);
+    else hipLaunchKernelGGL(k_step<3>, grid, block, smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset, epw);
 }
-void rgk_regen(const RgState *S, const RgState *SP, const RgState *SN, const RgConfig *c, int use_next, hipStream_t st) {
+void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw);
-    hipLaunchKernelGGL(k_regen, dim3((SP->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *S, *SP, *SN, *c, use_next);
+    hipLaunchKernelGGL(k_regen, dim3((SP->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *SP, *c);
 }
 }

@@ -78,11 +78,6 @@ struct RgState {
     unsigned long long *prof;
     // spare-level pipeline: 0 = spare must be (re)generated, 1 = ready, 2 = generation in progress
     uint32_t *sp_ready; // [n] (shared by the live and the spare view)
-    // next-level speculation (k_regen): an env whose player stands on the stairs gets its next level generated ahead of the '>' key, from the
-    // RNG states / level number it has at that moment; the descent takes it only if those 13 words still match (sn_tag)
-    uint32_t *sn_req;   // [n] 1 = requested by k_step (player on the stairs at the end of the step)
-    uint32_t *sn_ready; // [n] 0 = none, 1 = ready, 2 = generation in progress
-    uint32_t *sn_tag;   // [13][n] the inputs the ready level was generated from: 12 RNG words + dungeon level
     // status mirror
     int32_t *status;    // [n][10]
 };

@@ -162,22 +162,9 @@ def test_inline_generation_path_without_spares(goldens, monkeypatch):
     lockstep(goldens["configs"]["mini"], list(range(256)), rand_keys(rng, ALL_KEYS, 256, 200), max_steps=60, check_every=1, internal_every=40)
 
 
-def test_inline_descents_without_speculation(goldens, monkeypatch):
-    """k_regen pre-generates the next level of envs standing on the stairs; a descent whose RNG states still match takes it.  With the
-    speculation disabled every descent generates inside its step wave.  Both paths must give identical states."""
-    monkeypatch.setenv("ROGUE_GYM_HIP_NO_SPEC", "1")
-    cfg = goldens["configs"]["ddqn"]
-    n = 128
-    seeds = [5 if i % 3 == 0 else 300 + i for i in range(n)]
-    keys = [np.full(n, ord(ch), np.uint8) for ch in goldens["ddqn_keys"][:200]]
-    lockstep(cfg, seeds, keys, max_steps=1000, check_every=2, internal_every=25)
-    rng = np.random.RandomState(23)
-    lockstep(goldens["configs"]["mini"], list(range(192)), rand_keys(rng, ALL_KEYS, 192, 150), max_steps=80, check_every=1, internal_every=50)
-
-
-def test_speculated_descents_with_monsters(goldens):
-    """Descents with monsters around: the speculated level is only valid while no RNG stream has moved since it was generated (monster turns
-    draw from the enemy / dungeon streams), so both the hit and the fall-back path run.  Keys: walk randomly, press '>' often."""
+def test_frequent_descents_with_monsters(goldens):
+    """A policy that presses '>' often: descents with monsters around, and descents in consecutive steps (the player can be placed on the
+    stairs) -- after the second one the reference's history plane shows the level that was just discarded, not the one before it."""
     cfg = dict(goldens["configs"]["mini"], hide_dungeon=False)
     n = 256
     rng = np.random.RandomState(77)
