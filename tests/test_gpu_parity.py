@@ -221,6 +221,96 @@ def test_lockstep_other_geometries(goldens, w, h, rx, ry):
     hip.h.L.rg_sync(hip.h.h)  # drain a possible tile-error flag
 
 
+def _stair_seeker_keys(oracles, rng, stuck):
+    """One key per env from the oracle's own state: '>' on the stairs, else a greedy step down the BFS distance to the stairs (8 directions,
+    hidden / locked cells impassable), else search or wander.  Test policy only -- it exists to reach deep levels quickly."""
+    dirs = {(0, -1): "k", (0, 1): "j", (-1, 0): "h", (1, 0): "l", (-1, -1): "y", (1, -1): "u", (-1, 1): "b", (1, 1): "n"}
+    out = []
+    for i, o in enumerate(oracles):
+        surf, attr, _, _ = o.grid()
+        sc = o.scalars()
+        px, py = sc["px"], sc["py"]
+        h, w = surf.shape
+        if surf[py, px] == 4:
+            out.append(ord(">")); continue
+        walk = ~np.isin(surf, (2, 3, 7)) & ((attr & 0x12) == 0)   # not a wall / nothing, not hidden (0x02) or locked (0x10)
+        ys, xs = np.nonzero(surf == 4)
+        key = None
+        if len(xs) and stuck[i] < 6:
+            dist = np.full((h, w), 1 << 20, np.int32)
+            dist[ys[0], xs[0]] = 0
+            front = [(xs[0], ys[0])]
+            while front:
+                nxt = []
+                for (x, y) in front:
+                    for (dx, dy) in dirs:
+                        nx, ny = x + dx, y + dy
+                        if 0 <= nx < w and 0 <= ny < h and walk[ny, nx] and dist[ny, nx] > dist[y, x] + 1:
+                            if dx and dy and not (walk[y, nx] and walk[ny, x]):
+                                continue
+                            dist[ny, nx] = dist[y, x] + 1
+                            nxt.append((nx, ny))
+                front = nxt
+            best = dist[py, px]
+            for (dx, dy), k in dirs.items():
+                nx, ny = px + dx, py + dy
+                if 0 <= nx < w and 0 <= ny < h and walk[ny, nx] and dist[ny, nx] < best and (not (dx and dy) or (walk[py, nx] and walk[ny, px])):
+                    best, key = dist[ny, nx], k
+        if key is None:
+            stuck[i] = (stuck[i] + 1) % 24
+            key = "s" if stuck[i] % 3 == 0 else "hjklyubn"[rng.randint(0, 8)]
+        else:
+            stuck[i] = 0
+        out.append(ord(key))
+    return np.array(out, np.uint8)
+
+
+def test_deep_levels_without_enemies(goldens):
+    """A stairs-seeking policy without monsters goes dozens of levels down, where every room is dark and mazes and hidden passages / locked
+    doors are common (dark_level 10, maze_rate_inv 15, amulet_level 25) -- the part of the generator and of the field-of-view code the
+    level-1 goldens never reach.  Every step compares the mirrors, every 100th the whole internal state."""
+    cfg = dict(goldens["configs"]["mini"], enemies={"enemies": []})
+    n = 48
+    seeds = list(range(900, 900 + n))
+    hip = HipBatch(cfg, seeds, max_steps=100000)
+    oracles = make_oracles(cfg, seeds, max_steps=100000)
+    rng = np.random.RandomState(5)
+    stuck = [0] * n
+    for t in range(900):
+        keys = _stair_seeker_keys(oracles, rng, stuck)
+        hip.step(keys)
+        for i, o in enumerate(oracles):
+            o.step_autoreset(int(keys[i]))
+        compare_mirrors(hip, oracles, "t=%d" % t)
+        if t % 100 == 99:
+            compare_internal(hip, oracles, range(n), "t=%d" % t)
+    levels = sorted(int(o.status_arr()[0]) for o in oracles)
+    assert levels[n // 2] >= 8 and levels[-1] >= 20, levels
+
+
+def test_stair_seekers_with_enemies(goldens):
+    """The same policy with the 26 builtin monsters: players get a few levels down before they die (auto-reset), so monster tables, combat
+    and level-ups run at dungeon levels the random policy never sees."""
+    cfg = goldens["configs"]["mini"]
+    n = 64
+    seeds = list(range(1300, 1300 + n))
+    hip = HipBatch(cfg, seeds, max_steps=400)
+    oracles = make_oracles(cfg, seeds, max_steps=400)
+    rng = np.random.RandomState(6)
+    stuck = [0] * n
+    deepest = 1
+    for t in range(700):
+        keys = _stair_seeker_keys(oracles, rng, stuck)
+        hip.step(keys)
+        for i, o in enumerate(oracles):
+            o.step_autoreset(int(keys[i]))
+        compare_mirrors(hip, oracles, "t=%d" % t)
+        if t % 100 == 99:
+            compare_internal(hip, oracles, range(n), "t=%d" % t)
+        deepest = max(deepest, max(int(o.status_arr()[0]) for o in oracles))
+    assert deepest >= 5, deepest
+
+
 def test_spares_survive_reseeding(goldens):
     """rg_seed invalidates the pre-generated spares: after seed() + reset() and further auto-resets the envs follow the new seeds."""
     cfg = goldens["configs"]["mini"]
