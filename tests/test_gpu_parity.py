@@ -311,6 +311,29 @@ def test_stair_seekers_with_enemies(goldens):
     assert deepest >= 5, deepest
 
 
+def test_stair_seekers_default_dungeon(goldens):
+    """Stairs-seeking policy on the default 80x24 / 3x3-room dungeon with monsters: deeper levels, mazes and dark rooms on the wide-grid
+    code paths (two-word row masks in the BFS, 256-thread observation blocks)."""
+    cfg = dict(goldens["configs"]["default"])
+    n = 12
+    seeds = list(range(40, 40 + n))
+    hip = HipBatch(cfg, seeds, max_steps=600)
+    oracles = make_oracles(cfg, seeds, max_steps=600)
+    rng = np.random.RandomState(8)
+    stuck = [0] * n
+    deepest = 1
+    for t in range(450):
+        keys = _stair_seeker_keys(oracles, rng, stuck)
+        hip.step(keys)
+        for i, o in enumerate(oracles):
+            o.step_autoreset(int(keys[i]))
+        compare_mirrors(hip, oracles, "t=%d" % t)
+        if t % 150 == 149:
+            compare_internal(hip, oracles, range(n), "t=%d" % t)
+        deepest = max(deepest, max(int(o.status_arr()[0]) for o in oracles))
+    assert deepest >= 4, deepest
+
+
 def test_spares_survive_reseeding(goldens):
     """rg_seed invalidates the pre-generated spares: after seed() + reset() and further auto-resets the envs follow the new seeds."""
     cfg = goldens["configs"]["mini"]
