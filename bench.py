@@ -184,7 +184,7 @@ def main():
         achieved = algo_bytes * n / dom_s / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from rocprofv3 --pmc passes (see profiles/README.md)
-        if os.path.exists(pmc) and args.workload == "mini":
+        if os.path.exists(pmc) and args.workload == "mini" and n == 65536:  # the PMC passes ran on 65 536 envs per launch
             with open(pmc) as f:
                 traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
         out = {
