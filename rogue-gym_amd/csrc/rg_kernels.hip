@@ -844,7 +844,7 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     write_status(S, c, E);
     S.dc_len[e] = 0; S.dc_head[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
     S.steps[e] = 0;
-    S.flags[e] = RG_FLAG_REDRAW;
+    S.flags[e] = RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY;
     S.reward[e] = 0.f;
     S.done[e] = 0;
 }
@@ -1166,6 +1166,7 @@ __device__ __forceinline__ void bfs_service(const RgState &S, const RgConfig &c,
 #define R_STATUS 2u
 #define R_GRAVE 4u
 #define R_HIST_STALE 8u
+#define R_HIST_CHANGED 16u  // a cell became VISITED: the history mirror must be rewritten at the next Redraw
 #define MSG_HIT_FROM (1u << 8)
 #define MSG_HIT_TO (2u << 8)
 #define MSG_MISS_TO (4u << 8)
@@ -1369,7 +1370,7 @@ __device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c,
         }
         here = win_get(w, nk);
     }
-    if (!(here & C_VISITED)) win_set(w, nk, here | C_VISITED);
+    if (!(here & C_VISITED)) { win_set(w, nk, here | C_VISITED); react |= R_HIST_CHANGED; }
 #pragma unroll
     for (int j = -2; j <= 2; j++)
 #pragma unroll
@@ -1769,7 +1770,8 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
             flags = (react & 0x7f00u);                       // message flags of this key only
             if (react & R_REDRAW) flags |= RG_FLAG_REDRAW | ((react & R_HIST_STALE) ? RG_FLAG_HIST_STALE : 0);
             else flags |= old_flags & (RG_FLAG_REDRAW | RG_FLAG_HIST_STALE);
-            flags |= old_flags & RG_FLAG_HIST_LAG;
+            flags |= old_flags & (RG_FLAG_HIST_LAG | RG_FLAG_HIST_DIRTY);
+            if ((react & R_HIST_CHANGED) || descends) flags |= RG_FLAG_HIST_DIRTY;
             if (react & R_STATUS) write_status(S, c, E);
             if (ui_dead) flags |= RG_FLAG_DEAD;
             steps += 1;
@@ -1792,7 +1794,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
         write_status(S, c, E);
         S.dc_len[e] = 0; S.dc_head[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
         steps = 0;
-        flags = RG_FLAG_REDRAW;
+        flags = RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY;
     }
     if (terminal) flags |= RG_FLAG_TERMINAL;
     store_env(S, E);

@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RgState S, RgConfig c
             for (int i = tid; i < HW / 4; i += RENDER_THREADS) d4[i] = s4[i];
         } else
             for (int i = tid; i < HW; i += RENDER_THREADS) scr[i] = s_scr[i];
-        if (tid == 0) S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG)) | ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u);
+        if (tid == 0)  // the history plane was written unless this Redraw was stale
+            S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | (upd_hist ? RG_FLAG_HIST_DIRTY : 0u))) | ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u);
         __syncthreads();
     }
     (void)s_cell_at;
@@ -210,28 +211,41 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
     const int nplanes = base_planes + __popc(sflag) + (with_hist ? 1 : 0);
     uint8_t *scr = envs + (size_t)le * OBS_ENV_BYTES(HW);
     ObsTabs *tb = reinterpret_cast<ObsTabs *>(scr + HW);
-    // Persistent blocks, software-pipelined: the loads of the NEXT env of this block (flag word and, speculatively -- most steps redraw --
-    // its first tile quad + entity tables) are requested before the current env is encoded, so every env costs one exposed round trip at most.
-    // An env that did not redraw wastes <= 1 KB of reads.
-    struct Pre { uint32_t fl; uint4 v0; uint32_t rect, mon, gold, meta, ppos; };
-    auto prefetch = [&](int base) {
-        Pre p; p.fl = 0; p.v0 = make_uint4(0, 0, 0, 0); p.rect = p.mon = p.gold = p.meta = p.ppos = 0;
+    // Persistent blocks, software-pipelined two envs deep: the flag word of the env after next and -- now that its flag word is known -- the
+    // inputs of the next env (tile quad + entity tables if it redraws, its screen mirror if not) are requested before the current env is
+    // encoded, so an env costs no exposed round trip and nothing is fetched that is not used.
+    struct Pre { uint4 v0; uint32_t rect, mon, gold, meta, ppos; };
+    const int stride = gridDim.x * epb;
+    auto load_flag = [&](int base) -> uint32_t {
+        const int e = base + le;
+        return (le < epb && e < n) ? S.flags[e] : 0u;
+    };
+    auto prefetch = [&](int base, uint32_t fl) {
+        Pre p; p.v0 = make_uint4(0, 0, 0, 0); p.rect = p.mon = p.gold = p.meta = p.ppos = 0;
         const int e = base + le;
         if (le < epb && e < n) {
-            p.fl = S.flags[e];
-            if (lt < Q8) p.v0 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW)[lt];
-            if (lt < nrooms) { p.rect = S.room_rect[lt * n + e]; p.meta = S.room_meta[lt * n + e]; p.mon = S.mon_w0[lt * n + e]; p.gold = S.gold_pos[lt * n + e]; }
-            if (lt == tpe - 1) p.ppos = S.p_pos[e];
+            if (fl & RG_FLAG_REDRAW) {
+                if (lt < Q8) p.v0 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW)[lt];
+                if (lt < nrooms) { p.rect = S.room_rect[lt * n + e]; p.meta = S.room_meta[lt * n + e]; p.mon = S.mon_w0[lt * n + e]; p.gold = S.gold_pos[lt * n + e]; }
+                if (lt == tpe - 1) p.ppos = S.p_pos[e];
+            } else if (lt < Q8) {
+                const uint2 m = reinterpret_cast<const uint2 *>(S.screen + (size_t)e * HW)[lt];
+                p.v0.x = m.x; p.v0.y = m.y;
+            }
         }
         return p;
     };
-    Pre nxt = prefetch(blockIdx.x * epb);
-    for (int base = blockIdx.x * epb; base < n; base += gridDim.x * epb) {
+    const int base0 = blockIdx.x * epb;
+    uint32_t fl_cur = load_flag(base0), fl_nxt = load_flag(base0 + stride);
+    Pre nxt = prefetch(base0, fl_cur);
+    for (int base = base0; base < n; base += stride) {
         const int e = base + le;
         const bool valid = le < epb && e < n;
         const Pre cur = nxt;
-        if (base + (int)gridDim.x * epb < n) nxt = prefetch(base + gridDim.x * epb);
-        const uint32_t fl = cur.fl;
+        const uint32_t fl = fl_cur;
+        fl_cur = fl_nxt;
+        fl_nxt = load_flag(base + 2 * stride);
+        if (base + stride < n) nxt = prefetch(base + stride, fl_cur);
         const bool redraw = valid && (fl & RG_FLAG_REDRAW);
         const uint4 *cell4 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW);
         const uint4 v0 = cur.v0;
@@ -241,7 +255,9 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
             if (redraw) {
                 if (lt < nrooms) { tb->rect[lt] = t_rect; tb->meta[lt] = (uint8_t)t_meta; tb->mon[lt] = t_mon; tb->gold[lt] = t_gold; }
                 if (lt == tpe - 1) tb->ppos = t_ppos;
-                const bool upd_hist = !(fl & RG_FLAG_HIST_STALE);
+                // the history plane is rewritten only when the visited set changed since it was last written (k_step: HIST_DIRTY), never on a
+                // stale Redraw
+                const bool upd_hist = !(fl & RG_FLAG_HIST_STALE) && (fl & RG_FLAG_HIST_DIRTY);
                 uint2 *hist8 = reinterpret_cast<uint2 *>(S.hist + (size_t)e * HW);
                 for (int i = lt; i < Q8; i += tpe) {
                     uint4 v = i == lt ? v0 : cell4[i];
@@ -263,7 +279,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                 }
             } else {
                 const uint2 *m8 = reinterpret_cast<const uint2 *>(S.screen + (size_t)e * HW);
-                for (int i = lt; i < Q8; i += tpe) reinterpret_cast<uint2 *>(scr)[i] = m8[i];
+                for (int i = lt; i < Q8; i += tpe) reinterpret_cast<uint2 *>(scr)[i] = i == lt ? make_uint2(v0.x, v0.y) : m8[i];
             }
         }
         lds_barrier();
@@ -349,8 +365,8 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
             }
             if (KIND == 1 && bad) { atomicOr(&S.flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
             if (redraw && lt == 0)  // a stale Redraw leaves the history mirror one level behind (k_step refreshes it before the next descent)
-                S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG)) | ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u) |
-                             (KIND == 1 && bad ? RG_FLAG_ERR_TILE : 0);
+                S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | ((fl & RG_FLAG_HIST_STALE) ? 0u : RG_FLAG_HIST_DIRTY))) |
+                             ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u) | (KIND == 1 && bad ? RG_FLAG_ERR_TILE : 0);
         }
     }
 }
