@@ -15,13 +15,23 @@ Envs shard across ranks in contiguous blocks with no data-path collective (weak 
 envs per GPU); the optional observation all-gather of the north-star text is timed separately and
 reported under "allgather".
 
-Rank 0 prints ONE JSON line: the contract fields + "roofline" (dominant kernel, HIP-event timed on
-the launch stream) + "cpu_baseline" (the C oracle on the host cores, bounded sample; N=1 only).
+Timed region: W untimed warm-up steps, barrier + synchronize, EXACTLY K steps, barrier + synchronize; max over ranks.
+Before the warm-up there is a DISCLOSED, fixed-duration clock-warm phase ("clock_warm" in the JSON): a scratch batch of
+envs (not the measured one) is stepped for --clock-warm-s seconds so that a cold GPU has ramped its shader clock before
+anything is timed -- `steps` / `warmup` keep their meaning.  The effective shader clock is probed (s_memtime vs the
+100 MHz s_memrealtime) before and after and reported.
+
+Rank 0 prints ONE JSON line: the contract fields + "roofline" (dominant kernel, HIP-event timed on the launch stream,
+plus the end-to-end and per-kernel fractions and the on-box copy peak) + "workload_rates" (resets/s, descents/s,
+BFS maps/s) + "repeats" (4 further runs of K steps, median) + "extra_workloads" (the 80x24 default and nohide-symbol
+configs of SURVEY.md 8d through the same harness, short runs) + "cpu_baseline" (the C oracle on the host cores,
+bounded samples at 65 536 / 1 024 / 64 envs; N=1 only).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -31,12 +41,9 @@ sys.path.insert(0, os.path.join(ROOT, "rogue-gym_amd"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 KERNELS = ["k_step", "k_render", "k_obs", "k_build"]
-# per-kernel share of the algorithmic bytes (DESIGN.md "Kernels"): scalars/entities | tile state | obs write (+ mirror read)
-KERNEL_ALGO_BYTES = {"k_step": 128, "k_render": 1024, "k_obs": 3072}  # k_obs = fused mirror refresh + encode: 1024 tile + 2048 obs
 
-
-# --workload: the default is BASELINE.json configs[1] (the one the metric is quoted on).  The others are the larger parity configs of
-# SURVEY.md 8(d), benchable through the same harness for DESIGN.md's tables; they are not the headline line.
+# --workload: the default is BASELINE.json configs[1] (the one the metric is quoted on).  The others are the larger configs of
+# SURVEY.md 8(d); the default run also reports them (short) under "extra_workloads".
 WORKLOADS = {
     #  name            golden config, envs/GPU, obs kind, algorithmic B/env-step, per-kernel {k_step, k_obs} bytes, description
     "mini":          ("mini", 65536, "gray", 3200, (128, 3072), "config-mini.json 32x16"),
@@ -50,14 +57,11 @@ def golden_config(name):
         return json.load(f)["configs"][name]
 
 
-def cpu_baseline(cfg, desc, budget_s=12.0):
-    """The C oracle (a port, not the Rust reference) on all host cores, same workload shape."""
+def cpu_sample(cfg, n, cores, budget_s):
     import numpy as np
     from oracle.pyoracle import OracleBatch
 
-    cores = os.cpu_count() or 1
-    n = 65536 if cores >= 64 else 8192  # enough envs per thread that the per-step barrier is noise
-    b = OracleBatch([cfg] * n, max_steps=1000, n_threads=cores, seeds=list(range(n)))
+    b = OracleBatch([cfg] * n, max_steps=1000, n_threads=min(cores, n), seeds=list(range(n)))
     obs = np.zeros((n, 1, cfg["height"], cfg["width"]), np.float32)
     acts = np.frombuffer(b".hjklnbuy>s", np.uint8)
     rng = np.random.RandomState(0)
@@ -70,9 +74,92 @@ def cpu_baseline(cfg, desc, budget_s=12.0):
             b.step(keys[(steps + t) % 32], obs)
         steps += 10
     dt = time.time() - t0
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d lock-step steps of %s (seeds 0..%d, random 11-action policy, gray obs), C oracle -O3, %d pthreads, %.1f s"
-                      % (n, steps, desc, n - 1, cores, dt)}
+    return n * steps / dt, steps, dt, min(cores, n)
+
+
+def cpu_baseline(cfg, desc, budget_s=10.0):
+    """The C oracle (a port, not the Rust reference) on all host cores, same workload shape."""
+    cores = os.cpu_count() or 1
+    n = 65536 if cores >= 64 else 8192  # enough envs per thread that the per-step barrier is noise
+    v, steps, dt, used = cpu_sample(cfg, n, cores, budget_s)
+    out = {"value": v, "unit": "env-steps/s", "cores": used, "kind": "port",
+           "sample": "%d envs x %d lock-step steps of %s (seeds 0..%d, random 11-action policy, gray obs), C oracle -O3, %d pthreads, %.1f s"
+                     % (n, steps, desc, n - 1, used, dt), "other_sizes": {}}
+    for m in (1024, 64):  # BASELINE.md section 3: the CPU side at 64 / 1 024 envs too (what the reference's thread-per-env design can reach)
+        v2, s2, dt2, used2 = cpu_sample(cfg, m, cores, 2.0)
+        out["other_sizes"][str(m)] = {"value": v2, "cores": used2, "sample": "%d envs x %d steps, %.1f s" % (m, s2, dt2)}
+    return out
+
+
+class Harness:
+    """One workload on this rank: env batch + pre-generated action tensor."""
+
+    def __init__(self, torch, workload, n, rank, local_rank, need_steps):
+        from rogue_gym.envs import DungeonType, HipVecRogueEnv, ImageSetting, StatusFlag
+
+        cfg_name, n_default, obs_kind, self.algo_bytes, (self.step_bytes, self.obs_bytes), self.desc = WORKLOADS[workload]
+        self.cfg = golden_config(cfg_name)
+        self.n = n or n_default
+        self.obs_kind = obs_kind
+        first = rank * self.n
+        cfgs = [json.dumps(dict(self.cfg, seed=first + i)) for i in range(self.n)]
+        self.env = HipVecRogueEnv(cfgs, max_steps=1000,
+                                  image_setting=ImageSetting(DungeonType.GRAY if obs_kind == "gray" else DungeonType.SYMBOL, StatusFlag.EMPTY, False),
+                                  device=local_rank)
+        dev = self.env.device
+        gen = torch.Generator(device=dev).manual_seed(rank)  # action source is not part of parity
+        # pre-generated action tensor; the per-step "action fetch" is the row lookup below
+        actions = torch.randint(0, 11, (min(256, max(1, need_steps)), self.n), generator=gen, device=dev, dtype=torch.int64)
+        self.keys_all = self.env._action_keys[actions].contiguous()
+        self.t = 0
+
+    def step(self):
+        r = self.env.step_keys(self.keys_all[self.t % self.keys_all.shape[0]])
+        self.t += 1
+        return r
+
+    def timing(self, every):
+        self.env._h.check(self.env._h.L.rg_timing_enable(self.env._h.h, every))
+
+    def read_timing(self):
+        ms, cnt = (C.c_double * 4)(), (C.c_uint64 * 4)()
+        self.env._h.check(self.env._h.L.rg_timing_read(self.env._h.h, ms, cnt))
+        out = {}
+        kb = {"k_step": self.step_bytes, "k_obs": self.obs_bytes, "k_render": 1024}
+        for k in range(3):
+            if cnt[k]:
+                avg_ms = ms[k] / cnt[k]
+                gbps = kb[KERNELS[k]] * self.n / (avg_ms * 1e-3) / 1e9
+                out[KERNELS[k]] = {"avg_us": avg_ms * 1e3, "launches": int(cnt[k]), "algo_bytes_per_env": kb[KERNELS[k]], "algo_GBps": gbps,
+                                   "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
+        return out
+
+    def sclk(self):
+        mhz = C.c_double()
+        self.env._h.check(self.env._h.L.rg_probe_sclk(self.env._h.h, C.byref(mhz)))
+        return mhz.value
+
+    def close(self):
+        self.env.close()
+
+
+def copy_peak(torch, dev):
+    """On-box device-to-device copy rate (read + write bytes per second), the achievable-HBM reference next to the 8 TB/s nominal figure."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 20
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    del a, b
+    return 2.0 * n * reps / (ms * 1e-3) / 1e9
 
 
 def main():
@@ -83,7 +170,10 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mini")
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="default: the workload's own size (65 536 for mini)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--time-every", type=int, default=8, help="bracket every N-th kernel launch with HIP events (roofline leg)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short extra_workloads runs (default / nohide-symbol)")
+    ap.add_argument("--no-repeats", action="store_true", help="skip the 4 further runs of K steps (median)")
+    ap.add_argument("--clock-warm-s", type=float, default=1.5, help="untimed fixed-duration stepping of a SCRATCH batch before anything else (0 = off)")
+    ap.add_argument("--time-every", type=int, default=8, help="bracket every N-th kernel launch with HIP events (every launch when steps < 64)")
     ap.add_argument("--gather-steps", type=int, default=50, help="extra steps timed WITH the observation all-gather (N>1)")
     args = ap.parse_args()
 
@@ -110,46 +200,47 @@ def main():
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from rogue_gym.envs import DungeonType, HipVecRogueEnv, ImageSetting, StatusFlag
-
-    cfg_name, n_default, obs_kind, algo_bytes, (step_bytes, obs_bytes), wl_desc = WORKLOADS[args.workload]
-    cfg = golden_config(cfg_name)
-    n = args.envs_per_gpu or n_default
-    KERNEL_ALGO_BYTES.update({"k_step": step_bytes, "k_obs": obs_bytes})
-    first = rank * n
-    cfgs = [json.dumps(dict(cfg, seed=first + i)) for i in range(n)]
-    env = HipVecRogueEnv(cfgs, max_steps=1000, image_setting=ImageSetting(DungeonType.GRAY if obs_kind == "gray" else DungeonType.SYMBOL, StatusFlag.EMPTY, False),
-                         device=local_rank)
-    L, h = env._h.L, env._h.h
-
-    K, W = args.steps, args.warmup
-    gen = torch.Generator(device=dev).manual_seed(rank)  # action source is not part of parity
-    # pre-generated action tensor; the per-step "action fetch" is the index -> key gather below
-    chunk = 256
-    actions = torch.randint(0, 11, (min(chunk, K + W), n), generator=gen, device=dev, dtype=torch.int64)
-    keys_all = env._action_keys[actions].contiguous()
-
-    def one_step(t):
-        return env.step_keys(keys_all[t % keys_all.shape[0]])
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for t in range(W):
-        one_step(t)
-    env._h.check(L.rg_timing_enable(h, args.time_every))  # HIP-event pairs on the launch stream around every N-th launch
+    K, W = args.steps, args.warmup
+
+    # ---- disclosed clock-warm phase on a scratch batch (never the measured one) ----
+    clock_warm = None
+    if args.clock_warm_s > 0:
+        scratch = Harness(torch, "mini", 16384, rank, local_rank, 64)
+        mhz0 = scratch.sclk()
+        t0, warm_steps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < args.clock_warm_s:
+            for _ in range(50):
+                scratch.step()
+            torch.cuda.synchronize()
+            warm_steps += 50
+        mhz1 = scratch.sclk()
+        clock_warm = {"seconds": args.clock_warm_s, "batch": "scratch batch of 16384 mini envs (destroyed before the measured batch is created)",
+                      "scratch_steps": warm_steps, "sclk_mhz_before": mhz0, "sclk_mhz_after": mhz1}
+        scratch.close()
+        del scratch
+
+    hz = Harness(torch, args.workload, args.envs_per_gpu, rank, local_rank, K + W)
+    n, env = hz.n, hz.env
+    for _ in range(W):
+        hz.step()
+    every = 1 if K < 64 else args.time_every
+    hz.timing(every)  # HIP-event pairs on the launch stream around every `every`-th launch of each kernel
+    env.counters(reset=True)
     barrier()
     t0 = time.perf_counter()
-    for t in range(K):
-        one_step(W + t)
+    for _ in range(K):
+        hz.step()
     barrier()
     dt = time.perf_counter() - t0
-    ms = (C.c_double * 4)()
-    cnt = (C.c_uint64 * 4)()
-    env._h.check(L.rg_timing_read(h, ms, cnt))
-    env._h.check(L.rg_timing_enable(h, 0))
+    per_kernel = hz.read_timing()
+    hz.timing(0)
+    counts = env.counters(reset=True)
+    sclk_after = hz.sclk()
     env.check_errors()
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -157,36 +248,56 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_max = float(tmax.item())
 
-    # optional: the north-star's observation all-gather (compact u8 screen + i32 status), timed separately
+    # ---- 4 further runs of K steps (no event timing): the spread of the headline number ----
+    repeats = None
+    if not args.no_repeats:
+        runs = [dt_max / K * 1e3]
+        for _ in range(4):
+            barrier()
+            r0 = time.perf_counter()
+            for _ in range(K):
+                hz.step()
+            barrier()
+            r = torch.tensor([time.perf_counter() - r0], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(r, op=dist.ReduceOp.MAX)
+            runs.append(float(r.item()) / K * 1e3)
+        med = statistics.median(runs)
+        repeats = {"ms_per_step": runs, "median_ms_per_step": med, "median_value": n * world / (med * 1e-3),
+                   "note": "run 0 is the timed region `value` is computed from; runs 1-4 repeat it without HIP-event bracketing"}
+
+    # optional: the north-star's observation all-gather (ONE collective of the packed compact records, expanded by HIP kernels on the consumer)
     gather = None
     if world > 1 and args.gather_steps > 0:
-        for t in range(5):
-            one_step(t); env.all_gather_obs(compact=True)
+        for _ in range(5):
+            hz.step(); env.all_gather_obs(compact=True)
         barrier()
         g0 = time.perf_counter()
-        for t in range(args.gather_steps):
-            one_step(t); env.all_gather_obs(compact=True)
+        for _ in range(args.gather_steps):
+            hz.step(); env.all_gather_obs(compact=True)
         barrier()
         gdt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=dev)
         dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
+        rec = env._h.L.rg_compact_record_bytes(env._h.h, 0)
         gather = {"value": n * world * args.gather_steps / float(gdt.item()), "unit": "env-steps/s",
-                  "payload": "u8 screen [N,16,32] + i32 status [N,10] all-gathered to every rank each step (RCCL)"}
+                  "payload": "one all-gather per step of %d-byte records (u8 screen [%d,%d] + i32 status [10]) = %.1f MB per rank, expanded to f32 [N,%d,%d,%d] "
+                             "on every rank by rg_expand_compact" % (rec, env.height, env.width, rec * n / 1e6, env.channels, env.height, env.width)}
 
+    out = None
     if rank == 0:
-        per_kernel = {}
-        for k in range(3):
-            if cnt[k]:
-                avg_ms = ms[k] / cnt[k]
-                per_kernel[KERNELS[k]] = {"avg_us": avg_ms * 1e3, "launches": int(cnt[k]),
-                                          "algo_GBps": KERNEL_ALGO_BYTES[KERNELS[k]] * n / (avg_ms * 1e-3) / 1e9}
         dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_us"]) if per_kernel else "k_step"
         dom_s = per_kernel[dom]["avg_us"] * 1e-6 if per_kernel else dt_max / K
-        achieved = algo_bytes * n / dom_s / 1e9
-        traffic = None
+        achieved = hz.algo_bytes * n / dom_s / 1e9
+        e2e = hz.algo_bytes * n / (dt_max / K) / 1e9
+        traffic, traffic_all = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from rocprofv3 --pmc passes (see profiles/README.md)
         if os.path.exists(pmc) and args.workload == "mini" and n == 65536:  # the PMC passes ran on 65 536 envs per launch
             with open(pmc) as f:
-                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+                pj = json.load(f)
+            traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
+            traffic_all = {k: {"hbm_bytes_per_launch": v.get("hbm_bytes_per_launch"), "hbm_bytes_per_env_step": (v.get("hbm_bytes_per_launch") or 0) / 65536.0}
+                           for k, v in pj.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
+        rate = K * world / dt_max  # batch steps per second over the whole job... per-rank counters are rank 0's: scale by world
         out = {
             "metric": "env-steps/sec (whole node) at 65 536 envs, 32x16 mini-dungeon" if args.workload == "mini" and n == 65536
                       else "env-steps/sec (whole node), workload %s, %d envs per GPU" % (args.workload, n),
@@ -202,19 +313,72 @@ def main():
             "dtype": "u8/u16 integer state, f32 observation",
             "data": "synthetic (per-env seed = env index, uniform-random 11-action policy)",
             "config": {"workload": "%s, %d envs per GPU (%d total), %s-image obs [N,%d,%d,%d] f32, max_steps 1000, auto-reset"
-                                   % (wl_desc, n, n * world, obs_kind, env.channels, env.height, env.width), "envs_per_gpu": n, "parallelism": "env-sharded x%d, no data-path collective" % world},
+                                   % (hz.desc, n, n * world, hz.obs_kind, env.channels, env.height, env.width), "envs_per_gpu": n,
+                       "parallelism": "env-sharded x%d, no data-path collective" % world},
+            "clock_warm": clock_warm,
+            "sclk_mhz_after_timed_region": sclk_after,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic,
-                         "note": "achieved = %d algorithmic B/env-step x %d envs / avg %s duration (HIP events on the launch stream); "
-                                 "the step kernel is latency/divergence-bound, not bandwidth-bound" % (algo_bytes, n, dom),
-                         "per_kernel": per_kernel},
+                         "frac_end_to_end": e2e / HBM_PEAK_GBPS, "achieved_end_to_end": e2e,
+                         "event_sampling": "every %d-th launch of each kernel bracketed by a HIP-event pair on the launch stream" % every,
+                         "note": "achieved = %d algorithmic B/env-step x %d envs / avg %s duration (the contract's definition: it charges the whole step's "
+                                 "bytes to the dominant kernel); frac_end_to_end = the same bytes / ms_per_step; per_kernel has every kernel's own algorithmic share. "
+                                 "k_step is instruction-issue / latency / divergence-bound, k_obs is the HBM-side kernel." % (hz.algo_bytes, n, dom),
+                         "per_kernel": per_kernel, "pmc_traffic": traffic_all},
+            "workload_rates": {"per": "whole job, per second (rank 0's counters x n_gpus)",
+                               **{k + "_per_s": v * world / dt_max for k, v in counts.items()},
+                               "per_batch_step": {k: v / K for k, v in counts.items()}},
         }
+        _ = rate
+        if repeats:
+            out["repeats"] = repeats
         if gather:
             out["allgather"] = gather
-        if world == 1 and not args.no_cpu_baseline and obs_kind == "gray":
-            out["cpu_baseline"] = cpu_baseline(cfg, wl_desc)
+    hz.close()
+    del hz, env
+
+    if rank == 0 and world == 1:
+        try:
+            peak = copy_peak(torch, dev)
+            out["roofline"]["copy_peak_GBps"] = peak
+            out["roofline"]["frac_of_copy_peak"] = out["roofline"]["achieved"] / peak
+            for v in out["roofline"]["per_kernel"].values():
+                v["frac_of_copy_peak"] = v["algo_GBps"] / peak
+        except Exception as e:  # never lose the headline line to the side measurement
+            out["roofline"]["copy_peak_GBps"] = None
+            out["roofline"]["copy_peak_error"] = str(e)
+        if args.workload == "mini" and not args.no_extra:
+            extra = {}
+            for name, ksteps, kwarm in (("default", 300, 50), ("nohide-symbol", 60, 10)):
+                try:
+                    x = Harness(torch, name, 0, 0, local_rank, ksteps + kwarm)
+                    for _ in range(kwarm):
+                        x.step()
+                    x.timing(4)
+                    x.env.counters(reset=True)
+                    torch.cuda.synchronize()
+                    x0 = time.perf_counter()
+                    for _ in range(ksteps):
+                        x.step()
+                    torch.cuda.synchronize()
+                    xdt = time.perf_counter() - x0
+                    pk = x.read_timing()
+                    cn = x.env.counters(reset=True)
+                    x.env.check_errors()
+                    extra[name] = {"value": x.n * ksteps / xdt, "unit": "env-steps/s", "envs": x.n, "steps": ksteps, "warmup": kwarm, "ms_per_step": xdt / ksteps * 1e3,
+                                   "workload": "%s, %s-image obs [N,%d,%d,%d] f32" % (x.desc, x.obs_kind, x.env.channels, x.env.height, x.env.width),
+                                   "algo_bytes_per_env_step": x.algo_bytes, "achieved_end_to_end_GBps": x.algo_bytes * x.n / (xdt / ksteps) / 1e9,
+                                   "frac_end_to_end": x.algo_bytes * x.n / (xdt / ksteps) / 1e9 / HBM_PEAK_GBPS, "per_kernel": pk,
+                                   "rates_per_s": {k: v / xdt for k, v in cn.items()}}
+                    x.close()
+                    del x
+                except Exception as e:
+                    extra[name] = {"error": str(e)}
+            out["extra_workloads"] = extra
+        if not args.no_cpu_baseline and WORKLOADS[args.workload][2] == "gray":
+            out["cpu_baseline"] = cpu_baseline(golden_config(WORKLOADS[args.workload][0]), WORKLOADS[args.workload][5])
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    env.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -39,6 +39,7 @@ typedef struct rg_handle rg_t;
 #define RG_FLAG_ERR_KEY    0x00010000u  /* ErrorKind::InvalidInput: key not in KeyMap::ai (input.rs:73-100) */
 #define RG_FLAG_ERR_DEAD   0x00020000u  /* ErrorKind::IgnoredInput: action key while dead */
 #define RG_FLAG_ERR_TILE   0x00040000u  /* symbol image: glyph with symbol >= symbols-1 (python/src/lib.rs:96-102) */
+#define RG_FLAG_ERR_INTERNAL 0x00080000u /* a capacity guard of the stepper tripped (each is proven unreachable; see rg_kernels.hip) */
 #define RG_FLAG_ERR_MASK   0x00ff0000u
 
 /* Replaces GameState::__new__ / ParallelGameState::new (python/src/lib.rs:217-225,270-294) and
@@ -69,6 +70,10 @@ int rg_reset(rg_t *h);
  * state_impls.rs:51-79, thread_impls.rs:61-81): one key byte per env.  `keys` is a device pointer
  * when keys_on_device != 0, else a host pointer (copied H2D on the stream). */
 int rg_step(rg_t *h, const uint8_t *keys, int keys_on_device);
+/* ThreadConductor::step zips the key vector with the envs (thread_impls.rs:62-64): with n_keys < n_env only the first n_keys envs receive a
+ * key; surplus keys are dropped.  (The reference then blocks forever on the reply of the envs that got no instruction; here they simply keep
+ * their state, reward 0.)  rg_step == rg_step_prefix with n_keys = n_env. */
+int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device);
 /* Wait for the stream; returns non-zero (and sets the error text) if any env raised an error flag
  * since the last call (invalid key / action while dead), like the PyRuntimeError of lib.rs:20-26. */
 int rg_sync(rg_t *h);
@@ -96,6 +101,9 @@ int rg_obs_gray(rg_t *h, uint32_t status_flag, int with_hist, float *out_dev);
 int rg_obs_symbol(rg_t *h, uint32_t status_flag, int with_hist, float *out_dev);
 int rg_obs_channels(const rg_t *h, int symbol, uint32_t status_flag, int with_hist);
 
+/* PlayerState::status_vec (python/src/lib.rs:158-161, flags.rs:67-87) for the whole batch: out_host = i32 [n_env][popcount(flag)].  Synchronous. */
+int rg_status_vec(rg_t *h, uint32_t status_flag, int32_t *out_host);
+
 /* Host copies for the value-object API (ParallelGameState::states/step return Vec<PlayerState>):
  * synchronous D2H of the mirrors; any pointer may be NULL. */
 int rg_fetch_states(rg_t *h, uint8_t *screen, uint8_t *hist, int32_t *status, uint32_t *flags);
@@ -105,6 +113,44 @@ int rg_fetch_states(rg_t *h, uint8_t *screen, uint8_t *hist, int32_t *status, ui
  * kind 0 = gray, 1 = symbol.  Returns non-zero on the symbol-image tile error. */
 int rg_encode_host(int device, const uint8_t *screen, const uint8_t *hist, const int32_t *status, int height, int width,
                    int symbols, uint32_t status_flag, int with_hist, int kind, float *out_host);
+
+/* The same for n snapshots at once (screen / hist u8 [n][H][W], status i32 [n][10], out f32 [n][C][H][W]); the device scratch is cached per
+ * device, so repeated calls allocate nothing. */
+int rg_encode_host_batch(int device, int n, const uint8_t *screen, const uint8_t *hist, const int32_t *status, int height, int width,
+                         int symbols, uint32_t status_flag, int with_hist, int kind, float *out_host);
+/* PlayerState images of the handle's CURRENT states for the whole batch, into host memory: fused mirror refresh + encode on the device
+ * (scratch kept by the handle), one D2H copy.  Synchronous.  out_host = f32 [n_env][C][H][W], ideally pinned (rg_host_alloc). */
+int rg_obs_host(rg_t *h, int kind, uint32_t status_flag, int with_hist, float *out_host);
+/* Pinned (page-locked) host memory for rg_fetch_states / rg_obs_host destinations (D2H at full PCIe rate). */
+int rg_host_alloc(size_t bytes, void **out);
+void rg_host_free(void *p);
+
+/* Multi-GPU: the ONE per-step collective gathers a compact record per env instead of the f32 observation.
+ * rg_pack_compact writes u8 [n_env][rg_compact_record_bytes] = {screen u8[H*W], status i32[10], hist u8[H*W] if with_hist} into out_dev
+ * (flushes the pending render first); after the all-gather, the consumer expands any number of records with rg_expand_compact into
+ * out_dev = f32 [n][C][H][W] -- PlayerState::{gray,symbol}_image[_with_hist] (python/src/lib.rs:72-111; symbol.rs:51-71) from the packed
+ * bytes.  H*W must be divisible by 4. */
+int rg_compact_record_bytes(const rg_t *h, int with_hist);
+int rg_pack_compact(rg_t *h, int with_hist, uint8_t *out_dev);
+int rg_expand_compact(rg_t *h, const uint8_t *packed_dev, int n, int packed_has_hist, int kind, uint32_t status_flag, int with_hist, float *out_dev);
+
+/* Action-history log (RunTime::saved_inputs, core/src/lib.rs:288; GameState::dump_history, python/src/lib.rs:245-250).  Off by default;
+ * rg_history_enable allocates a device-side key log of cap_per_env keys for the running and for the previous episode of every env (an
+ * episode = one RunTime: it ends at rg_reset or at the auto-reset).  Every key that is in KeyMap::ai is logged when it is received (also
+ * the ones rejected with IgnoredInput while dead), as the reference does.
+ * rg_history_keys: raw key bytes; which = 0 running episode, 1 previous episode; *len = keys received (returns 2 if that exceeds the
+ * capacity, i.e. the log is truncated).  rg_dump_history: the same as serde_json::to_string_pretty(Vec<InputCode>), the format of
+ * data/learned/ddqn-minidungeon/best-actions.json; *needed = bytes incl. NUL (buf may be NULL to query). */
+int rg_history_enable(rg_t *h, int cap_per_env);
+int rg_history_keys(rg_t *h, int env, int which, uint8_t *keys, size_t cap, uint32_t *len);
+int rg_dump_history(rg_t *h, int env, int which, char *buf, size_t cap, size_t *needed);
+
+/* Workload counters accumulated by rg_step since the last reset of the counters: out[0] auto-resets, [1] descents, [2] dist maps built (BFS),
+ * [3] levels generated inline by the step kernel, [4] spare levels taken, [5] Redraw reactions, [6] keys processed, [7] unused.  Synchronous. */
+int rg_counters(rg_t *h, uint64_t out[8], int reset);
+/* Effective shader clock right now: a one-wave spin kernel on the handle's stream compares s_memtime (shader-clock ticks) with
+ * s_memrealtime (constant 100 MHz).  Synchronous; bench.py's evidence for the clock state of a run. */
+int rg_probe_sclk(rg_t *h, double *mhz);
 
 /* Per-kernel timing with HIP events recorded on the handle's stream (bench.py's roofline leg).
  * While enabled, every rg_step / render flush / rg_obs_* launch is bracketed by an event pair (up to
@@ -131,9 +177,16 @@ typedef struct rg_debug_state {
     int32_t mon_x[32], mon_y[32], mon_type[32], mon_active[32], mon_hp[32];
     uint32_t mon_exp[32];
     int32_t gold_x[32], gold_y[32], gold_amount[32];
+    int32_t n_rooms;         /* room_num_x * room_num_y, row-major room ids */
+    uint32_t room_rect[32];  /* x0 | y0<<8 | x1<<16 | y1<<24, half-open (Empty room: x0, y0 = its anchor cell) */
+    int32_t room_meta[32];   /* bits 0-1 kind (0 Normal, 1 Maze, 2 Empty; rooms.rs:11-19), 4 dark, 8 visited, 16 has gold */
 } rg_debug_state;
 /* cells: u16 [H][W] = surface (bits 0-2, rogue/mod.rs:137-147) | door<<3 | CellAttr<<4 (field.rs:107-124) */
 int rg_debug_fetch(rg_t *h, int env, rg_debug_state *out, uint16_t *cells);
+/* Parity/debug: every env generates its next dungeon level and places the player there (Dungeon::new_level, rogue/mod.rs:434-481 +
+ * actions::new_level, actions.rs:121-138) as on a successful '>' but without the turn around it (no hunger tick, no monster move,
+ * no step count).  Lets tests reach levels 2..30 of thousands of seeds directly.  Mirrors are redrawn at the next read. */
+int rg_debug_descend(rg_t *h);
 
 #ifdef __cplusplus
 }

@@ -73,6 +73,8 @@ def lib():
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_set_seed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
         L.orc_reset.argtypes = [C.c_void_p]
+        L.orc_debug_descend.argtypes = [C.c_void_p]
+        L.orc_debug_descend.restype = None
         L.orc_react.argtypes = [C.c_void_p, C.c_uint8]
         L.orc_step_autoreset.argtypes = [C.c_void_p, C.c_uint8]
         for f in ("orc_screen", "orc_hist", "orc_status", "orc_flags", "orc_scalars"):
@@ -176,6 +178,9 @@ class OracleEnv:
 
     def reset(self):
         self._L.orc_reset(self._e)
+
+    def debug_descend(self):
+        self._L.orc_debug_descend(self._e)
 
     def react(self, key):
         rc = self._L.orc_react(self._e, key if isinstance(key, int) else ord(key))

@@ -1220,6 +1220,9 @@ void orc_rng(const orc_env *e, uint32_t s[12], uint64_t counts[3]) {
     const rng_t *r[3] = {&e->rng_d, &e->rng_i, &e->rng_e};
     for (int i = 0; i < 3; i++) { s[4 * i] = r[i]->x; s[4 * i + 1] = r[i]->y; s[4 * i + 2] = r[i]->z; s[4 * i + 3] = r[i]->w; counts[i] = r[i]->count; }
 }
+/* test hook: Dungeon::new_level + actions::new_level's player placement as on a successful '>' (actions.rs:27-33,121-138), without the turn
+ * around it; the mirrors are left alone */
+void orc_debug_descend(orc_env *e) { actions_new_level(e, 0); }
 int orc_move_enemy_kat(orc_env *e, int fx, int fy, int tx, int ty, int *nx, int *ny) {
     return move_enemy(e, fx, fy, tx, ty, skip_never, nx, ny);
 }

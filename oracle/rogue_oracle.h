@@ -95,6 +95,8 @@ void orc_rng(const orc_env *e, uint32_t state[12], uint64_t counts[3]);
 /* Dungeon::move_enemy with skip = |_| false (rogue/mod.rs:339-375), for the reference KAT
  * rogue/mod.rs:566-578.  Returns 0 CantMove, 1 CanMove (nx,ny set), 2 Reach. */
 int orc_move_enemy_kat(orc_env *e, int fx, int fy, int tx, int ty, int *nx, int *ny);
+/* test hook: generate the next level and place the player as on a successful '>' (actions.rs:27-33,121-138) without the turn around it */
+void orc_debug_descend(orc_env *e);
 
 /* ---- observation encoders (python/src/lib.rs:72-205, flags.rs:67-115, symbol.rs:17-71) ---- */
 int orc_status_vec(const uint32_t status[10], uint32_t flag, int32_t *out); /* returns len */

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <random>
 #include <string>
 #include <vector>
@@ -15,11 +16,14 @@
 
 extern "C" {
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st);
-void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, int use_spares, hipStream_t st);
+void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, int use_spares, hipStream_t st);
+void rgk_probe_clock(unsigned long long *out, int spin, hipStream_t st);
 void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st);
+void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st);
 void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st);
-void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, int symbols,
-                uint32_t sflag, int with_hist, int kind, float *out, hipStream_t st);
+void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, size_t rs, size_t rst,
+                int symbols, uint32_t sflag, int with_hist, int kind, float *out, hipStream_t st);
+void rgk_pack(const RgState *S, int with_hist, uint8_t *out, hipStream_t st);
 int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, hipStream_t st);
 }
 
@@ -38,8 +42,12 @@ struct rg_handle {
     uint32_t *d_err = nullptr;
     uint8_t *d_keys = nullptr;
     bool render_pending = false;
-    std::vector<uint64_t> seed_lo, seed_hi;  // host copy of the seeds the next reset will use
-    std::vector<uint8_t> reseed;
+    float *obs_scratch = nullptr;  // rg_obs_host: device-side observation buffer, kept between calls
+    size_t obs_scratch_cap = 0;
+    std::vector<uint64_t> seed_lo, seed_hi;  // host copy of the seeds the next reset will use (reseed envs: the base of the per-build hash)
+    std::vector<uint8_t> reseed;             // 0 = configured seed, 1 = fresh seed per build, 2 = fresh seed inside seed_range per build
+    std::vector<uint64_t> range_lo, range_span;  // [2][n] low / high words; empty if no env has a seed_range
+    unsigned long long *d_probe = nullptr;
     std::string err;
     // per-kernel HIP-event timing (rg_timing_*)
     bool timing = false;
@@ -98,13 +106,11 @@ static int flush_render(rg_handle *h) {
     return 0;
 }
 
-static int upload_seeds(rg_handle *h) {
-    size_t n = (size_t)h->S.n;
+static int upload_seeds(rg_handle *h, size_t n) {  // the first n envs
     HIPCHK(h, hipMemcpyAsync(h->S.seed_lo, h->seed_lo.data(), n * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->S.seed_hi, h->seed_hi.data(), n * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->S.reseed, h->reseed.data(), n, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));  // host vectors may change right after
-    return 0;
+    return 0;  // pageable sources: the runtime stages them before returning, so the host vectors may change right after
 }
 
 extern "C" {
@@ -134,10 +140,18 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
             prev = js;
         }
         if (p.has_seed) { h->seed_lo[i] = p.seed_lo; h->seed_hi[i] = p.seed_hi; h->reseed[i] = 0; }
-        else {
-            unsigned __int128 s = ((unsigned __int128)gen() << 64) | gen();
-            if (p.has_seed_range && p.seed_range[1] > p.seed_range[0]) s = p.seed_range[0] + s % (p.seed_range[1] - p.seed_range[0]);
-            h->seed_lo[i] = (uint64_t)s; h->seed_hi[i] = (uint64_t)(s >> 64); h->reseed[i] = 1;
+        else {  // `seed: None`: every build draws its own seed on the device from this base (build_prologue), inside seed_range if one is given
+            h->seed_lo[i] = gen(); h->seed_hi[i] = gen(); h->reseed[i] = 1;
+            if (p.has_seed_range) {
+                if (!(p.seed_range[1] > p.seed_range[0])) {  // rng::gen_ranged_seed -> gen_range(start, end) panics when start >= end (core/src/rng.rs:42-45)
+                    g_create_err = "Invalid Setting: seed_range must satisfy start < end"; delete h; return 1;
+                }
+                if (h->range_lo.empty()) { h->range_lo.assign(2 * (size_t)n_env, 0); h->range_span.assign(2 * (size_t)n_env, 0); }
+                const unsigned __int128 span = p.seed_range[1] - p.seed_range[0];
+                h->range_lo[i] = (uint64_t)p.seed_range[0]; h->range_lo[n_env + i] = (uint64_t)(p.seed_range[0] >> 64);
+                h->range_span[i] = (uint64_t)span; h->range_span[n_env + i] = (uint64_t)(span >> 64);
+                h->reseed[i] = 2;
+            }
         }
     }
     h->cfg = h->parsed.cfg;
@@ -153,7 +167,10 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
     RgState &S = h->S;
     memset(&S, 0, sizeof S);
     const size_t n = (size_t)n_env, hw = (size_t)h->cfg.width * h->cfg.height;
-    S.n = n_env; S.hw = (int)hw;
+    S.n = n_env; S.hw = (int)hw; S.n_keys = n_env;
+    // one DFS stack entry per maze node at most: nodes of the largest assigned area (maze rooms span the area minus one row / column, rooms.rs:240-247)
+    const int maze_cap = ((h->cfg.width / h->cfg.room_num_x + 1) / 2) * ((h->cfg.height / h->cfg.room_num_y + 1) / 2) + 1;
+    S.maze_cap = maze_cap;
     bool ok = dev_alloc(h, &S.cell, n * hw) && dev_alloc(h, &S.screen, n * hw) && dev_alloc(h, &S.hist, n * hw) &&
               dev_alloc(h, &S.p_pos, n) && dev_alloc(h, &S.p_hp, n) && dev_alloc(h, &S.p_hpmax, n) && dev_alloc(h, &S.p_lvl, n) &&
               dev_alloc(h, &S.p_exp, n) && dev_alloc(h, &S.food, n) && dev_alloc(h, &S.quiet, n) && dev_alloc(h, &S.pack_gold, n) &&
@@ -163,11 +180,18 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
               dev_alloc(h, &S.mon_w0, RG_MAX_ROOMS * n) && dev_alloc(h, &S.mon_hp, RG_MAX_ROOMS * n) && dev_alloc(h, &S.mon_exp, RG_MAX_ROOMS * n) &&
               dev_alloc(h, &S.mon_cnt, n) && dev_alloc(h, &S.gold_pos, RG_MAX_ROOMS * n) && dev_alloc(h, &S.gold_amt, RG_MAX_ROOMS * n) &&
               dev_alloc(h, &S.edge_a, RG_MAX_EDGES * n) && dev_alloc(h, &S.edge_b, RG_MAX_EDGES * n) &&
-              dev_alloc(h, &S.maze_stack, RG_MAZE_STACK * n) &&
+              dev_alloc(h, &S.maze_stack, (size_t)maze_cap * n) && dev_alloc(h, &S.build_ctr, n) && dev_alloc(h, &S.stats, 8) &&
               dev_alloc(h, &S.dc_map, h->cfg.n_enemies > 0 ? n * RG_DIST_SLOTS * hw : 16) && dev_alloc(h, &S.dc_key, RG_DIST_SLOTS * n) &&
               dev_alloc(h, &S.dc_head, n) && dev_alloc(h, &S.dc_len, n) && dev_alloc(h, &S.status, n * 10) &&
               dev_alloc(h, &h->d_err, 4) && dev_alloc(h, &h->d_keys, n);
-    ok = ok && dev_alloc(h, &S.sp_ready, n);
+    ok = ok && dev_alloc(h, &S.sp_ready, n) && dev_alloc(h, &h->d_probe, 4);
+    S.err_any = h->d_err;
+    if (ok && !h->range_lo.empty()) {
+        ok = dev_alloc(h, &S.range_lo, 2 * n) && dev_alloc(h, &S.range_span, 2 * n) &&
+             hipMemcpy(S.range_lo, h->range_lo.data(), 2 * n * 8, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(S.range_span, h->range_span.data(), 2 * n * 8, hipMemcpyHostToDevice) == hipSuccess;
+        if (!ok && h->err.empty()) h->err = "hipMemcpy failed";
+    }
     h->SP = S;
     h->spares = auto_reset != 0 && getenv("ROGUE_GYM_HIP_NO_SPARES") == nullptr;
     if (ok && h->spares) {
@@ -177,7 +201,7 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
              dev_alloc(h, &P.rng, 12 * n) && dev_alloc(h, &P.room_rect, RG_MAX_ROOMS * n) && dev_alloc(h, &P.room_meta, RG_MAX_ROOMS * n) &&
              dev_alloc(h, &P.mon_w0, RG_MAX_ROOMS * n) && dev_alloc(h, &P.mon_hp, RG_MAX_ROOMS * n) && dev_alloc(h, &P.mon_exp, RG_MAX_ROOMS * n) &&
              dev_alloc(h, &P.mon_cnt, n) && dev_alloc(h, &P.gold_pos, RG_MAX_ROOMS * n) && dev_alloc(h, &P.gold_amt, RG_MAX_ROOMS * n) &&
-             dev_alloc(h, &P.edge_a, RG_MAX_EDGES * n) && dev_alloc(h, &P.edge_b, RG_MAX_EDGES * n) && dev_alloc(h, &P.maze_stack, RG_MAZE_STACK * n);
+             dev_alloc(h, &P.edge_a, RG_MAX_EDGES * n) && dev_alloc(h, &P.edge_b, RG_MAX_EDGES * n) && dev_alloc(h, &P.maze_stack, (size_t)maze_cap * n);
         P.prof = nullptr;
         int lo = 0, hi = 0;
         if (ok && (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, getenv("ROGUE_GYM_HIP_SIDE_LOWPRIO") ? lo : hi) != hipSuccess ||
@@ -188,15 +212,20 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
     if (!ok) { g_create_err = h->err; free_all(h); delete h; return 1; }
     // screen rows 0 and H-1 are never drawn: PlayerState::new fills the map with b' ' (python/src/lib.rs:41-50)
     if (hipMemset(S.screen, ' ', n * hw) != hipSuccess) { g_create_err = "hipMemset failed"; free_all(h); delete h; return 1; }
-    if (upload_seeds(h)) { g_create_err = h->err; free_all(h); delete h; return 1; }
+    if (upload_seeds(h, n)) { g_create_err = h->err; free_all(h); delete h; return 1; }
     rgk_build(&h->S, &h->cfg, h->stream);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { g_create_err = std::string("k_build: ") + hipGetErrorString(e); free_all(h); delete h; return 1; }
     h->render_pending = true;
-    if (h->spares) {  // first spares: generated in the background right away
+    if (h->spares) {
+        // first spares.  rg_create waits for them: left in the background, this one-off generation of EVERY env's spare (~2 ms at 65 536 envs)
+        // competes with the first few hundred steps for issue slots (the driver's 20-step bench ran k_step at 141 us instead of ~100 us).
         rgk_regen(&h->SP, &h->cfg, h->side);
         (void)hipEventRecord(h->ev_regen, h->side);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(h->side);
+        if (e != hipSuccess) { g_create_err = std::string("k_regen: ") + hipGetErrorString(e); free_all(h); delete h; return 1; }
     }
     *out = h;
     return 0;
@@ -210,6 +239,7 @@ void rg_destroy(rg_t *h) {
     if (h->ev_step) (void)hipEventDestroy(h->ev_step);
     if (h->ev_regen) (void)hipEventDestroy(h->ev_regen);
     for (int k = 0; k < 4; k++) for (auto &e : h->ev[k]) (void)hipEventDestroy(e);
+    if (h->obs_scratch) (void)hipFree(h->obs_scratch);
     free_all(h);
     delete h;
 }
@@ -231,40 +261,40 @@ int rg_set_stream(rg_t *h, void *hip_stream) {
 
 int rg_seed(rg_t *h, const uint64_t *seed_lo, const uint64_t *seed_hi, int n) {
     if (n > h->S.n) n = h->S.n;
+    if (n <= 0) return 0;
     HIPCHK(h, hipSetDevice(h->device));
-    // envs without a configured seed advance their seed on the device at every build: keep those values
-    if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
-    std::vector<uint64_t> lo(h->S.n), hi(h->S.n);
-    HIPCHK(h, hipMemcpyAsync(lo.data(), h->S.seed_lo, (size_t)h->S.n * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(hi.data(), h->S.seed_hi, (size_t)h->S.n * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (int i = 0; i < h->S.n; i++)
-        if (h->reseed[i]) { h->seed_lo[i] = lo[i]; h->seed_hi[i] = hi[i]; }
     for (int i = 0; i < n; i++) { h->seed_lo[i] = seed_lo[i]; h->seed_hi[i] = seed_hi ? seed_hi[i] : 0; h->reseed[i] = 0; }
-    if (h->spares) {  // spares were generated from the old seeds: drop them (k_step falls back to inline generation until refilled)
+    if (h->spares) {
+        // the spares of these envs were generated from the old seeds: drop them (k_step generates inline until k_regen has refilled them).
+        // A k_regen in flight may be about to publish one of them, so the side stream is drained first; the main stream is not.
         HIPCHK(h, hipStreamSynchronize(h->side));
-        HIPCHK(h, hipMemsetAsync(h->S.sp_ready, 0, (size_t)h->S.n * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->S.sp_ready, 0, (size_t)n * 4, h->stream));
     }
-    return upload_seeds(h);
+    return upload_seeds(h, (size_t)n);  // only the touched prefix travels; the seeds of `seed: None` envs are derived on the device and never read back
 }
 
 int rg_reset(rg_t *h) {
     HIPCHK(h, hipSetDevice(h->device));
-    { TimedLaunch t(h, 3); rgk_build(&h->S, &h->cfg, h->stream); }
+    { TimedLaunch t(h, 3); rgk_build(&h->S, &h->cfg, h->stream); }  // (k_build and a k_regen in flight share only the atomically advanced build counters)
     HIPCHK(h, hipGetLastError());
     h->render_pending = true;
     return 0;
 }
 
-int rg_step(rg_t *h, const uint8_t *keys, int keys_on_device) {
+int rg_step(rg_t *h, const uint8_t *keys, int keys_on_device) { return rg_step_prefix(h, keys, h->S.n, keys_on_device); }
+
+int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device) {
     HIPCHK(h, hipSetDevice(h->device));
+    if (n_keys < 0) { h->err = "rg_step_prefix: negative key count"; return 1; }
+    if (n_keys > h->S.n) n_keys = h->S.n;  // zip: surplus keys are dropped
     if (flush_render(h)) return 1;
     const uint8_t *dk = keys;
     if (!keys_on_device) {
-        HIPCHK(h, hipMemcpyAsync(h->d_keys, keys, (size_t)h->S.n, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_keys, keys, (size_t)n_keys, hipMemcpyHostToDevice, h->stream));
         dk = h->d_keys;
     }
-    { TimedLaunch t(h, 0); rgk_step(&h->S, &h->SP, &h->cfg, dk, h->d_err, h->spares ? 1 : 0, h->stream); }
+    h->S.n_keys = n_keys;
+    { TimedLaunch t(h, 0); rgk_step(&h->S, &h->SP, &h->cfg, dk, h->spares ? 1 : 0, h->stream); }
     HIPCHK(h, hipGetLastError());
     static int regen_every = getenv("ROGUE_GYM_HIP_REGEN_EVERY") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_EVERY")) : 1;
     if (h->spares && (++h->step_count % (uint64_t)(regen_every < 1 ? 1 : regen_every)) == 0) {
@@ -288,7 +318,8 @@ int rg_sync(rg_t *h) {
     if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
     if (err) {
         HIPCHK(h, hipMemsetAsync(h->d_err, 0, 4, h->stream));
-        if (err & RG_FLAG_ERR_KEY) h->err = "Invalid input (key is not in the ai keymap)";
+        if (err & RG_FLAG_ERR_INTERNAL) h->err = "internal capacity guard of the HIP stepper tripped (please report the config)";
+        else if (err & RG_FLAG_ERR_KEY) h->err = "Invalid input (key is not in the ai keymap)";
         else if (err & RG_FLAG_ERR_DEAD) h->err = "Ignored input (action while the player is dead)";
         else h->err = "Invalid tile in symbol image (symbol >= symbols - 1)";
         return 1;
@@ -321,8 +352,8 @@ static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, fl
     if (flush_render(h)) return 1;
     {
         TimedLaunch t(h, 2);
-        rgk_encode(h->S.screen, h->S.hist, h->S.status, h->S.flags, h->d_err, h->S.n, h->S.hw, h->cfg.symbols, status_flag & 0x1ffu, with_hist ? 1 : 0, kind,
-                   out_dev, h->stream);
+        rgk_encode(h->S.screen, h->S.hist, h->S.status, h->S.flags, h->d_err, h->S.n, h->S.hw, (size_t)h->S.hw, 10, h->cfg.symbols, status_flag & 0x1ffu,
+                   with_hist ? 1 : 0, kind, out_dev, h->stream);
     }
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -342,30 +373,201 @@ int rg_fetch_states(rg_t *h, uint8_t *screen, uint8_t *hist, int32_t *status, ui
     return 0;
 }
 
-int rg_encode_host(int device, const uint8_t *screen, const uint8_t *hist, const int32_t *status, int height, int width, int symbols,
-                   uint32_t status_flag, int with_hist, int kind, float *out_host) {
+// Device scratch of the stateless encode (rg_encode_host*), one per device, grown on demand and kept: the value-object API calls this once per
+// PlayerState.gray_image() &c., and a hipMalloc / hipFree pair per call cost more than the encode itself.
+namespace {
+struct EncodeScratch { uint8_t *buf = nullptr; size_t cap = 0; uint32_t *err = nullptr; };
+EncodeScratch g_scratch[64];
+std::mutex g_scratch_mu;
+bool scratch_reserve(int device, size_t bytes) {
+    EncodeScratch &sc = g_scratch[device];
+    if (!sc.err && hipMalloc((void **)&sc.err, 16) != hipSuccess) return false;
+    if (sc.cap >= bytes) return true;
+    if (sc.buf) (void)hipFree(sc.buf);
+    sc.buf = nullptr; sc.cap = 0;
+    size_t want = bytes + bytes / 2;
+    if (hipMalloc((void **)&sc.buf, want) != hipSuccess) return false;
+    sc.cap = want;
+    return true;
+}
+}  // namespace
+
+int rg_encode_host_batch(int device, int n, const uint8_t *screen, const uint8_t *hist, const int32_t *status, int height, int width, int symbols,
+                         uint32_t status_flag, int with_hist, int kind, float *out_host) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_err = "no HIP device available (librogue_gym_hip has no CPU fallback)"; return 1; }
-    if (hipSetDevice(device) != hipSuccess) { g_create_err = "invalid HIP device"; return 1; }
-    size_t hw = (size_t)height * width;
+    if (device < 0 || device >= ndev || device >= 64 || hipSetDevice(device) != hipSuccess) { g_create_err = "invalid HIP device"; return 1; }
+    if (n <= 0) return 0;
+    const size_t hw = (size_t)height * width, hw4 = (hw + 3) & ~(size_t)3;
     status_flag &= 0x1ffu;
-    int c = (kind ? symbols : 1) + __builtin_popcount(status_flag) + (with_hist ? 1 : 0);
-    uint8_t *d_scr = nullptr, *d_hist = nullptr; int32_t *d_st = nullptr; uint32_t *d_err = nullptr; float *d_out = nullptr;
-    int rc = 1;
+    const int c = (kind ? symbols : 1) + __builtin_popcount(status_flag) + (with_hist ? 1 : 0);
+    // scratch layout: screens [n][hw4] | hists [n][hw4] | status [n][10] i32 | out [n][c][hw] f32
+    const size_t o_scr = 0, o_hist = (size_t)n * hw4, o_st = 2 * (size_t)n * hw4, o_out = (o_st + (size_t)n * 40 + 255) & ~(size_t)255;
+    const size_t out_bytes = (size_t)n * c * hw * 4;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!scratch_reserve(device, o_out + out_bytes)) { g_create_err = "hipMalloc failed"; return 1; }
+    EncodeScratch &sc = g_scratch[device];
     uint32_t err = 0;
-    if (hipMalloc((void **)&d_scr, hw) != hipSuccess || hipMalloc((void **)&d_hist, hw) != hipSuccess || hipMalloc((void **)&d_st, 40) != hipSuccess ||
-        hipMalloc((void **)&d_err, 4) != hipSuccess || hipMalloc((void **)&d_out, (size_t)c * hw * 4) != hipSuccess) { g_create_err = "hipMalloc failed"; goto done; }
-    if (hipMemcpy(d_scr, screen, hw, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_st, status, 40, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(d_err, 0, 4) != hipSuccess || (with_hist && hipMemcpy(d_hist, hist, hw, hipMemcpyHostToDevice) != hipSuccess)) { g_create_err = "hipMemcpy failed"; goto done; }
-    rgk_encode(d_scr, d_hist, d_st, nullptr, d_err, 1, (int)hw, symbols, status_flag, with_hist ? 1 : 0, kind, d_out, nullptr);
-    if (hipMemcpy(out_host, d_out, (size_t)c * hw * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost) != hipSuccess) {
-        g_create_err = "encode kernel failed"; goto done;
+    bool ok = hipMemcpy2D(sc.buf + o_scr, hw4, screen, hw, hw, (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(sc.buf + o_st, status, (size_t)n * 40, hipMemcpyHostToDevice) == hipSuccess && hipMemset(sc.err, 0, 4) == hipSuccess &&
+              (!with_hist || hipMemcpy2D(sc.buf + o_hist, hw4, hist, hw, hw, (size_t)n, hipMemcpyHostToDevice) == hipSuccess);
+    if (!ok) { g_create_err = "hipMemcpy failed"; return 1; }
+    rgk_encode(sc.buf + o_scr, sc.buf + o_hist, reinterpret_cast<const int32_t *>(sc.buf + o_st), nullptr, sc.err, n, (int)hw, hw4, 10, symbols, status_flag,
+               with_hist ? 1 : 0, kind, reinterpret_cast<float *>(sc.buf + o_out), nullptr);
+    if (hipMemcpy(out_host, sc.buf + o_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&err, sc.err, 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        g_create_err = "encode kernel failed"; return 1;
     }
-    if (err) { g_create_err = "Invalid tile in symbol image (symbol >= symbols - 1)"; goto done; }
-    rc = 0;
-done:
-    (void)hipFree(d_scr); (void)hipFree(d_hist); (void)hipFree(d_st); (void)hipFree(d_err); (void)hipFree(d_out);
-    return rc;
+    if (err) { g_create_err = "Invalid tile in symbol image (symbol >= symbols - 1)"; return 1; }
+    return 0;
+}
+
+int rg_encode_host(int device, const uint8_t *screen, const uint8_t *hist, const int32_t *status, int height, int width, int symbols,
+                   uint32_t status_flag, int with_hist, int kind, float *out_host) {
+    return rg_encode_host_batch(device, 1, screen, hist, status, height, width, symbols, status_flag, with_hist, kind, out_host);
+}
+
+// PlayerState images of the whole batch into host memory (the value-object API's batched path): the fused k_obs pass into a device scratch
+// kept by the handle, then one D2H copy.  out_host should be pinned (rg_host_alloc) for full PCIe rate.
+int rg_obs_host(rg_t *h, int kind, uint32_t status_flag, int with_hist, float *out_host) {
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->S.n * rg_obs_channels(h, kind, status_flag, with_hist) * h->S.hw * 4;
+    if (h->obs_scratch_cap < bytes) {
+        if (h->obs_scratch) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->obs_scratch); h->obs_scratch = nullptr; h->obs_scratch_cap = 0; }
+        HIPCHK(h, hipMalloc((void **)&h->obs_scratch, bytes));
+        h->obs_scratch_cap = bytes;
+    }
+    if (kind ? rg_obs_symbol(h, status_flag, with_hist, h->obs_scratch) : rg_obs_gray(h, status_flag, with_hist, h->obs_scratch)) return 1;
+    HIPCHK(h, hipMemcpyAsync(out_host, h->obs_scratch, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int rg_host_alloc(size_t bytes, void **out) {
+    if (hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { g_create_err = "hipHostMalloc failed"; return 1; }
+    return 0;
+}
+void rg_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+int rg_compact_record_bytes(const rg_t *h, int with_hist) { return h->S.hw + 40 + (with_hist ? h->S.hw : 0); }
+
+int rg_pack_compact(rg_t *h, int with_hist, uint8_t *out_dev) {
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->S.hw & 3) { h->err = "rg_pack_compact needs H*W divisible by 4"; return 1; }
+    if (flush_render(h)) return 1;
+    rgk_pack(&h->S, with_hist ? 1 : 0, out_dev, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int rg_expand_compact(rg_t *h, const uint8_t *packed_dev, int n, int packed_has_hist, int kind, uint32_t status_flag, int with_hist, float *out_dev) {
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->S.hw & 3) { h->err = "rg_expand_compact needs H*W divisible by 4"; return 1; }
+    if (with_hist && !packed_has_hist) { h->err = "rg_expand_compact: the packed batch carries no history plane"; return 1; }
+    const size_t hw = (size_t)h->S.hw, rec = hw + 40 + (packed_has_hist ? hw : 0);
+    rgk_encode(packed_dev, packed_dev + hw + 40, reinterpret_cast<const int32_t *>(packed_dev + hw), nullptr, h->d_err, n, (int)hw, rec, rec / 4, h->cfg.symbols,
+               status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int rg_status_vec(rg_t *h, uint32_t status_flag, int32_t *out_host) {
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n = (size_t)h->S.n;
+    std::vector<int32_t> st(n * 10);
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->S.status, n * 40, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    static const int order[9] = {0, 2, 3, 4, 5, 6, 7, 8, 9};  // StatusFlagInner::to_vector (flags.rs:67-87): gold is not part of it
+    size_t k = 0;
+    for (size_t e = 0; e < n; e++)
+        for (int b = 0; b < 9; b++)
+            if (status_flag & (1u << b)) out_host[k++] = st[e * 10 + order[b]];
+    return 0;
+}
+
+// ---- action-history log (GameState::dump_history, python/src/lib.rs:245-250 -> RunTime::saved_inputs_as_json, core/src/lib.rs:357-375) ----
+int rg_history_enable(rg_t *h, int cap_per_env) {
+    HIPCHK(h, hipSetDevice(h->device));
+    if (cap_per_env <= 0) { h->err = "rg_history_enable: capacity must be positive"; return 1; }
+    if (h->S.klog) { h->err = "rg_history_enable: already enabled"; return 1; }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
+    const size_t n = (size_t)h->S.n;
+    uint8_t *log = nullptr, *cur = nullptr; uint32_t *len = nullptr;
+    if (!dev_alloc(h, &log, n * 2 * (size_t)cap_per_env) || !dev_alloc(h, &len, 2 * n) || !dev_alloc(h, &cur, n)) return 1;
+    h->S.klog = log; h->S.klog_len = len; h->S.klog_cur = cur; h->S.klog_cap = cap_per_env;
+    h->SP.klog = nullptr;  // the spare view never logs
+    return 0;
+}
+
+int rg_history_keys(rg_t *h, int env, int which, uint8_t *keys, size_t cap, uint32_t *len) {
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->S.klog) { h->err = "the action history is not enabled (rg_history_enable)"; return 1; }
+    if (env < 0 || env >= h->S.n || (which != 0 && which != 1)) { h->err = "rg_history_keys: env / which out of range"; return 1; }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t n = (size_t)h->S.n;
+    uint8_t cur = 0;
+    HIPCHK(h, hipMemcpy(&cur, h->S.klog_cur + env, 1, hipMemcpyDeviceToHost));
+    const uint32_t buf = which ? (cur ^ 1u) : cur;
+    uint32_t l = 0;
+    HIPCHK(h, hipMemcpy(&l, h->S.klog_len + buf * n + env, 4, hipMemcpyDeviceToHost));
+    if (len) *len = l;
+    if (l > (uint32_t)h->S.klog_cap) { h->err = "action history truncated: " + std::to_string(l) + " keys in the episode, capacity " + std::to_string(h->S.klog_cap); return 2; }
+    if (keys) {
+        if (cap < l) { h->err = "rg_history_keys: buffer too small"; return 3; }
+        if (l) HIPCHK(h, hipMemcpy(keys, h->S.klog + ((size_t)env * 2 + buf) * h->S.klog_cap, l, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+// serde form of InputCode for a key of KeyMap::ai (input.rs:73-100; enum Action / Direction names), pretty-printed like
+// serde_json::to_string_pretty (4-space indent), the format of data/learned/*/best-actions.json
+static void append_input_code(std::string &s, uint8_t key) {
+    static const char *dirs[8] = {"Up", "Down", "Left", "Right", "LeftUp", "RightUp", "LeftDown", "RightDown"};
+    const char lower = (char)(key | 0x20);
+    int d = -1;
+    switch (lower) { case 'k': d = 0; break; case 'j': d = 1; break; case 'h': d = 2; break; case 'l': d = 3; break;
+                     case 'y': d = 4; break; case 'u': d = 5; break; case 'b': d = 6; break; case 'n': d = 7; break; }
+    s += "    {\n        \"Act\": ";
+    if (d >= 0 && key != '.' && key != '>' ) {
+        s += std::string("{\n            \"") + ((key & 0x20) ? "Move" : "MoveUntil") + "\": \"" + dirs[d] + "\"\n        }";
+    } else s += std::string("\"") + (key == '.' ? "NoOp" : key == 's' ? "Search" : "DownStair") + "\"";
+    s += "\n    }";
+}
+
+int rg_dump_history(rg_t *h, int env, int which, char *buf, size_t cap, size_t *needed) {
+    uint32_t len = 0;
+    int rc = rg_history_keys(h, env, which, nullptr, 0, &len);
+    if (rc) return rc;
+    std::vector<uint8_t> keys(len ? len : 1);
+    rc = rg_history_keys(h, env, which, keys.data(), keys.size(), &len);
+    if (rc) return rc;
+    std::string s = len ? "[\n" : "[]";
+    for (uint32_t i = 0; i < len; i++) { append_input_code(s, keys[i]); s += i + 1 < len ? ",\n" : "\n"; }
+    if (len) s += "]";
+    if (needed) *needed = s.size() + 1;
+    if (!buf) return 0;
+    if (s.size() + 1 > cap) { h->err = "rg_dump_history: buffer too small"; return 3; }
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return 0;
+}
+
+int rg_counters(rg_t *h, uint64_t out[8], int reset) {
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (out) HIPCHK(h, hipMemcpy(out, h->S.stats, 64, hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(h, hipMemset(h->S.stats, 0, 64));
+    return 0;
+}
+
+int rg_probe_sclk(rg_t *h, double *mhz) {
+    HIPCHK(h, hipSetDevice(h->device));
+    rgk_probe_clock(h->d_probe, 20000, h->stream);  // ~40 k dependent VALU instructions: 50-100 us
+    HIPCHK(h, hipGetLastError());
+    unsigned long long r[4] = {0, 0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(r, h->d_probe, 32, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (mhz) *mhz = r[1] ? 100.0 * (double)r[0] / (double)r[1] : 0.0;  // s_memrealtime ticks at a constant 100 MHz
+    return 0;
 }
 
 // development aid: in-kernel phase trace; out = [ceil(n_env / 64)][64] words, one row per wave of the LAST k_step / k_build launch
@@ -429,6 +631,15 @@ int rg_config_canonical(const char *cfg_json, char *buf, size_t cap) {
     return 0;
 }
 
+int rg_debug_descend(rg_t *h) {
+    HIPCHK(h, hipSetDevice(h->device));
+    if (flush_render(h)) return 1;
+    rgk_debug_descend(&h->S, &h->cfg, h->stream);
+    HIPCHK(h, hipGetLastError());
+    h->render_pending = true;
+    return 0;
+}
+
 int rg_debug_fetch(rg_t *h, int env, rg_debug_state *out, uint16_t *cells) {
     HIPCHK(h, hipSetDevice(h->device));
     if (env < 0 || env >= h->S.n) { h->err = "env out of range"; return 1; }
@@ -469,6 +680,13 @@ int rg_debug_fetch(rg_t *h, int env, rg_debug_state *out, uint16_t *cells) {
         out->gold_amount[ng] = (int32_t)a; ng++;
     }
     out->n_gold = ng;
+    out->n_rooms = h->cfg.room_num_x * h->cfg.room_num_y;
+    for (int s = 0; s < out->n_rooms; s++) {
+        uint8_t m;
+        HIPCHK(h, hipMemcpy(&out->room_rect[s], S.room_rect + s * n + e, 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(&m, S.room_meta + s * n + e, 1, hipMemcpyDeviceToHost));
+        out->room_meta[s] = m;
+    }
     if (cells) HIPCHK(h, hipMemcpy(cells, S.cell + e * S.hw, (size_t)S.hw * 2, hipMemcpyDeviceToHost));
     return 0;
 }

@@ -348,6 +348,11 @@ std::string rg_dump_config_json(const RgParsed &p, uint64_t seed_lo, uint64_t se
     if (c.width != 80) { sep(); s += "\"width\": " + std::to_string(c.width); }
     if (c.height != 24) { sep(); s += "\"height\": " + std::to_string(c.height); }
     if (has_seed) { sep(); s += "\"seed\": " + u128_str(seed_lo, seed_hi); }
+    if (p.has_seed_range) {  // kept whether or not a seed is set (it only takes effect without one, core/src/lib.rs:57-61)
+        sep();
+        s += "\"seed_range\": [" + u128_str((uint64_t)p.seed_range[0], (uint64_t)(p.seed_range[0] >> 64)) + ", " +
+             u128_str((uint64_t)p.seed_range[1], (uint64_t)(p.seed_range[1] >> 64)) + "]";
+    }
     bool dung_default = c.room_num_x == z.room_num_x && c.room_num_y == z.room_num_y && c.min_room_x == z.min_room_x && c.min_room_y == z.min_room_y &&
         c.max_empty_rooms == z.max_empty_rooms && c.amulet_level == z.amulet_level && c.maze_rate_inv == z.maze_rate_inv && c.dark_level == z.dark_level &&
         c.hidden_passage_rate_inv == z.hidden_passage_rate_inv && c.locked_door_rate_inv == z.locked_door_rate_inv && c.max_extra_edges == z.max_extra_edges &&

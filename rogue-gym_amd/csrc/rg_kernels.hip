@@ -129,6 +129,7 @@ struct Env {
     lds_u16 *lc;        // generation: the lane's LDS staging grid through an LDS-typed pointer (ds_read / ds_write instead of flat accesses)
     uint16_t *stk_lds;  // generation: LDS maze stack of the lane's slot (GEN_STACK_LDS entries), else nullptr
     uint32_t *mc;       // k_step: this lane's column of the wave's LDS monster cache (word s at mc[s * WAVE]); write-through
+    uint32_t err;       // RG_FLAG_ERR_INTERNAL if a capacity guard tripped (each guard carries its proof of unreachability)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -330,9 +331,13 @@ __device__ __forceinline__ uint32_t select_door(const RgState &S, const RgConfig
         int k = (int)range64(E.rd, 0, (uint64_t)(y1 - y0 - 2));
         return POS(dir == 2 ? x0 : x1 - 1, y0 + 1 + k);
     }
-    // Maze: shrink the probe rectangle from the facing side until its edge holds maze cells
+    // Maze: shrink the probe rectangle from the facing side until its edge holds maze cells.
+    // Termination: Up / Left probe the edge through the lattice origin (x0, y0), which dig_maze always digs => they return in round 0 (the
+    // reference's `start -= 1` quirk of those arms, passages.rs:163-171, is never reached).  Down / Right shrink the far side by one per round
+    // and reach the origin row / column after at most y1 - y0 / x1 - x0 <= RG_MAX_W rounds.  The guard below cannot trip; if it ever does, the
+    // env raises RG_FLAG_ERR_INTERNAL instead of silently using a wrong door.
     int rx0 = x0, ry0 = y0, rx1 = x1, ry1 = y1;
-    for (int guard = 0; guard < 256 && rx0 < rx1 && ry0 < ry1; guard++) {
+    for (int guard = 0; guard <= RG_MAX_W && rx0 < rx1 && ry0 < ry1; guard++) {
         // the facing edge of the probe rectangle, clipped to the room: a 1-cell-thick rectangle scanned by the lanes
         int lx0, ly0, lrw, larea;
         if (dir < 2) {
@@ -352,6 +357,7 @@ __device__ __forceinline__ uint32_t select_door(const RgState &S, const RgConfig
         }
         if (dir == 1) ry1--; else if (dir == 2) rx0--; else if (dir == 3) rx1--; else ry0--;
     }
+    E.err |= RG_FLAG_ERR_INTERNAL;
     return POS(x0, y0);
 }
 
@@ -366,11 +372,11 @@ __device__ __forceinline__ void connect_rooms(const RgState &S, const RgConfig &
     int bend;
     if (dir == 1) bend = (int)range32(E.rd, (uint32_t)(POS_Y(s) + 1), (uint32_t)POS_Y(t));
     else bend = (int)range32(E.rd, (uint32_t)(POS_X(s) + 1), (uint32_t)POS_X(t));
-    if (n_edges < RG_MAX_EDGES) {
+    if (n_edges < RG_MAX_EDGES) {  // always: RG_MAX_EDGES >= the number of grid-adjacent room pairs (rg_state.h)
         S.edge_a[n_edges * E.n + E.e] = s | (t << 16);
         S.edge_b[n_edges * E.n + E.e] = (uint32_t)bend | ((uint32_t)(dir == 1) << 8) | ((uint32_t)k1 << 9) | ((uint32_t)k2 << 10);
         n_edges++;
-    }
+    } else E.err |= RG_FLAG_ERR_INTERNAL;
 }
 // replay one recorded corridor in registration order (passages.rs:98-132 + floor.rs:87-101): start door, end door, then the three legs.
 // The cells of one corridor are distinct, so the lanes fetch them all up front (cell i in lane i), the gen_attr draws run in
@@ -460,7 +466,7 @@ __device__ __forceinline__ void dig_maze(const RgState &S, const RgConfig &c, En
     // maze nodes = every other cell of the room in x and y; the DFS holds at most one stack entry per node
     const int mw = (x1 - x0 + 1) >> 1, mh = (y1 - y0 + 1) >> 1;
     lds_u16 *ls = (lds_u16 *)E.stk_lds;
-    uint16_t *gs = S.maze_stack + (size_t)E.e * RG_MAZE_STACK;
+    uint16_t *gs = S.maze_stack + (size_t)E.e * S.maze_cap;
     const bool in_lds = E.stk_lds && mw * mh <= GEN_STACK_LDS;
     const bool bitmap = mw * mh <= 64;  // dug nodes as a 64-bit scalar mask: the neighbour tests never touch memory
     const int W = c.width;
@@ -495,7 +501,9 @@ __device__ __forceinline__ void dig_maze(const RgState &S, const RgConfig &c, En
         E.lc[(cy + ddy) * W + cx + ddx] = dug;
         E.lc[(cy + 2 * ddy) * W + cx + 2 * ddx] = dug;
         if (bitmap) seen |= 1ull << ((((cy + 2 * ddy) - y0) >> 1) * mw + (((cx + 2 * ddx) - x0) >> 1));
-        if (sp < RG_MAZE_STACK) {  // descend: the current cell goes on the stack
+        const int stack_cap = bitmap ? 64 : (in_lds ? GEN_STACK_LDS : S.maze_cap);  // every form holds one entry per maze node of the room (maze_cap: rg_api.cpp)
+        if (sp >= stack_cap) E.err |= RG_FLAG_ERR_INTERNAL;  // never: the DFS path visits a node at most once
+        if (sp < stack_cap) {  // descend: the current cell goes on the stack
             const uint16_t cur = (uint16_t)POS(cx, cy);
             if (bitmap) stk_v = (int)threadIdx.x == sp - 1 ? (int)cur : stk_v;  // <= 64 nodes: the stack is one VGPR, entry i in lane i
             else if (in_lds) ls[sp - 1] = cur;
@@ -695,12 +703,38 @@ __device__ __forceinline__ void place_player(const RgState &S, const RgConfig &c
 }
 
 // GameConfig::build (core/src/lib.rs:193-228), split around the level generator
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// GameConfig::to_global's seed choice (core/src/lib.rs:157-165).  A configured seed is used as is.  `seed: None` draws a fresh seed for EVERY
+// build (rng::gen_seed / gen_ranged_seed use thread_rng, so the values themselves are not parity-relevant): build k of the env uses
+// hash(base, k) with k taken atomically -- the inline generation of k_step and a k_regen running concurrently on the side stream each get
+// their own k, and nothing is read-modify-written non-atomically.  With a seed_range the value is uniform in [r0, r1) by mask rejection
+// (no 128-bit division on the device).
 __device__ __forceinline__ void build_prologue(const RgState &S, Env &E) {
-    uint64_t lo = S.seed_lo[E.e], hi = S.seed_hi[E.e];
-    if (S.reseed[E.e]) {  // `seed: None` => a new random seed per build; not parity-relevant, splitmix64 chain
-        uint64_t z = lo + 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-        uint64_t y = (hi ^ z) + 0x9E3779B97F4A7C15ull; y = (y ^ (y >> 30)) * 0xBF58476D1CE4E5B9ull; y = (y ^ (y >> 27)) * 0x94D049BB133111EBull; y ^= y >> 31;
-        S.seed_lo[E.e] = z; S.seed_hi[E.e] = y;
+    uint64_t lo = uni((uint32_t)S.seed_lo[E.e]) | ((uint64_t)uni((uint32_t)(S.seed_lo[E.e] >> 32)) << 32);
+    uint64_t hi = uni((uint32_t)S.seed_hi[E.e]) | ((uint64_t)uni((uint32_t)(S.seed_hi[E.e] >> 32)) << 32);
+    const uint32_t mode = uni(S.reseed[E.e]);
+    if (mode) {
+        uint32_t k = 0;
+        if (threadIdx.x == 0) k = atomicAdd(&S.build_ctr[E.e], 1u);  // wave-uniform caller: one lane takes the ticket
+        k = uni(k);
+        uint64_t z = splitmix64(lo ^ splitmix64(hi + k)), y = splitmix64(z ^ hi);
+        if (mode == 2 && S.range_lo) {
+            const int n = E.n, e = E.e;
+            const uint64_t r_lo = S.range_lo[e], r_hi = S.range_lo[n + e], sp_lo = S.range_span[e], sp_hi = S.range_span[n + e];
+            uint64_t m_lo, m_hi;  // smallest 2^b - 1 >= span - 1
+            if (sp_hi) { m_lo = ~0ull; m_hi = ~0ull >> __clzll((long long)sp_hi); }
+            else { m_hi = 0; m_lo = sp_lo > 1 ? ~0ull >> __clzll((long long)(sp_lo - 1)) : 0ull; }
+            for (int t = 0; t < 64; t++) {  // accepts with p >= 1/2 per round
+                const uint64_t c_lo = z & m_lo, c_hi = y & m_hi;
+                if (c_hi < sp_hi || (c_hi == sp_hi && c_lo < sp_lo) || t == 63) { z = c_lo; y = c_hi; break; }
+                z = splitmix64(z); y = splitmix64(y ^ z);
+            }
+            if (!(y < sp_hi || (y == sp_hi && z < sp_lo))) { z = 0; y = 0; }  // 2^-63: fall back to r0 rather than leave the range
+            lo = r_lo + z; hi = r_hi + y + (lo < r_lo ? 1ull : 0ull);
+        } else { lo = z; hi = y; }
     }
     rng_seed(E.ri, lo, hi); rng_seed(E.re, lo, hi); rng_seed(E.rd, lo, hi);
     E.dlevel = 0;
@@ -728,11 +762,13 @@ __device__ __forceinline__ void env_from_lane(Env &U, const Env &E, int src) {
     U.hp = (int)lane_get((uint32_t)E.hp, src); U.hpmax = (int)lane_get((uint32_t)E.hpmax, src); U.plvl = (int)lane_get((uint32_t)E.plvl, src);
     U.exp = lane_get(E.exp, src); U.food = lane_get(E.food, src); U.quiet = lane_get(E.quiet, src); U.gold = lane_get(E.gold, src);
     U.dlevel = lane_get(E.dlevel, src); U.mon_alive = lane_get(E.mon_alive, src); U.mon_active = lane_get(E.mon_active, src);
+    U.err = 0;
 }
 __device__ __forceinline__ void env_to_lane(Env &E, const Env &U) {  // the generated env's scalars back into its own lane
     E.rd = U.rd; E.ri = U.ri; E.re = U.re;
     E.px = U.px; E.py = U.py; E.hp = U.hp; E.hpmax = U.hpmax; E.plvl = U.plvl;
     E.exp = U.exp; E.food = U.food; E.quiet = U.quiet; E.gold = U.gold; E.dlevel = U.dlevel; E.mon_alive = U.mon_alive; E.mon_active = U.mon_active;
+    E.err |= U.err;
 }
 static_assert(sizeof(Rng) == 16, "Rng is 4 words");
 
@@ -757,7 +793,7 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
         RgState L = S;
         L.room_rect = T->room_rect; L.room_meta = T->room_meta; L.mon_w0 = T->mon_w0; L.mon_hp = T->mon_hp; L.mon_exp = T->mon_exp;
         L.gold_pos = T->gold_pos; L.gold_amt = T->gold_amt; L.edge_a = T->edge_a; L.edge_b = T->edge_b;
-        L.maze_stack = S.maze_stack + (size_t)real_e * RG_MAZE_STACK;
+        L.maze_stack = S.maze_stack + (size_t)real_e * S.maze_cap;
         U.e = 0; U.n = 1;
         uint32_t non_empty = gen_level(L, c, U, pf);
         if (is_build) build_epilogue(L, c, U);
@@ -823,6 +859,23 @@ __device__ __forceinline__ void store_env(const RgState &S, const Env &E) {
     S.mon_cnt[e] = E.mon_alive | (E.mon_active << 8);
 }
 
+// Action-history log (RunTime::saved_inputs: react_to_input pushes every mapped key before it is processed, core/src/lib.rs:288; a rebuilt
+// RunTime starts an empty log).  Two buffers per env: the running episode and the one before it, so the keys of an episode that ended in an
+// auto-reset can still be dumped (rg_dump_history).
+__device__ __forceinline__ void klog_new_episode(const RgState &S, int e) {
+    if (!S.klog) return;
+    const uint32_t cur = S.klog_cur[e] ^ 1u;
+    S.klog_cur[e] = (uint8_t)cur;
+    S.klog_len[cur * S.n + e] = 0;
+}
+__device__ __forceinline__ void klog_push(const RgState &S, int e, uint32_t key) {
+    if (!S.klog) return;
+    const uint32_t cur = S.klog_cur[e];
+    const uint32_t len = S.klog_len[cur * S.n + e];
+    if (len < (uint32_t)S.klog_cap) S.klog[((size_t)e * 2 + cur) * S.klog_cap + len] = (uint8_t)key;
+    S.klog_len[cur * S.n + e] = len + 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_build: (re)build every env from its seed
 // ---------------------------------------------------------------------------------------------
@@ -836,7 +889,7 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     const int e = blockIdx.x * BUILD_EPB + lane;
     const bool valid = lane < BUILD_EPB && e < S.n;
     Env E;
-    E.e = valid ? e : 0; E.n = S.n; E.cell = E.gcell = S.cell + (size_t)E.e * S.hw;
+    E.e = valid ? e : 0; E.n = S.n; E.cell = E.gcell = S.cell + (size_t)E.e * S.hw; E.err = 0;
     Prof pf; pf.start(S.prof);
     gen_service(S, c, E, lane, e, valid, true, reinterpret_cast<uint16_t *>(g_smem), pf);
     if (!valid) return;
@@ -844,9 +897,30 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     write_status(S, c, E);
     S.dc_len[e] = 0; S.dc_head[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
     S.steps[e] = 0;
-    S.flags[e] = RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY;
+    S.flags[e] = RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY | E.err;
+    if (E.err) atomicOr(S.err_any, E.err);
     S.reward[e] = 0.f;
     S.done[e] = 0;
+    klog_new_episode(S, e);
+}
+
+// Parity / property-test hook (rg_debug_descend): every env takes Dungeon::new_level + actions::new_level's player placement as if it had
+// pressed '>' on the stairs, without the turn around it -- the descent path of k_step (gen_service, is_build = false) on its own, so tests
+// can look at levels 2..30 of thousands of seeds without walking there.
+__global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x * BUILD_EPB + lane;
+    const bool valid = lane < BUILD_EPB && e < S.n;
+    Env E;
+    E.err = 0;
+    load_env(S, E, valid ? e : 0);
+    Prof pf; pf.start(nullptr);
+    gen_service(S, c, E, lane, e, valid, false, reinterpret_cast<uint16_t *>(g_smem), pf);
+    if (!valid) return;
+    store_env(S, E);
+    write_status(S, c, E);
+    S.flags[e] = (S.flags[e] & (RG_FLAG_TERMINAL | RG_FLAG_DEAD)) | RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY | E.err;
+    if (E.err) atomicOr(S.err_any, E.err);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -867,10 +941,11 @@ __global__ void __launch_bounds__(WAVE) k_regen(RgState SP, RgConfig c) {
         claim = atomicCAS(&SP.sp_ready[e], 0u, 2u) == 0u;
     if (!__any(claim)) return;
     Env E;
-    E.e = valid ? e : 0; E.n = SP.n; E.cell = E.gcell = SP.cell + (size_t)E.e * SP.hw;
+    E.e = valid ? e : 0; E.n = SP.n; E.cell = E.gcell = SP.cell + (size_t)E.e * SP.hw; E.err = 0;
     Prof pf; pf.start(nullptr);
     gen_service(SP, c, E, lane, e, claim, true, reinterpret_cast<uint16_t *>(g_smem), pf);
     if (claim) store_env(SP, E);
+    if (claim && E.err) atomicOr(SP.err_any, E.err);  // (the flag word belongs to the concurrently running k_step)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (claim) __hip_atomic_store(&SP.sp_ready[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1135,6 +1210,11 @@ __device__ __forceinline__ void bfs_rows_w32(const RgState &S, const RgConfig &c
     __syncthreads();  // the requesting lanes read their maps right after (monsters_move): the stores of the other lanes must have landed
 }
 
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {  // sum over the 64 lanes (values are tiny: per-lane event counts)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    return v;
+}
 // serve every lane of `need` (ballot mask): G requests per round.  BW = width class of the grid (0: W = 32, else 64-bit words per row): the
 // step kernel is instantiated per class, so a narrow grid does not pay the register footprint of the wide-row BFS (above 384 registers a
 // k_regen wave no longer fits beside a step wave on the SIMD).
@@ -1571,7 +1651,9 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
             }
             if (!reach && found) fin = bp;
         }
-        if (reach && n_att < 12) { att_list |= (uint64_t)slot << (5 * n_att); n_att++; }  // at most 8 monsters are adjacent to the player
+        // A reaching monster stays on its cell, which is one of the player's 8 neighbours; two monsters never end a turn on one cell (a
+        // monster that stays put replaces one that moved onto it, below) => at most 8 attackers, and the 12-entry list cannot overflow.
+        if (reach) { if (n_att < 12) { att_list |= (uint64_t)slot << (5 * n_att); n_att++; } else E.err |= RG_FLAG_ERR_INTERNAL; }
         if (fin == (w & 0xffff)) {
             // BTreeMap::insert on its own key replaces a monster that already moved onto this cell
             for (int s = 0; s < nrooms; s++) {
@@ -1611,8 +1693,7 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
 // k_step: one key for every env
 // ---------------------------------------------------------------------------------------------
 template <int BW>
-__global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c, const uint8_t *__restrict__ keys, uint32_t *__restrict__ err_any, int use_spares,
-                                               int mc_offset, int epw) {
+__global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset, int epw) {
     __builtin_amdgcn_s_setprio(3);  // issue-bound kernel: win VALU arbitration against the co-resident background k_regen waves
     uint16_t *lds_grid = reinterpret_cast<uint16_t *>(g_smem);
     const int lane = threadIdx.x;
@@ -1620,20 +1701,27 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
     const bool valid = lane < epw && e < S.n;
     Prof pf; pf.start(S.prof);
     Env E;
+    E.err = 0;
     uint32_t react = 0, err = 0, old_flags = 0, steps = 0, flags = 0;
     int act = ACT_NOOP, dir = 0;
     int gold_before = 0;
     bool live = false;   // this lane processes a key this call
     bool ui_dead = false, terminal = false;
+    uint32_t n_bfs = 0, n_inline = 0, n_taken = 0;  // workload counters (S.stats)
+    const bool has_key = valid && e < S.n_keys;  // ThreadConductor::step zips keys with envs (thread_impls.rs:62-64)
     if (valid) {
         old_flags = S.flags[e];
         steps = S.steps[e];
         gold_before = S.status[(size_t)e * 10 + 1];
-        if (!(steps > c.max_steps)) {  // state_impls.rs:52-54
-            act = decode_key(keys[e], dir);
-            if (act == ACT_INVALID) err = RG_FLAG_ERR_KEY;            // ErrorKind::InvalidInput
-            else if (old_flags & RG_FLAG_DEAD) err = RG_FLAG_ERR_DEAD; // Grave modal + InputCode::Act => IgnoredInput
-            else live = true;
+        if (has_key && !(steps > c.max_steps)) {  // state_impls.rs:52-54
+            const uint32_t key = keys[e];
+            act = decode_key(key, dir);
+            if (act == ACT_INVALID) err = RG_FLAG_ERR_KEY;            // ErrorKind::InvalidInput: not mapped, not logged
+            else {
+                klog_push(S, e, key);                                  // saved_inputs.push precedes the modal check (core/src/lib.rs:288)
+                if (old_flags & RG_FLAG_DEAD) err = RG_FLAG_ERR_DEAD; // Grave modal + InputCode::Act => IgnoredInput
+                else live = true;
+            }
         }
         if (live) load_env(S, E, e);
     }
@@ -1688,6 +1776,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
                         S.gold_pos[sl * n + e] = SP.gold_pos[sl * n + e]; S.gold_amt[sl * n + e] = SP.gold_amt[sl * n + e];
                     }
                     need_gen = false;
+                    n_taken++;
                 }
                 uint64_t mm = tm;
                 while (mm) {  // the wave streams each taken grid spare -> live with 16-byte accesses
@@ -1706,6 +1795,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
             }
         }
         const bool regenerated = descends && pass == 0;
+        if (need_gen) n_inline++;
         gen_service(S, c, E, lane, e, need_gen, pass == 1, lds_grid, pf);
         if (regenerated) for (int s = 0; s < nrooms_k; s++) E.mc[s * WAVE] = S.mon_w0[s * S.n + e];  // descended: reload this lane's cache column (after a reset nothing reads it again)
         pf.mark(2);
@@ -1753,6 +1843,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
             win_flush(c, E.cell, w);
             pf.mark(27);
             uint64_t m = __ballot(need_bfs);
+            if (need_bfs) n_bfs++;
             if (m) {  // serve the requesting lanes with the whole wave, several maps per round
                 unsigned long long tb0 = pf.p ? __builtin_amdgcn_s_memtime() : 0;
                 bfs_service<BW>(S, c, reinterpret_cast<uint64_t *>(lds_grid), m, e, E.px, E.py, map_slot, lane);
@@ -1762,7 +1853,8 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
             if (do_turn && E.mon_active > 0) ui_dead = monsters_move(S, c, E, rand_mask, rand_dir, map_slot, react);  // `ui` of the LAST after_turn wins
             else if (do_turn) ui_dead = false;
             pf.mark(5);
-            if (++iter > RG_MAX_W + RG_MAX_H) running = false;
+            // a MoveUntil run moves one cell in a fixed direction per iteration => it ends after at most max(W, H) iterations
+            if (++iter > RG_MAX_W + RG_MAX_H && running) { running = false; E.err |= RG_FLAG_ERR_INTERNAL; }
             if (running) win_load(c, E.cell, w, E.px, E.py);  // a MoveUntil run continues from the new cell
         }
         if (live) {
@@ -1781,21 +1873,31 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
     }
     pf.mark(6);
     pf.finish();
+    if (S.stats) {  // one atomic per wave and non-zero counter
+        const uint32_t cnt[7] = {(uint32_t)__popcll(__ballot(live && terminal && c.auto_reset)), (uint32_t)__popcll(__ballot(descends)),
+                                 wave_sum(n_bfs), wave_sum(n_inline), wave_sum(n_taken), (uint32_t)__popcll(__ballot(live && (react & R_REDRAW))),
+                                 (uint32_t)__popcll(__ballot(live))};
+        if (lane == 0)
+            for (int k = 0; k < 7; k++)
+                if (cnt[k]) atomicAdd(&S.stats[k], (unsigned long long)cnt[k]);
+    }
     if (!valid) return;
     if (err) {
         S.flags[e] = (old_flags & ~RG_FLAG_ERR_MASK) | err;
         S.reward[e] = 0.f;
         S.done[e] = (old_flags & RG_FLAG_TERMINAL) ? 1 : 0;
-        atomicOr(err_any, err);
+        atomicOr(S.err_any, err);
         return;
     }
-    if (!live) { S.reward[e] = 0.f; S.done[e] = (old_flags & RG_FLAG_TERMINAL) ? 1 : 0; return; }  // steps > max_steps: silent no-op
+    if (!live) { S.reward[e] = 0.f; S.done[e] = (old_flags & RG_FLAG_TERMINAL) ? 1 : 0; return; }  // steps > max_steps / no key for this env: silent no-op
     if (terminal && c.auto_reset) {
         write_status(S, c, E);
         S.dc_len[e] = 0; S.dc_head[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
         steps = 0;
         flags = RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY;
+        klog_new_episode(S, e);
     }
+    if (E.err) { flags |= E.err; atomicOr(S.err_any, E.err); }
     if (terminal) flags |= RG_FLAG_TERMINAL;
     store_env(S, E);
     S.steps[e] = steps;
@@ -1814,7 +1916,7 @@ void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
     size_t smem = GEN_SLOT_BYTES(hw);  // one level at a time per wave: one staging grid + the generator's tables
     hipLaunchKernelGGL(k_build, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), smem, st, *S, *c);
 }
-void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, uint32_t *err_any, int use_spares, hipStream_t st) {
+void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, int use_spares, hipStream_t st) {
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw);  // the generator's staging grid + tables (inline descents, spare misses), shared with ...
     const size_t bfs_hi = c->width <= 32 ? 0 : (size_t)10 * ((c->width + 63) / 64) * WAVE * 8;  // ... the BFS high distance planes
@@ -1829,10 +1931,14 @@ void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint
     while (epw > 16 && (S->n + epw - 1) / epw < 1024) epw >>= 1;
     if (epw_env == 16 || epw_env == 32 || epw_env == 64) epw = epw_env;
     const dim3 grid((S->n + epw - 1) / epw), block(WAVE);
-    if (c->width <= 32) hipLaunchKernelGGL(k_step<0>, grid, block, smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset, epw);
-    else if (c->width <= 64) hipLaunchKernelGGL(k_step<1>, grid, block, smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset, epw);
-    else if (c->width <= 128) hipLaunchKernelGGL(k_step<2>, grid, block, smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset, epw);
-    else hipLaunchKernelGGL(k_step<3>, grid, block, smem, st, *S, *SP, *c, keys, err_any, use_spares, mc_offset, epw);
+    if (c->width <= 32) hipLaunchKernelGGL(k_step<0>, grid, block, smem, st, *S, *SP, *c, keys, use_spares, mc_offset, epw);
+    else if (c->width <= 64) hipLaunchKernelGGL(k_step<1>, grid, block, smem, st, *S, *SP, *c, keys, use_spares, mc_offset, epw);
+    else if (c->width <= 128) hipLaunchKernelGGL(k_step<2>, grid, block, smem, st, *S, *SP, *c, keys, use_spares, mc_offset, epw);
+    else hipLaunchKernelGGL(k_step<3>, grid, block, smem, st, *S, *SP, *c, keys, use_spares, mc_offset, epw);
+}
+void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st) {
+    int hw = c->width * c->height;
+    hipLaunchKernelGGL(k_debug_descend, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), GEN_SLOT_BYTES(hw), st, *S, *c);
 }
 void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;

@@ -90,15 +90,17 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RgState S, RgConfig c
 // StatusFlagInner bit b -> index into Status::to_vec
 __device__ __constant__ uint8_t kStatusIdx[9] = {0, 2, 3, 4, 5, 6, 7, 8, 9};
 
+// rs / rst: distance between two envs' records in bytes (screen, hist) and in i32 words (status): hw and 10 for the mirrors, the record size for
+// a packed compact batch (rg_pack_compact)
 __global__ void __launch_bounds__(256) k_gray(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status,
-                                              int n, int hw, int symbols, uint32_t sflag, int with_hist, float *__restrict__ out) {
+                                              int n, int hw, size_t rs, size_t rst, int symbols, uint32_t sflag, int with_hist, float *__restrict__ out) {
     const int q = hw >> 2;  // quads per env (hw % 4 == 0 checked on the host)
     const size_t total = (size_t)n * q;
     const int nplanes = 1 + __popc(sflag) + (with_hist ? 1 : 0);
     const float fsym = (float)(uint8_t)symbols;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
         int e = (int)(g / q), i = (int)(g - (size_t)e * q);
-        uint32_t s4 = reinterpret_cast<const uint32_t *>(screen + (size_t)e * hw)[i];
+        uint32_t s4 = reinterpret_cast<const uint32_t *>(screen + (size_t)e * rs)[i];
         float4 v;
         v.x = (float)(uint8_t)tile_to_sym(s4 & 0xff) / fsym;
         v.y = (float)(uint8_t)tile_to_sym((s4 >> 8) & 0xff) / fsym;
@@ -109,13 +111,13 @@ __global__ void __launch_bounds__(256) k_gray(const uint8_t *__restrict__ screen
         int p = 1;
         for (int b = 0; b < 9; b++)
             if (sflag & (1u << b)) {
-                float f = (float)status[(size_t)e * 10 + kStatusIdx[b]];
+                float f = (float)status[(size_t)e * rst + kStatusIdx[b]];
                 float4 sv; sv.x = sv.y = sv.z = sv.w = f;
                 o[(size_t)p * q] = sv;
                 p++;
             }
         if (with_hist) {
-            uint32_t h4 = reinterpret_cast<const uint32_t *>(hist + (size_t)e * hw)[i];
+            uint32_t h4 = reinterpret_cast<const uint32_t *>(hist + (size_t)e * rs)[i];
             float4 hv;
             hv.x = (h4 & 0xff) ? 1.f : 0.f; hv.y = (h4 & 0xff00) ? 1.f : 0.f; hv.z = (h4 & 0xff0000) ? 1.f : 0.f; hv.w = (h4 >> 24) ? 1.f : 0.f;
             o[(size_t)p * q] = hv;
@@ -125,14 +127,14 @@ __global__ void __launch_bounds__(256) k_gray(const uint8_t *__restrict__ screen
 
 __global__ void __launch_bounds__(256) k_symbol(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status,
                                                 uint32_t *__restrict__ flags, uint32_t *__restrict__ err_any,
-                                                int n, int hw, int symbols, uint32_t sflag, int with_hist, float *__restrict__ out) {
+                                                int n, int hw, size_t rs, size_t rst, int symbols, uint32_t sflag, int with_hist, float *__restrict__ out) {
     const int q = hw >> 2;
     const size_t total = (size_t)n * q;
     const int nplanes = symbols + __popc(sflag) + (with_hist ? 1 : 0);
     const uint32_t symbol_max = (uint32_t)symbols - 1;  // construct_symbol_map fills channels 0..symbols-2 (symbol.rs:51-71)
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
         int e = (int)(g / q), i = (int)(g - (size_t)e * q);
-        uint32_t s4 = reinterpret_cast<const uint32_t *>(screen + (size_t)e * hw)[i];
+        uint32_t s4 = reinterpret_cast<const uint32_t *>(screen + (size_t)e * rs)[i];
         uint32_t a = tile_to_sym(s4 & 0xff), b = tile_to_sym((s4 >> 8) & 0xff), cc = tile_to_sym((s4 >> 16) & 0xff), d = tile_to_sym(s4 >> 24);
         if (a >= symbol_max || b >= symbol_max || cc >= symbol_max || d >= symbol_max) {  // InvalidTileError (e.g. 'Z')
             if (flags) atomicOr(&flags[e], RG_FLAG_ERR_TILE);
@@ -148,13 +150,13 @@ __global__ void __launch_bounds__(256) k_symbol(const uint8_t *__restrict__ scre
         int p = symbols;
         for (int bb = 0; bb < 9; bb++)
             if (sflag & (1u << bb)) {
-                float f = (float)status[(size_t)e * 10 + kStatusIdx[bb]];
+                float f = (float)status[(size_t)e * rst + kStatusIdx[bb]];
                 float4 sv; sv.x = sv.y = sv.z = sv.w = f;
                 o[(size_t)p * q] = sv;
                 p++;
             }
         if (with_hist) {
-            uint32_t h4 = reinterpret_cast<const uint32_t *>(hist + (size_t)e * hw)[i];
+            uint32_t h4 = reinterpret_cast<const uint32_t *>(hist + (size_t)e * rs)[i];
             float4 hv;
             hv.x = (h4 & 0xff) ? 1.f : 0.f; hv.y = (h4 & 0xff00) ? 1.f : 0.f; hv.z = (h4 & 0xff0000) ? 1.f : 0.f; hv.w = (h4 >> 24) ? 1.f : 0.f;
             o[(size_t)p * q] = hv;
@@ -371,16 +373,39 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
     }
 }
 
+// one 4-byte word of the compact record per thread (hw % 4 == 0: every record section is word-aligned)
+__global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status, int n, int hw,
+                                              int with_hist, uint32_t *__restrict__ out) {
+    const int qs = hw >> 2, qr = qs + 10 + (with_hist ? qs : 0);
+    const size_t total = (size_t)n * qr;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(g / qr), i = (int)(g - (size_t)e * qr);
+        uint32_t v;
+        if (i < qs) v = reinterpret_cast<const uint32_t *>(screen + (size_t)e * hw)[i];
+        else if (i < qs + 10) v = (uint32_t)status[(size_t)e * 10 + (i - qs)];
+        else v = reinterpret_cast<const uint32_t *>(hist + (size_t)e * hw)[i - qs - 10];
+        out[g] = v;
+    }
+}
+
+__global__ void k_probe_clock(unsigned long long *out, int spin) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t x = threadIdx.x + 1u;
+    for (int i = 0; i < spin; i++) x = x * 1664525u + 1013904223u;  // dependent VALU chain: 2 instructions per iteration
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; out[2] = x; out[3] = (unsigned long long)spin; }
+}
+
 // scalar fallbacks for H*W not divisible by 4 (never the case for the benchmark sizes)
 __global__ void __launch_bounds__(256) k_encode_scalar(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status,
-                                                       uint32_t *__restrict__ flags, uint32_t *__restrict__ err_any, int n, int hw, int symbols,
+                                                       uint32_t *__restrict__ flags, uint32_t *__restrict__ err_any, int n, int hw, size_t rs, size_t rst, int symbols,
                                                        uint32_t sflag, int with_hist, int kind, float *__restrict__ out) {
     const size_t total = (size_t)n * hw;
     const int base = kind ? symbols : 1;
     const int nplanes = base + __popc(sflag) + (with_hist ? 1 : 0);
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
         int e = (int)(g / hw), i = (int)(g - (size_t)e * hw);
-        uint32_t sym = tile_to_sym(screen[g]);
+        uint32_t sym = tile_to_sym(screen[(size_t)e * rs + i]);
         float *o = out + (size_t)e * nplanes * hw + i;
         if (!kind) o[0] = (float)(uint8_t)sym / (float)(uint8_t)symbols;
         else {
@@ -389,8 +414,8 @@ __global__ void __launch_bounds__(256) k_encode_scalar(const uint8_t *__restrict
         }
         int p = base;
         for (int b = 0; b < 9; b++)
-            if (sflag & (1u << b)) { o[(size_t)p * hw] = (float)status[(size_t)e * 10 + kStatusIdx[b]]; p++; }
-        if (with_hist) o[(size_t)p * hw] = hist[g] ? 1.f : 0.f;
+            if (sflag & (1u << b)) { o[(size_t)p * hw] = (float)status[(size_t)e * rst + kStatusIdx[b]]; p++; }
+        if (with_hist) o[(size_t)p * hw] = hist[(size_t)e * rs + i] ? 1.f : 0.f;
     }
 }
 
@@ -418,18 +443,30 @@ int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, 
     else hipLaunchKernelGGL(k_obs<1>, dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb);
     return 1;
 }
-void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, int symbols,
-                uint32_t sflag, int with_hist, int kind, float *out, hipStream_t st) {
-    if ((hw & 3) == 0) {
+void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, size_t rs, size_t rst,
+                int symbols, uint32_t sflag, int with_hist, int kind, float *out, hipStream_t st) {
+    if ((hw & 3) == 0 && (rs & 3) == 0) {
         size_t total = (size_t)n * (hw >> 2);
         int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
         if (blocks < 1) blocks = 1;
-        if (!kind) hipLaunchKernelGGL(k_gray, dim3(blocks), dim3(256), 0, st, screen, hist, status, n, hw, symbols, sflag, with_hist, out);
-        else hipLaunchKernelGGL(k_symbol, dim3(blocks), dim3(256), 0, st, screen, hist, status, flags, err_any, n, hw, symbols, sflag, with_hist, out);
+        if (!kind) hipLaunchKernelGGL(k_gray, dim3(blocks), dim3(256), 0, st, screen, hist, status, n, hw, rs, rst, symbols, sflag, with_hist, out);
+        else hipLaunchKernelGGL(k_symbol, dim3(blocks), dim3(256), 0, st, screen, hist, status, flags, err_any, n, hw, rs, rst, symbols, sflag, with_hist, out);
     } else {
         size_t total = (size_t)n * hw;
         int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-        hipLaunchKernelGGL(k_encode_scalar, dim3(blocks), dim3(256), 0, st, screen, hist, status, flags, err_any, n, hw, symbols, sflag, with_hist, kind, out);
+        hipLaunchKernelGGL(k_encode_scalar, dim3(blocks), dim3(256), 0, st, screen, hist, status, flags, err_any, n, hw, rs, rst, symbols, sflag, with_hist, kind, out);
     }
 }
+// compact observation record of every env: {screen u8[hw], status i32[10], hist u8[hw] (optional)}, back to back -- the payload of the ONE
+// all-gather per step of the multi-GPU path; expanded on the consumer by rgk_encode with rs = record size
+void rgk_pack(const RgState *S, int with_hist, uint8_t *out, hipStream_t st) {
+    const int hw = S->hw;
+    const size_t rec = (size_t)hw + 40 + (with_hist ? hw : 0);
+    const size_t total = (size_t)S->n * (rec / 4);
+    int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, st, S->screen, S->hist, S->status, S->n, hw, with_hist, reinterpret_cast<uint32_t *>(out));
+}
+// shader-clock probe: one wave spins for `spin` iterations and reports {s_memtime ticks (shader clock), s_memrealtime ticks (constant 100 MHz)}
+void rgk_probe_clock(unsigned long long *out, int spin, hipStream_t st) { hipLaunchKernelGGL(k_probe_clock, dim3(1), dim3(64), 0, st, out, spin); }
 }

@@ -37,8 +37,9 @@ enum { RK_NORMAL = 0, RK_MAZE = 1, RK_EMPTY = 2 };
 #define MF_ACTIVE  0x02u      // in active_enemies (and `running`)
 #define MF_PENDING 0x04u      // active and not yet moved this turn (still in the taken map, enemies.rs:376-380)
 
-#define RG_MAX_EDGES (RG_MAX_ROOMS + 16)
-#define RG_MAZE_STACK 512
+// Every connect_2rooms call joins a pair of grid-adjacent rooms that was not joined before (dig_passges excludes joined pairs, passages.rs:33-66),
+// so a level has at most rnx*(rny-1) + rny*(rnx-1) < 2 * rooms corridors whatever max_extra_edges says.
+#define RG_MAX_EDGES (2 * RG_MAX_ROOMS)
 
 struct RgState {
     int32_t n;          // environments on this device
@@ -55,8 +56,12 @@ struct RgState {
     float *reward;
     uint8_t *done;      // [n] 1 = the last key ended the episode (is_terminal of the returned state)
     uint32_t *rng;      // [12][n]  dungeon{x,y,z,w}, item{..}, enemy{..}
-    uint64_t *seed_lo, *seed_hi;  // [n] seed used by the next build
-    uint8_t *reseed;    // [n] 1 = config has no seed: draw a fresh one for every build (core/src/lib.rs:157-165)
+    uint64_t *seed_lo, *seed_hi;  // [n] seed of the next build (reseed == 0), else the base every build's seed is derived from
+    uint8_t *reseed;    // [n] 0 = `seed` given; 1 = no seed: a fresh one per build (rng::gen_seed); 2 = fresh one inside `seed_range`
+                        //     (rng::gen_ranged_seed, core/src/lib.rs:157-165)
+    uint32_t *build_ctr;          // [n] builds taken so far: build k of a reseed env uses hash(base, k); taken atomically, so k_step's inline
+                                  //     generation and a concurrent k_regen never share or tear a seed
+    uint64_t *range_lo, *range_span;  // [2][n] (low word, high word) of seed_range[0] and of seed_range[1] - seed_range[0]; NULL if no env has a range
     // rooms [RG_MAX_ROOMS][n]
     uint32_t *room_rect;  // x0 | y0<<8 | x1<<16 | y1<<24 (half-open; Empty: x0,y0 = up_left)
     uint8_t *room_meta;
@@ -69,7 +74,8 @@ struct RgState {
     uint32_t *gold_pos, *gold_amt;
     // generator scratch
     uint32_t *edge_a, *edge_b;  // [RG_MAX_EDGES][n] corridor records, replayed for gen_attr (floor.rs:73-102)
-    uint16_t *maze_stack;       // [n][RG_MAZE_STACK]
+    uint16_t *maze_stack;       // [n][maze_cap]: DFS stack of a maze room too large for the LDS stack
+    int32_t maze_cap;           // >= the maze nodes of the largest assigned area (one stack entry per node at most)
     // DistCache (rogue/mod.rs:492-518)
     uint16_t *dc_map;   // [n][RG_DIST_SLOTS][hw], 0xFFFF = unreachable
     uint16_t *dc_key;   // [RG_DIST_SLOTS][n] target pos
@@ -80,4 +86,15 @@ struct RgState {
     uint32_t *sp_ready; // [n] (shared by the live and the spare view)
     // status mirror
     int32_t *status;    // [n][10]
+    // action-history log (RunTime::saved_inputs, core/src/lib.rs:288): the keys of the current and of the previous episode, NULL = off
+    uint8_t *klog;      // [n][2][klog_cap]
+    uint32_t *klog_len; // [2][n] keys accepted in episode buffer 0 / 1 (may exceed klog_cap: the tail is then not stored)
+    uint8_t *klog_cur;  // [n] which buffer holds the running episode
+    int32_t klog_cap;
+    // workload counters (bench.py: resets/s, descents/s, BFS maps/s): [0] auto-resets [1] descents [2] dist maps built [3] inline level
+    // generations [4] spare levels taken [5] Redraw reactions [6] keys processed; one atomicAdd per wave and counter
+    unsigned long long *stats;
+    uint32_t *err_any;  // [1] OR of every error bit raised since the last rg_sync
+    // ThreadConductor::step zips keys with envs (thread_impls.rs:62-64): envs >= n_keys receive no key this call
+    int32_t n_keys;
 };

@@ -55,6 +55,7 @@ class HipVecRogueEnv:
             self.status = torch.as_tensor(_DevArray(p.value, (self.num_envs, 10), "<i4"), device=self.device)
             self._h.check(L.rg_screen(h, C.byref(p)))
             self.screen = torch.as_tensor(_DevArray(p.value, (self.num_envs, self.height, self.width), "|u1"), device=self.device)
+        self._scratch = {}
         self._encode()
 
     def _encode(self):
@@ -75,7 +76,10 @@ class HipVecRogueEnv:
         self._h.check(self._h.L.rg_seed(self._h.h, lo, hi, n))
 
     def step_keys(self, keys):
-        """keys: uint8 CUDA tensor [num_envs] of key bytes (KeyMap::ai)."""
+        """keys: uint8 CUDA tensor [num_envs] of key bytes (KeyMap::ai), contiguous, on this env's device."""
+        if keys.dtype != self.torch.uint8 or keys.device != self.device or not keys.is_contiguous() or keys.numel() != self.num_envs:
+            raise ValueError("step_keys needs a contiguous uint8 tensor of %d keys on %s, got %s %s on %s"
+                             % (self.num_envs, self.device, tuple(keys.shape), keys.dtype, keys.device))
         self._h.check(self._h.L.rg_step(self._h.h, C.c_void_p(keys.data_ptr()), 1))
         obs = self._encode()
         return obs, self.reward, self.done
@@ -88,10 +92,37 @@ class HipVecRogueEnv:
         """Synchronise and raise like the reference's PyRuntimeError if any env saw an invalid key."""
         self._h.check(self._h.L.rg_sync(self._h.h))
 
+    def packed_records(self, with_hist: bool = False):
+        """u8 [num_envs, record]: the compact observation record of every env of this rank (rg_pack_compact)."""
+        L, h = self._h.L, self._h.h
+        rec = L.rg_compact_record_bytes(h, int(with_hist))
+        key = ("packed", bool(with_hist))
+        buf = self._scratch.get(key)
+        if buf is None:
+            buf = self._scratch[key] = self.torch.empty((self.num_envs, rec), dtype=self.torch.uint8, device=self.device)
+        self._h.check(L.rg_pack_compact(h, int(with_hist), C.c_void_p(buf.data_ptr())))
+        return buf
+
+    def expand_records(self, packed, image_setting: Optional[ImageSetting] = None, packed_has_hist: bool = False, out=None):
+        """f32 [N, C, H, W] from N compact records (of any rank) under `image_setting`: the HIP encode kernels on the consumer GPU."""
+        st = self.image_setting if image_setting is None else image_setting
+        sym = st.dungeon == DungeonType.SYMBOL
+        L, h = self._h.L, self._h.h
+        n = int(packed.shape[0])
+        c = L.rg_obs_channels(h, int(sym), st.status.value, int(st.includes_hist))
+        if out is None:
+            out = self.torch.empty((n, c, self.height, self.width), dtype=self.torch.float32, device=self.device)
+        if packed.dtype != self.torch.uint8 or not packed.is_contiguous() or packed.device != self.device:
+            raise ValueError("expand_records needs a contiguous uint8 tensor on %s" % (self.device,))
+        self._h.check(L.rg_expand_compact(h, C.c_void_p(packed.data_ptr()), n, int(packed_has_hist), int(sym), st.status.value, int(st.includes_hist),
+                                          C.c_void_p(out.data_ptr())))
+        return out
+
     def all_gather_obs(self, compact: bool = True):
-        """Whole-job observation batch on every rank (one RCCL all-gather over xGMI).
-        compact=True gathers the u8 screen + i32 status (1/4 .. 1/170 of the f32 payload) and
-        expands on the consumer GPU; compact=False gathers the f32 observation itself."""
+        """Whole-job observation batch f32 [world * num_envs, C, H, W] on every rank, env order = rank order -- the same type whatever the
+        world size (world 1: this rank's own `obs`).  compact=True (default): ONE RCCL all-gather over xGMI of the packed records
+        (552 B per mini env instead of 2 KB .. 330 KB of f32), expanded on the consumer GPU by the HIP encode kernels;
+        compact=False gathers the f32 observation itself (xGMI-bound for the one-hot image)."""
         import torch.distributed as dist
 
         torch = self.torch
@@ -102,10 +133,44 @@ class HipVecRogueEnv:
             out = torch.empty((ws * self.num_envs,) + tuple(self.obs.shape[1:]), dtype=self.obs.dtype, device=self.device)
             dist.all_gather_into_tensor(out, self.obs)
             return out
-        from .sharding import all_gather_compact
+        from .sharding import all_gather_packed
 
-        _ = ws
-        return all_gather_compact(self.screen, self.status)
+        with_hist = bool(self.image_setting.includes_hist)
+        gathered = all_gather_packed(self.packed_records(with_hist))
+        return self.expand_records(gathered, packed_has_hist=with_hist)
+
+    def all_gather_compact(self, with_hist: bool = False):
+        """The gathered records themselves, as views: (screen u8 [N,H,W], status i32 [N,10], hist u8 [N,H,W] or None)."""
+        import torch.distributed as dist
+        from .sharding import all_gather_packed, unpack_records
+
+        packed = self.packed_records(with_hist)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            packed = all_gather_packed(packed)
+        return unpack_records(packed, self.height, self.width, with_hist)
+
+    def status_vec(self, flag=None):
+        """i32 [num_envs, popcount(flag)] device tensor: PlayerState::status_vec of every env (flags.rs:67-87)."""
+        flag = self.image_setting.status.value if flag is None else int(getattr(flag, "value", flag))
+        cols = [c for b, c in enumerate((0, 2, 3, 4, 5, 6, 7, 8, 9)) if flag & (1 << b)]
+        return self.status[:, cols]
+
+    def counters(self, reset: bool = False):
+        """Workload counters since the last reset of the counters (rg_counters)."""
+        out = (C.c_uint64 * 8)()
+        self._h.check(self._h.L.rg_counters(self._h.h, out, int(reset)))
+        names = ("resets", "descents", "dist_maps", "inline_generations", "spares_taken", "redraws", "keys")
+        return dict(zip(names, (int(v) for v in out)))
+
+    def enable_history(self, cap_per_env: int):
+        self._h.check(self._h.L.rg_history_enable(self._h.h, int(cap_per_env)))
+
+    def dump_history(self, env: int, previous: bool = False) -> str:
+        """GameState::dump_history (python/src/lib.rs:245-250) of env `env`: the InputCode JSON of its running (or previous) episode."""
+        return self._h.dump_history(int(env), previous)
+
+    def history_keys(self, env: int, previous: bool = False) -> bytes:
+        return self._h.history_keys(int(env), previous)
 
     def close(self):
         self._h.close()

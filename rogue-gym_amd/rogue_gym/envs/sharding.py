@@ -1,5 +1,7 @@
 """Env sharding across ranks: rank r owns the contiguous block of env indices
-[r*N/P, (r+1)*N/P); the only exchange is an optional all-gather of the compact observation."""
+[r*N/P, (r+1)*N/P); the only exchange is ONE optional all-gather per step of the compact observation records
+(u8 screen + i32 status (+ u8 history) per env, packed by rg_pack_compact), expanded to f32 images on the consumer GPU by the HIP
+encode kernels (rg_expand_compact)."""
 from typing import Tuple
 
 
@@ -9,30 +11,32 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return (n_total * rank) // world, (n_total * (rank + 1)) // world
 
 
-def all_gather_compact(screen, status, group=None):
-    """One all-gather (RCCL over xGMI with backend "nccl"; gloo on CPU) of the compact observation:
-    u8 screen [n,H,W] and i32 status [n,10] -> [world*n, ...] on every rank.  Equal shard sizes."""
+def record_layout(height: int, width: int, with_hist: bool = False):
+    """Byte offsets inside one compact record: (screen, status, hist or None, record size)."""
+    hw = height * width
+    return 0, hw, (hw + 40 if with_hist else None), hw + 40 + (hw if with_hist else 0)
+
+
+def all_gather_packed(packed, group=None):
+    """The one collective of the multi-GPU path (RCCL over xGMI with backend "nccl"; gloo on CPU): u8 [n, record] of every rank ->
+    u8 [world * n, record] on every rank, rank slices in rank order.  Equal shard sizes."""
     import torch
     import torch.distributed as dist
 
     ws = dist.get_world_size(group)
-    scr = torch.empty((ws * screen.shape[0],) + tuple(screen.shape[1:]), dtype=screen.dtype, device=screen.device)
-    st = torch.empty((ws * status.shape[0],) + tuple(status.shape[1:]), dtype=status.dtype, device=status.device)
-    dist.all_gather_into_tensor(scr, screen.contiguous(), group=group)
-    dist.all_gather_into_tensor(st, status.contiguous(), group=group)
-    return scr, st
+    out = torch.empty((ws * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed.contiguous(), group=group)
+    return out
 
 
-def expand_gray(screen, symbols: int):
-    """Consumer-side expansion of a gathered u8 screen to the f32 gray image (python/src/lib.rs:72-87):
-    sym(glyph) / symbols, via a 256-entry table (core/src/symbol.rs:17-40)."""
+def unpack_records(packed, height: int, width: int, with_hist: bool = False):
+    """Views into a gathered batch of records: (screen u8 [N,H,W], status i32 [N,10], hist u8 [N,H,W] or None)."""
     import torch
 
-    lut = torch.zeros(256, dtype=torch.float32)
-    for i, ch in enumerate(" @#.-%+^!?])/*:=,"):
-        lut[ord(ch)] = i
-    lut[ord("|")] = 4
-    for i in range(26):
-        lut[ord("A") + i] = 17 + i
-    lut = (lut / float(symbols)).to(screen.device)
-    return lut[screen.long()].unsqueeze(1)
+    o_scr, o_st, o_hist, rec = record_layout(height, width, with_hist)
+    n = packed.shape[0]
+    flat = packed.reshape(n, rec)
+    screen = flat[:, o_scr:o_st].reshape(n, height, width)
+    status = flat[:, o_st:o_st + 40].contiguous().view(torch.int32).reshape(n, 10)
+    hist = flat[:, o_hist:o_hist + height * width].reshape(n, height, width) if with_hist else None
+    return screen, status, hist

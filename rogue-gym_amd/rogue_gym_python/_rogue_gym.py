@@ -33,10 +33,18 @@ class RgDebugState(C.Structure):
         ("mon_x", C.c_int32 * 32), ("mon_y", C.c_int32 * 32), ("mon_type", C.c_int32 * 32), ("mon_active", C.c_int32 * 32), ("mon_hp", C.c_int32 * 32),
         ("mon_exp", C.c_uint32 * 32),
         ("gold_x", C.c_int32 * 32), ("gold_y", C.c_int32 * 32), ("gold_amount", C.c_int32 * 32),
+        ("n_rooms", C.c_int32), ("room_rect", C.c_uint32 * 32), ("room_meta", C.c_int32 * 32),
     ]
 
 
 _lib = None
+
+_INT_FUNCS = (
+    "rg_create", "rg_dims", "rg_set_stream", "rg_seed", "rg_reset", "rg_step", "rg_step_prefix", "rg_sync", "rg_screen", "rg_hist", "rg_status", "rg_flags",
+    "rg_reward", "rg_done", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_encode_host_batch", "rg_obs_host",
+    "rg_host_alloc", "rg_compact_record_bytes", "rg_pack_compact", "rg_expand_compact", "rg_status_vec", "rg_history_enable", "rg_history_keys",
+    "rg_dump_history", "rg_counters", "rg_probe_sclk", "rg_dump_config", "rg_config_canonical", "rg_debug_fetch", "rg_debug_descend", "rg_timing_enable", "rg_timing_read",
+)
 
 
 def load_library():
@@ -57,44 +65,83 @@ def load_library():
     except ImportError:
         pass
     L = C.CDLL(_SO)
-    vp, u8p, i32p, u32p, f32p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_float)
-    L.rg_create.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(vp)]
-    L.rg_destroy.argtypes = [vp]
+    vp, i32, u32, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_size_t
+    sig = {
+        "rg_create": [C.POINTER(C.c_char_p), i32, C.c_uint64, i32, i32, C.POINTER(vp)],
+        "rg_destroy": [vp],
+        "rg_last_error": [vp],
+        "rg_dims": [vp] + [C.POINTER(i32)] * 4,
+        "rg_set_stream": [vp, vp],
+        "rg_seed": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i32],
+        "rg_reset": [vp],
+        "rg_step": [vp, vp, i32],
+        "rg_step_prefix": [vp, vp, i32, i32],
+        "rg_sync": [vp],
+        "rg_screen": [vp, C.POINTER(vp)], "rg_hist": [vp, C.POINTER(vp)], "rg_status": [vp, C.POINTER(vp)], "rg_flags": [vp, C.POINTER(vp)],
+        "rg_reward": [vp, C.POINTER(vp)], "rg_done": [vp, C.POINTER(vp)],
+        "rg_obs_gray": [vp, u32, i32, vp], "rg_obs_symbol": [vp, u32, i32, vp], "rg_obs_channels": [vp, i32, u32, i32],
+        "rg_fetch_states": [vp, vp, vp, vp, vp],
+        "rg_encode_host": [i32, vp, vp, vp, i32, i32, i32, u32, i32, i32, vp],
+        "rg_encode_host_batch": [i32, i32, vp, vp, vp, i32, i32, i32, u32, i32, i32, vp],
+        "rg_obs_host": [vp, i32, u32, i32, vp],
+        "rg_host_alloc": [sz, C.POINTER(vp)], "rg_host_free": [vp],
+        "rg_compact_record_bytes": [vp, i32], "rg_pack_compact": [vp, i32, vp], "rg_expand_compact": [vp, vp, i32, i32, i32, u32, i32, vp],
+        "rg_status_vec": [vp, u32, vp],
+        "rg_history_enable": [vp, i32], "rg_history_keys": [vp, i32, i32, vp, sz, C.POINTER(u32)],
+        "rg_dump_history": [vp, i32, i32, C.c_char_p, sz, C.POINTER(sz)],
+        "rg_counters": [vp, C.POINTER(C.c_uint64), i32], "rg_probe_sclk": [vp, C.POINTER(C.c_double)],
+        "rg_timing_enable": [vp, i32], "rg_timing_read": [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
+        "rg_dump_config": [vp, i32, C.c_char_p, sz], "rg_config_canonical": [C.c_char_p, C.c_char_p, sz],
+        "rg_debug_fetch": [vp, i32, C.POINTER(RgDebugState), vp], "rg_debug_descend": [vp],
+    }
+    for name, argtypes in sig.items():
+        getattr(L, name).argtypes = argtypes
     L.rg_destroy.restype = None
-    L.rg_last_error.argtypes = [vp]
+    L.rg_host_free.restype = None
     L.rg_last_error.restype = C.c_char_p
-    L.rg_dims.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
-    L.rg_set_stream.argtypes = [vp, vp]
-    L.rg_seed.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
-    L.rg_reset.argtypes = [vp]
-    L.rg_step.argtypes = [vp, vp, C.c_int]
-    L.rg_sync.argtypes = [vp]
-    L.rg_screen.argtypes = [vp, C.POINTER(vp)]
-    L.rg_hist.argtypes = [vp, C.POINTER(vp)]
-    L.rg_status.argtypes = [vp, C.POINTER(vp)]
-    L.rg_flags.argtypes = [vp, C.POINTER(vp)]
-    L.rg_reward.argtypes = [vp, C.POINTER(vp)]
-    L.rg_done.argtypes = [vp, C.POINTER(vp)]
-    L.rg_obs_gray.argtypes = [vp, C.c_uint32, C.c_int, vp]
-    L.rg_obs_symbol.argtypes = [vp, C.c_uint32, C.c_int, vp]
-    L.rg_obs_channels.argtypes = [vp, C.c_int, C.c_uint32, C.c_int]
-    L.rg_fetch_states.argtypes = [vp, vp, vp, vp, vp]
-    L.rg_encode_host.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, vp]
-    L.rg_timing_enable.argtypes = [vp, C.c_int]
-    L.rg_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
-    L.rg_dump_config.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
-    L.rg_config_canonical.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
-    L.rg_debug_fetch.argtypes = [vp, C.c_int, C.POINTER(RgDebugState), vp]
-    for f in ("rg_create", "rg_dims", "rg_set_stream", "rg_seed", "rg_reset", "rg_step", "rg_sync", "rg_screen", "rg_hist", "rg_status", "rg_flags",
-              "rg_reward", "rg_done", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_dump_config", "rg_config_canonical", "rg_debug_fetch", "rg_timing_enable", "rg_timing_read"):
-        getattr(L, f).restype = C.c_int
-    _ = (u8p, i32p, u32p, f32p)
+    for name in _INT_FUNCS:
+        getattr(L, name).restype = C.c_int
     _lib = L
     return L
 
 
 def _default_device():
     return int(os.environ.get("ROGUE_GYM_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+class _PinnedPool:
+    """Page-locked host buffers for the per-step D2H copies of the value-object API.  A StateBatch borrows its buffers and hands them back
+    when it is collected, so a stepping loop settles on two or three buffer sets and the copies run at full PCIe rate."""
+
+    def __init__(self, L):
+        self.L, self.free, self.closed = L, {}, False
+
+    def take(self, nbytes):
+        lst = self.free.get(nbytes)
+        if lst:
+            return lst.pop()
+        p = C.c_void_p()
+        if self.L.rg_host_alloc(nbytes, C.byref(p)):
+            raise RuntimeError("Error in rogue-gym: " + self.L.rg_last_error(None).decode())
+        return p.value
+
+    def give(self, ptr, nbytes):
+        if self.closed:
+            self.L.rg_host_free(C.c_void_p(ptr))
+        else:
+            self.free.setdefault(nbytes, []).append(ptr)
+
+    def close(self):
+        self.closed = True
+        for lst in self.free.values():
+            for ptr in lst:
+                self.L.rg_host_free(C.c_void_p(ptr))
+        self.free = {}
+
+
+def _view(ptr, shape, dtype):
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    return np.frombuffer((C.c_uint8 * n).from_address(ptr), dtype=dtype).reshape(shape)
 
 
 class _Handle:
@@ -119,6 +166,8 @@ class _Handle:
         hh, ww, ss, nn = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         L.rg_dims(h, C.byref(hh), C.byref(ww), C.byref(ss), C.byref(nn))
         self.height, self.width, self.symbols, self.n = hh.value, ww.value, ss.value, nn.value
+        self.pool = _PinnedPool(L)
+        self.epoch = 0  # bumped by every call that changes the device-side states (a StateBatch remembers the epoch it was taken at)
 
     def check(self, rc):
         if rc:
@@ -128,6 +177,7 @@ class _Handle:
         if getattr(self, "h", None):
             self.L.rg_destroy(self.h)
             self.h = None
+            self.pool.close()
 
     def __del__(self):
         try:
@@ -136,18 +186,21 @@ class _Handle:
             pass
 
     def fetch(self):
-        n, hw = self.n, self.height * self.width
+        """Fresh numpy copies of the mirrors (screen, hist, status, flags)."""
+        n = self.n
         screen = np.empty((n, self.height, self.width), np.uint8)
         hist = np.empty((n, self.height, self.width), np.uint8)
         status = np.empty((n, 10), np.int32)
         flags = np.empty(n, np.uint32)
         self.check(self.L.rg_fetch_states(self.h, screen.ctypes.data, hist.ctypes.data, status.ctypes.data, flags.ctypes.data))
-        _ = hw
         return screen, hist, status, flags
 
+    def snapshot(self):
+        """The current states of all envs as one StateBatch (one D2H copy into pinned memory)."""
+        return StateBatch(self)
+
     def states(self):
-        screen, hist, status, flags = self.fetch()
-        return [PlayerState(screen[i], hist[i], status[i], self.symbols, int(flags[i]), self.device) for i in range(self.n)]
+        return self.snapshot()
 
     def debug_state(self, env):
         out = RgDebugState()
@@ -155,12 +208,120 @@ class _Handle:
         self.check(self.L.rg_debug_fetch(self.h, env, C.byref(out), cells.ctypes.data))
         return out, cells
 
+    def history_keys(self, env, previous=False):
+        n = C.c_uint32()
+        rc = self.L.rg_history_keys(self.h, env, int(previous), None, 0, C.byref(n))
+        self.check(rc)
+        buf = (C.c_uint8 * max(1, n.value))()
+        self.check(self.L.rg_history_keys(self.h, env, int(previous), buf, len(buf), C.byref(n)))
+        return bytes(buf[: n.value])
+
+    def dump_history(self, env, previous=False):
+        need = C.c_size_t()
+        self.check(self.L.rg_dump_history(self.h, env, int(previous), None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value)
+        self.check(self.L.rg_dump_history(self.h, env, int(previous), buf, need.value, None))
+        return buf.value.decode()
+
+
+_IMAGE_BATCH_LIMIT = 1 << 28  # bytes: above this a batch does not cache whole-batch images (one-hot images of large batches are GBs)
+
+
+class StateBatch:
+    """What ParallelGameState::states/step/reset return (`Vec<PlayerState>`, python/src/lib.rs:308-328), kept as ONE snapshot of the batch
+    instead of n Python objects: a read-only sequence whose items are PlayerState views, plus vector accessors (gold, dungeon_level,
+    is_terminal) and whole-batch images computed by one kernel launch."""
+
+    def __init__(self, handle):
+        self._hd = handle
+        n, h, w = handle.n, handle.height, handle.width
+        self.n, self.symbols = n, handle.symbols
+        sizes = (n * h * w, n * h * w, n * 40, n * 4)
+        self._bufs = [(handle.pool.take(b), b) for b in sizes]
+        p = [b[0] for b in self._bufs]
+        handle.check(handle.L.rg_fetch_states(handle.h, p[0], p[1], p[2], p[3]))
+        self.screen = _view(p[0], (n, h, w), np.uint8)
+        self.hist = _view(p[1], (n, h, w), np.uint8)
+        self.status = _view(p[2], (n, 10), np.int32)
+        self.flags = _view(p[3], (n,), np.uint32)
+        self._epoch = handle.epoch
+        self._items = {}
+        self._images = {}
+
+    def __del__(self):
+        try:
+            for ptr, nbytes in self._bufs:
+                self._hd.pool.give(ptr, nbytes)
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(self.n))]
+        if i < 0:
+            i += self.n
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        st = self._items.get(i)
+        if st is None:
+            st = self._items[i] = PlayerState(self.screen[i], self.hist[i], self.status[i], self.symbols, int(self.flags[i]), self._hd.device, batch=self, index=i)
+        return st
+
+    def __iter__(self):
+        return (self[i] for i in range(self.n))
+
+    def __eq__(self, other):
+        if isinstance(other, StateBatch):
+            other = list(other)
+        return list(self) == other
+
+    @property
+    def gold(self):
+        return self.status[:, 1]
+
+    @property
+    def dungeon_level(self):
+        return self.status[:, 0]
+
+    @property
+    def is_terminal(self):
+        return (self.flags & RG_FLAG_TERMINAL) != 0
+
+    def status_vec(self, flag):
+        cols = [c for b, c in enumerate((0, 2, 3, 4, 5, 6, 7, 8, 9)) if int(flag) & (1 << b)]  # StatusFlagInner::to_vector (flags.rs:67-87)
+        return self.status[:, cols]
+
+    def images(self, kind, flag, with_hist):
+        """f32 [n, C, H, W]: PlayerState::{gray,symbol}_image[_with_hist] of every state of the batch."""
+        flag = 0 if flag is None else int(flag) & 0x1FF
+        key = (int(kind), flag, bool(with_hist))
+        img = self._images.get(key)
+        if img is not None:
+            return img
+        hd, L = self._hd, self._hd.L
+        h, w = self.screen.shape[1:]
+        c = (self.symbols if kind else 1) + bin(flag).count("1") + (1 if with_hist else 0)
+        img = np.empty((self.n, c, h, w), np.float32)
+        if hd.h is not None and hd.epoch == self._epoch:
+            hd.check(L.rg_obs_host(hd.h, int(kind), flag, int(with_hist), img.ctypes.data))  # the device still holds exactly these states
+        else:  # the envs have moved on: encode the snapshot itself
+            rc = L.rg_encode_host_batch(hd.device, self.n, self.screen.ctypes.data, self.hist.ctypes.data, self.status.ctypes.data, h, w, self.symbols, flag,
+                                        int(with_hist), int(kind), img.ctypes.data)
+            if rc:
+                raise RuntimeError("Error in rogue-gym: " + L.rg_last_error(None).decode())
+        if img.nbytes <= _IMAGE_BATCH_LIMIT:
+            self._images[key] = img
+        return img
+
 
 class PlayerState:
     """A memory efficient representation of Agent observation (python/src/lib.rs:27-206): a value
     object holding host copies of the mirror screen, history plane, status and flags."""
 
-    def __init__(self, screen, hist, status, symbols, flags, device=0):
+    def __init__(self, screen, hist, status, symbols, flags, device=0, batch=None, index=0):
         self._map = np.ascontiguousarray(screen, np.uint8)
         self._hist = np.ascontiguousarray(hist, np.uint8)
         self._status = np.ascontiguousarray(status, np.int32)
@@ -168,6 +329,7 @@ class PlayerState:
         self._flags = int(flags)
         self._terminal = bool(flags & RG_FLAG_TERMINAL)
         self._device = device
+        self._batch, self._index = batch, index  # keeps the batch (and its pinned buffers) alive while this view exists
 
     def __repr__(self):
         s = self._status  # Status::fmt (player.rs:433-449)
@@ -218,9 +380,12 @@ class PlayerState:
 
     def _image(self, kind, flag, with_hist):
         flag = 0 if flag is None else int(flag)
-        L = load_library()
         h, w = self._map.shape
         c = (self._symbols if kind else 1) + bin(flag & 0x1FF).count("1") + (1 if with_hist else 0)
+        b = self._batch
+        if b is not None and b.n * c * h * w * 4 <= _IMAGE_BATCH_LIMIT:
+            return b.images(kind, flag, with_hist)[self._index].copy()  # one launch serves every state of the batch
+        L = load_library()
         out = np.empty((c, h, w), np.float32)
         rc = L.rg_encode_host(self._device, self._map.ctypes.data, self._hist.ctypes.data, self._status.ctypes.data, h, w, self._symbols,
                               flag, int(with_hist), kind, out.ctypes.data)
@@ -241,18 +406,15 @@ class PlayerState:
         return self._image(1, flag, True)
 
 
-_KEY_TO_INPUT = {  # KeyMap::ai (input.rs:73-100) -> serde form of InputCode, for dump_history
-    "l": "Right", "k": "Up", "j": "Down", "h": "Left", "u": "RightUp", "y": "LeftUp", "n": "RightDown", "b": "LeftDown",
-}
+_HISTORY_CAP_MAX = 1 << 20
 
 
-def _input_code(key):
-    ch = chr(key)
-    if ch in _KEY_TO_INPUT:
-        return {"Act": {"Move": _KEY_TO_INPUT[ch]}}
-    if ch.lower() in _KEY_TO_INPUT and ch.isupper():
-        return {"Act": {"MoveUntil": _KEY_TO_INPUT[ch.lower()]}}
-    return {"Act": {".": "NoOp", "s": "Search", ">": "DownStair"}[ch]}
+def _keys_array(input):
+    if isinstance(input, (bytes, bytearray)):
+        return np.frombuffer(bytes(input), np.uint8)
+    if isinstance(input, np.ndarray):
+        return np.ascontiguousarray(input.astype(np.int64) & 0xFF, dtype=np.uint8)
+    return np.ascontiguousarray(np.fromiter((int(k) & 0xFF for k in input), dtype=np.int64), dtype=np.uint8)
 
 
 class GameState:
@@ -261,8 +423,8 @@ class GameState:
     def __init__(self, max_steps, config_str=None, device=None):
         self._h = _Handle([config_str], max_steps, auto_reset=False, device=device)
         self._max_steps = int(max_steps)
-        self._steps = 0
-        self._history = []
+        # saved_inputs lives on the device: react() beyond max_steps + 1 keys is a no-op, so the log never outgrows that
+        self._h.check(self._h.L.rg_history_enable(self._h.h, min(self._max_steps + 2, _HISTORY_CAP_MAX)))
         self._prev = None
 
     def screen_size(self):
@@ -275,32 +437,23 @@ class GameState:
 
     def reset(self):
         self._h.check(self._h.L.rg_reset(self._h.h))
-        self._steps = 0
-        self._history = []
+        self._h.epoch += 1
         self._prev = None
 
     def prev(self):
         if self._prev is None:
-            self._prev = self._h.states()[0]
+            self._prev = self._h.snapshot()[0]
         return self._prev
 
     def react(self, input):
-        key = int(input) & 0xFF
-        keys = (C.c_uint8 * 1)(key)
-        if self._steps > self._max_steps:
-            return
+        keys = (C.c_uint8 * 1)(int(input) & 0xFF)
         self._h.check(self._h.L.rg_step(self._h.h, keys, 0))
-        rc = self._h.L.rg_sync(self._h.h)
-        if rc:
-            if chr(key) in "hjklyubnHJKLYUBN.s>":
-                self._history.append(_input_code(key))  # saved_inputs.push precedes the IgnoredInput error (core/src/lib.rs:288)
-            self._h.check(rc)
-        self._history.append(_input_code(key))
-        self._steps += 1
+        self._h.epoch += 1
         self._prev = None
+        self._h.check(self._h.L.rg_sync(self._h.h))
 
     def dump_history(self):
-        return json.dumps(self._history, indent=2)
+        return self._h.dump_history(0)
 
     def dump_config(self):
         buf = C.create_string_buffer(1 << 16)
@@ -313,10 +466,13 @@ class GameState:
 
 class ParallelGameState:
     """python/src/lib.rs:260-335: the reference's one-OS-thread-per-env ThreadConductor becomes one
-    batched kernel launch; envs auto-reset on terminal (thread_impls.rs:69-79)."""
+    batched kernel launch; envs auto-reset on terminal (thread_impls.rs:69-79).  states/step/reset return a StateBatch
+    (a sequence of PlayerState, like the reference's Vec<PlayerState>)."""
 
-    def __init__(self, max_steps, configs, device=None):
+    def __init__(self, max_steps, configs, device=None, history=0):
         self._h = _Handle(list(configs), max_steps, auto_reset=True, device=device)
+        if history:
+            self.enable_history(history)
 
     def screen_size(self):
         return (self._h.height, self._h.width)
@@ -325,26 +481,43 @@ class ParallelGameState:
         return self._h.symbols
 
     def seed(self, seed):
-        seed = list(seed)[: self._h.n]
+        seed = [int(s) for s in seed][: self._h.n]  # zip (thread_impls.rs:45-50)
         n = len(seed)
-        lo = (C.c_uint64 * n)(*[int(s) & 0xFFFFFFFFFFFFFFFF for s in seed])
-        hi = (C.c_uint64 * n)(*[(int(s) >> 64) & 0xFFFFFFFFFFFFFFFF for s in seed])
+        if n == 0:
+            return
+        lo = (C.c_uint64 * n)(*[s & 0xFFFFFFFFFFFFFFFF for s in seed])
+        hi = (C.c_uint64 * n)(*[(s >> 64) & 0xFFFFFFFFFFFFFFFF for s in seed])
         self._h.check(self._h.L.rg_seed(self._h.h, lo, hi, n))
 
     def states(self):
-        return self._h.states()
+        return self._h.snapshot()
 
     def step(self, input):
-        keys = np.ascontiguousarray(np.asarray(list(input), dtype=np.int64) & 0xFF, dtype=np.uint8)
-        if keys.shape[0] < self._h.n:  # zip semantics (thread_impls.rs:62-64): missing keys leave an env unstepped; we require all
-            raise RuntimeError("Error in rogue-gym: expected %d keys, got %d" % (self._h.n, keys.shape[0]))
-        self._h.check(self._h.L.rg_step(self._h.h, keys.ctypes.data, 0))
+        """One key per env.  Like ThreadConductor::step the keys are zipped with the envs (thread_impls.rs:62-64): surplus keys are dropped,
+        and with fewer keys than envs only that prefix is stepped (the reference would then wait forever for the others' replies)."""
+        keys = _keys_array(input)
+        self._h.check(self._h.L.rg_step_prefix(self._h.h, keys.ctypes.data, int(keys.shape[0]), 0))
+        self._h.epoch += 1
         self._h.check(self._h.L.rg_sync(self._h.h))
-        return self._h.states()
+        return self._h.snapshot()
 
     def reset(self):
         self._h.check(self._h.L.rg_reset(self._h.h))
-        return self._h.states()
+        self._h.epoch += 1
+        return self._h.snapshot()
+
+    def dump_config(self, env=0):
+        buf = C.create_string_buffer(1 << 16)
+        self._h.check(self._h.L.rg_dump_config(self._h.h, int(env), buf, len(buf)))
+        return buf.value.decode()
+
+    def enable_history(self, cap_per_env):
+        """Keep the keys of the running and of the previous episode of every env on the device (not part of the reference's API)."""
+        self._h.check(self._h.L.rg_history_enable(self._h.h, int(cap_per_env)))
+
+    def dump_history(self, env, previous=False):
+        """GameState::dump_history for env `env` of the batch; previous=True: the episode that ended with the last auto-reset."""
+        return self._h.dump_history(int(env), previous)
 
     def close(self):
         self._h.close()

@@ -5,6 +5,7 @@ Inputs are data, not code: the expected screens / key strings held by the refere
 test_parallel.py / core/src/dungeon/rogue/mod.rs:566-578, and the JSON config + replay assets under
 /root/reference/data.  /root/reference does not exist on the GPU box; the committed JSON does.
 """
+import hashlib
 import importlib.util
 import json
 import os
@@ -79,6 +80,9 @@ golden = {
         "shapes": {"symbol_hist_noenem": [18, 24, 80], "gray": [1, 24, 80], "gray_hist": [2, 24, 80], "space_noenem_full": [26, 24, 80]},
     },
     "ddqn_keys": actions_to_keys(load("data/learned/ddqn-minidungeon/best-actions.json")),
+    # digest of the reference's own serialisation of that key log (RunTime::saved_inputs_as_json = serde_json::to_string_pretty): the
+    # action-history dump of the HIP stepper must reproduce the file byte for byte (trailing newline excluded)
+    "ddqn_actions_sha256": hashlib.sha256(open(os.path.join(REF, "data/learned/ddqn-minidungeon/best-actions.json")).read().rstrip("\n").encode()).hexdigest(),
 }
 
 with open(os.path.join(OUT, "reference_goldens.json"), "w") as f:

@@ -1,6 +1,7 @@
-"""World-size-2 gloo test of the N>1 path on CPU: env sharding arithmetic + the compact observation
-all-gather + consumer-side gray expansion.  Each rank steps its shard with the CPU oracle (stand-in for the
-per-rank HIP stepper, which needs a GPU); rank 0 checks the gathered batch against a single-process run."""
+"""World-size-2 gloo test of the N>1 path on CPU: env sharding arithmetic + the ONE all-gather of the packed compact records + the record
+layout the consumer unpacks.  Each rank steps its shard with the CPU oracle (stand-in for the per-rank HIP stepper, which needs a GPU --
+tests/test_gpu_distributed.py runs the same flow with the HIP stepper on both ranks); rank 0 checks the gathered batch against a
+single-process run."""
 import json
 import os
 import socket
@@ -28,7 +29,7 @@ def _worker(rank, world, port, n_total, steps, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle.pyoracle import OracleEnv
-    from rogue_gym.envs.sharding import all_gather_compact, expand_gray, shard_range
+    from rogue_gym.envs.sharding import all_gather_packed, record_layout, shard_range, unpack_records
 
     cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_goldens.json")))["configs"]["mini"]
     first, last = shard_range(n_total, rank, world)
@@ -39,12 +40,17 @@ def _worker(rank, world, port, n_total, steps, q):
         keys = acts[rng.randint(0, 11, n_total)]  # same global action tensor on every rank
         for j, e in enumerate(envs):
             e.step_autoreset(int(keys[first + j]))
-    screen = torch.from_numpy(np.stack([e.screen() for e in envs]))
-    status = torch.from_numpy(np.stack([e.status_arr().astype(np.int32) for e in envs]))
-    scr, st = all_gather_compact(screen, status)
-    gray = expand_gray(scr, 43)
+    # the record rg_pack_compact writes per env: screen bytes, status i32[10], history bytes
+    o_scr, o_st, o_hist, rec = record_layout(16, 32, with_hist=True)
+    packed = np.zeros((len(envs), rec), np.uint8)
+    for j, e in enumerate(envs):
+        packed[j, o_scr:o_st] = e.screen().reshape(-1)
+        packed[j, o_st:o_st + 40] = e.status_arr().astype(np.int32).view(np.uint8)
+        packed[j, o_hist:] = e.hist().reshape(-1)
+    gathered = all_gather_packed(torch.from_numpy(packed))  # ONE collective
+    scr, st, hist = unpack_records(gathered, 16, 32, with_hist=True)
     if rank == 0:
-        q.put((scr.numpy(), st.numpy(), gray.numpy()))
+        q.put((scr.numpy(), st.numpy(), hist.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,7 +78,7 @@ def test_world2_gloo_gather_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    scr, st, gray = q.get(timeout=100)
+    scr, st, hist = q.get(timeout=100)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -87,4 +93,4 @@ def test_world2_gloo_gather_matches_single_process():
     for i, e in enumerate(envs):
         assert np.array_equal(scr[i], e.screen())
         assert np.array_equal(st[i], e.status_arr().astype(np.int32))
-        assert np.array_equal(gray[i], e.gray_image(0))
+        assert np.array_equal(hist[i], e.hist())

@@ -1,0 +1,337 @@
+"""Round-2 boundary features of the HIP stepper, through the C-ABI / the drop-in package: action-history log, full GameConfig
+coverage (8f-3: seed_range, varied rates, room limit), ThreadConductor's zip semantics, the compact pack/expand path of the multi-GPU
+gather (8e), the batched value-object image path, workload counters."""
+import ctypes as C
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+from parity_util import ACTION_KEYS, ALL_KEYS, HipBatch, compare_internal, compare_mirrors, lockstep, make_oracles
+
+pytestmark = pytest.mark.gpu
+
+INPUT_TO_KEY = {"Right": "l", "Up": "k", "Down": "j", "Left": "h", "RightUp": "u", "LeftUp": "y", "RightDown": "n", "LeftDown": "b"}
+
+
+def keys_of_history(text):
+    """The reference's InputCode JSON -> ai-keymap keys (input.rs:73-100)."""
+    out = []
+    for item in json.loads(text):
+        act = item["Act"]
+        if isinstance(act, str):
+            out.append({"NoOp": ".", "Search": "s", "DownStair": ">"}[act])
+        elif "Move" in act:
+            out.append(INPUT_TO_KEY[act["Move"]])
+        else:
+            out.append(INPUT_TO_KEY[act["MoveUntil"]].upper())
+    return "".join(out)
+
+
+def test_history_dump_reproduces_reference_action_log(goldens, tmp_path):
+    """Replaying data/learned/ddqn-minidungeon/best-actions.json (as keys) and dumping the history gives the reference's own file back,
+    byte for byte (core/src/lib.rs:288,357-375; python/src/lib.rs:245-250); re-feeding the dump reproduces the final state."""
+    from rogue_gym.envs import RogueEnv
+
+    keys = goldens["ddqn_keys"]
+    env = RogueEnv(config_dict=dict(goldens["configs"]["ddqn"]), max_steps=2000)
+    for k in keys:
+        env.step(k)
+    dump = env.game.dump_history()
+    assert hashlib.sha256(dump.encode()).hexdigest() == goldens["ddqn_actions_sha256"]
+    assert keys_of_history(dump) == keys
+    env.save_actions(str(tmp_path / "actions.json"))
+    assert open(tmp_path / "actions.json").read() == dump
+    # the trajectory ends on level 2 with gold 4, hp 12/12
+    st = env.result.status
+    assert (st["dungeon_level"], st["gold"], st["hp_current"], st["hp_max"]) == (2, 4, 12, 12)
+    again = RogueEnv(config_dict=dict(goldens["configs"]["ddqn"]), max_steps=2000)
+    again.step(keys_of_history(dump))
+    assert again.result == env.result
+    assert again.game.dump_history() == dump
+    # a rebuilt RunTime starts an empty log
+    env.reset()
+    assert env.game.dump_history() == "[]"
+    env.step("Hs.>")
+    assert json.loads(env.game.dump_history()) == [{"Act": {"MoveUntil": "Left"}}, {"Act": "Search"}, {"Act": "NoOp"}, {"Act": "DownStair"}]
+
+
+def test_history_batched_with_autoreset(goldens):
+    """The device-side log for batched envs: running episode + the episode that ended with the last auto-reset."""
+    from rogue_gym_python._rogue_gym import ParallelGameState
+
+    n, max_steps = 64, 25
+    cfgs = [json.dumps(dict(goldens["configs"]["mini"], seed=i)) for i in range(n)]
+    game = ParallelGameState(max_steps, cfgs, history=max_steps + 1)
+    rng = np.random.RandomState(4)
+    log = [[] for _ in range(n)]     # keys of the running episode, per env
+    prev = [None] * n
+    for t in range(90):
+        keys = ACTION_KEYS[rng.randint(0, 11, n)]
+        states = game.step(keys)
+        done = states.is_terminal
+        for i in range(n):
+            log[i].append(chr(keys[i]))
+            if done[i]:
+                prev[i], log[i] = log[i], []
+    for i in range(0, n, 5):
+        assert keys_of_history(game.dump_history(i)) == "".join(log[i])
+        if prev[i] is not None:
+            assert keys_of_history(game.dump_history(i, previous=True)) == "".join(prev[i])
+    # a replay of a finished episode on a fresh single env ends terminal exactly at its last key
+    from rogue_gym.envs import RogueEnv
+    i = next(k for k in range(n) if prev[k] is not None)
+    env = RogueEnv(config_dict=dict(goldens["configs"]["mini"], seed=i), max_steps=max_steps)
+    # prev[i] is the LAST finished episode; seeds are fixed, so every episode of env i starts from the same level-1 state
+    _, _, done, _ = env.step("".join(prev[i]))
+    assert done
+    game.close()
+
+
+def test_history_truncation_is_loud(goldens):
+    h = HipBatch(goldens["configs"]["mini"], [1, 2], max_steps=1000)
+    h.h.check(h.h.L.rg_history_enable(h.h.h, 4))
+    for _ in range(6):
+        h.step(np.frombuffer(b"hh", np.uint8))
+    n = C.c_uint32()
+    assert h.h.L.rg_history_keys(h.h.h, 0, 0, None, 0, C.byref(n)) == 2 and n.value == 6
+    with pytest.raises(RuntimeError, match="truncated"):
+        h.h.dump_history(0)
+
+
+def test_step_prefix_zip_semantics(goldens):
+    """ThreadConductor::step zips keys with envs (thread_impls.rs:62-64): fewer keys step a prefix, surplus keys are dropped."""
+    from rogue_gym_python._rogue_gym import ParallelGameState
+
+    cfg = goldens["configs"]["mini"]
+    n = 12
+    game = ParallelGameState(1000, [json.dumps(dict(cfg, seed=3))] * n)
+    ref = ParallelGameState(1000, [json.dumps(dict(cfg, seed=3))] * n)
+    before = game.states()
+    after = game.step(b"l" * 5)            # only envs 0..4 receive the key
+    full = ref.step(b"l" * (n + 7))        # surplus keys are dropped
+    for i in range(n):
+        assert after[i] == (full[i] if i < 5 else before[i])
+    game.close(); ref.close()
+
+
+def test_seed_range_is_honoured_on_every_build(goldens):
+    """`seed: None` + `seed_range`: rng::gen_ranged_seed on EVERY GameConfig::build (core/src/lib.rs:157-165) -- creation, rg_reset, the
+    auto-reset inside rg_step and the background spare levels all stay inside the range."""
+    from rogue_gym_python._rogue_gym import ParallelGameState
+
+    cfg = dict(goldens["configs"]["mini"])
+    cfg.pop("seed", None)
+    # a range whose 12 first screens are pairwise distinct and differ from those of the 200 seeds after it, so that "the screen is one of the
+    # range's" really says "the seed was inside the range"
+    for lo in range(1000, 3000, 50):
+        hi = lo + 12
+        inside = [bytes(s.tobytes()) for s in HipBatch(goldens["configs"]["mini"], list(range(lo, hi))).fetch()[0]]
+        after = {bytes(s.tobytes()) for s in HipBatch(goldens["configs"]["mini"], list(range(hi, hi + 200))).fetch()[0]}
+        if len(set(inside)) == 12 and not set(inside) & after:
+            break
+    else:
+        pytest.fail("no discriminating seed range found")
+    allowed = set(inside)
+    cfg["seed_range"] = [lo, hi]
+    n = 512
+    game = ParallelGameState(6, [json.dumps(cfg)] * n)
+    seen = set()
+
+    def check(states, where):
+        for i in range(n):
+            if where == "create" or states.is_terminal[i] or where == "reset":
+                b = bytes(states.screen[i].tobytes())
+                assert b in allowed, "%s: env %d was built from a seed outside [%d, %d)" % (where, i, lo, hi)
+                seen.add(b)
+
+    check(game.states(), "create")
+    for t in range(40):  # max_steps 6: every env auto-resets every 6 steps (spares + inline generation both occur)
+        st = game.step(b"." * n)
+        check(st, "step %d" % t)
+    check(game.reset(), "reset")
+    assert seen == allowed  # 512 envs x ~8 builds over 12 seeds: every seed of the range shows up
+    assert json.loads(game.dump_config())["seed_range"] == [lo, hi]
+    game.close()
+    with pytest.raises(RuntimeError, match="seed_range"):
+        ParallelGameState(6, [json.dumps(dict(cfg, seed_range=[5, 5]))])
+
+
+def test_seed_none_draws_distinct_seeds(goldens):
+    from rogue_gym_python._rogue_gym import ParallelGameState
+
+    cfg = dict(goldens["configs"]["mini"])
+    cfg.pop("seed", None)
+    game = ParallelGameState(4, [json.dumps(cfg)] * 256)
+    shots = {bytes(s.tobytes()) for s in game.states().screen}
+    for _ in range(8):
+        st = game.step(b"." * 256)
+        shots |= {bytes(st.screen[i].tobytes()) for i in range(256) if st.is_terminal[i]}
+    assert len(shots) > 500  # 256 x 3 builds, (nearly) all different
+    game.close()
+
+
+VARIED = {
+    "rich_dark_mazy": {"dungeon": {"style": "rogue", "room_num_x": 2, "room_num_y": 2, "dark_level": 1, "maze_rate_inv": 2, "max_empty_rooms": 2,
+                                   "hidden_passage_rate_inv": 2, "locked_door_rate_inv": 2, "max_extra_edges": 3,
+                                   "door_unlock_rate_inv": 2, "passage_unlock_rate_inv": 2},
+                       "item": {"gold": {"rate_inv": 1, "base": 7, "per_level": 31, "minimum": 5}}},
+    "poor_bright": {"dungeon": {"style": "rogue", "room_num_x": 2, "room_num_y": 2, "dark_level": 1000, "maze_rate_inv": 1, "max_empty_rooms": 0,
+                                "hidden_passage_rate_inv": 1000, "locked_door_rate_inv": 1000, "max_extra_edges": 1, "amulet_level": 2},
+                    "item": {"gold": {"rate_inv": 5, "base": 1, "per_level": 1, "minimum": 0}},
+                    "player": {"hunger_time": 60, "init_hp": 40},
+                    "enemies": {"appear_rate_gold": 100, "appear_rate_nogold": 100}},
+}
+
+
+@pytest.mark.parametrize("name", sorted(VARIED))
+def test_lockstep_varied_rates(goldens, name):
+    """8f-3: gold / dark / maze / hidden / locked / unlock rates, max_empty_rooms, amulet_level, hunger_time, init_hp, appear rates varied
+    away from their defaults (rogue/mod.rs:23-134, item/gold.rs:6-52, player.rs:37-66, enemies.rs:56-85), lock step against the oracle."""
+    cfg = dict(goldens["configs"]["mini"])
+    cfg.update(VARIED[name])
+    rng = np.random.RandomState(21)
+    table = np.frombuffer(b"hjklyubnHJKLYUBN>>>ss.", np.uint8)
+    keys = [table[rng.randint(0, len(table), 192)] for _ in range(350)]
+    lockstep(cfg, list(range(500, 692)), keys, max_steps=200, check_every=1, internal_every=35)
+
+
+def test_lockstep_varied_rates_default_size(goldens):
+    cfg = dict(goldens["configs"]["default"])
+    cfg["dungeon"] = {"style": "rogue", "room_num_x": 4, "room_num_y": 2, "dark_level": 2, "maze_rate_inv": 3, "max_empty_rooms": 5,
+                      "hidden_passage_rate_inv": 3, "locked_door_rate_inv": 3, "max_extra_edges": 9}
+    cfg["item"] = {"gold": {"rate_inv": 3, "base": 100, "per_level": 0, "minimum": 1}}
+    rng = np.random.RandomState(5)
+    table = np.frombuffer(b"hjklyubnHJKLYUBN>>s", np.uint8)
+    keys = [table[rng.randint(0, len(table), 96)] for _ in range(300)]
+    lockstep(cfg, list(range(96)), keys, max_steps=150, check_every=1, internal_every=50)
+
+
+def test_room_limit_is_a_loud_error(goldens):
+    """The reference has no room-count limit (rooms.rs:165-211); the HIP stepper's room bitmasks hold 32.  33+ rooms must fail at creation
+    with a message naming the limit, never silently."""
+    from rogue_gym_python._rogue_gym import GameState
+
+    big = {"width": 160, "height": 48, "seed": 1, "dungeon": {"style": "rogue", "room_num_x": 11, "room_num_y": 3}}
+    with pytest.raises(RuntimeError, match="room_num_x \\* room_num_y must be in 1..=32"):
+        GameState(100, json.dumps(big))
+    ok = dict(big, dungeon={"style": "rogue", "room_num_x": 8, "room_num_y": 4})  # exactly 32 rooms
+    rng = np.random.RandomState(9)
+    keys = [ALL_KEYS[rng.randint(0, len(ALL_KEYS), 24)] for _ in range(120)]
+    lockstep(ok, list(range(24)), keys, max_steps=100, check_every=4, internal_every=40)
+
+
+def test_many_extra_edges_fit_the_corridor_table(goldens):
+    """max_extra_edges far above the number of adjacent room pairs: every pair gets joined at most once, so the corridor table
+    (RG_MAX_EDGES = 2 x rooms) cannot overflow and no env raises the internal-guard error."""
+    cfg = {"width": 160, "height": 48, "dungeon": {"style": "rogue", "room_num_x": 8, "room_num_y": 4, "max_extra_edges": 400}, "enemies": {"enemies": []}}
+    seeds = list(range(40))
+    hip = HipBatch(cfg, seeds)
+    oracles = make_oracles(cfg, seeds)
+    compare_mirrors(hip, oracles, "edges")
+    compare_internal(hip, oracles, range(0, 40, 3), "edges")
+    hip.sync()  # would raise on RG_FLAG_ERR_INTERNAL
+
+
+def test_big_maze_needs_the_full_dfs_stack(goldens):
+    """One room filling a 160x48 screen: a maze of 80 x 23 nodes, DFS depth far beyond the old 512-entry stack."""
+    cfg = {"width": 160, "height": 48, "hide_dungeon": False, "enemies": {"enemies": []},
+           "dungeon": {"style": "rogue", "room_num_x": 1, "room_num_y": 1, "dark_level": 1, "maze_rate_inv": 1, "max_empty_rooms": 0}}
+    seeds = list(range(12))
+    hip = HipBatch(cfg, seeds)
+    oracles = make_oracles(cfg, seeds)
+    compare_mirrors(hip, oracles, "maze")
+    compare_internal(hip, oracles, range(12), "maze")
+    hip.sync()
+
+
+@pytest.mark.parametrize("name", ["mini", "nohide"])
+def test_pack_expand_compact_equals_direct_obs(goldens, name):
+    """Multi-GPU path: rg_pack_compact -> (all-gather) -> rg_expand_compact gives exactly the tensors rg_obs_* writes."""
+    import torch
+    from rogue_gym.envs import DungeonType, HipVecRogueEnv, ImageSetting, StatusFlag
+
+    n = 256
+    cfgs = [dict(goldens["configs"][name], seed=i) for i in range(n)]
+    for st in (ImageSetting(DungeonType.GRAY, StatusFlag.EMPTY, False), ImageSetting(DungeonType.GRAY, StatusFlag.FULL, True),
+               ImageSetting(DungeonType.SYMBOL, StatusFlag.DUNGEON_LEVEL | StatusFlag.EXP, True)):
+        env = HipVecRogueEnv(cfgs, max_steps=60, image_setting=st)
+        g = torch.Generator(device="cpu").manual_seed(1)
+        for _ in range(40):
+            obs, _, _ = env.step(torch.randint(0, 11, (n,), generator=g).to(env.device))
+        packed = env.packed_records(with_hist=st.includes_hist)
+        twice = torch.cat([packed, packed])  # what a world-2 gather of identical shards would hold
+        out = env.expand_records(twice, packed_has_hist=st.includes_hist)
+        torch.cuda.synchronize()
+        assert torch.equal(out[:n], obs) and torch.equal(out[n:], obs)
+        scr, status, hist = env.all_gather_compact(with_hist=True)
+        assert torch.equal(scr, env.screen) and torch.equal(status, env.status)
+        sv = env.status_vec(StatusFlag.FULL)
+        assert sv.shape == (n, 9) and torch.equal(sv[:, 0], env.status[:, 0]) and torch.equal(sv[:, 1], env.status[:, 2])
+        env.close()
+
+
+def test_state_batch_images_and_value_objects(goldens):
+    """The batched value-object path: StateBatch.images (one launch) == per-state encode == oracle, also for a batch the envs have moved past."""
+    from rogue_gym.envs import DungeonType, ImageSetting, ParallelRogueEnv, StatusFlag
+
+    n = 96
+    cfg = goldens["configs"]["mini"]
+    st = ImageSetting(DungeonType.GRAY, StatusFlag.HP_CURRENT | StatusFlag.HUNGER, True)
+    env = ParallelRogueEnv([dict(cfg, seed=i) for i in range(n)], max_steps=40, image_setting=st)
+    oracles = make_oracles(cfg, list(range(n)), max_steps=40)
+    rng = np.random.RandomState(8)
+    old = None
+    for t in range(55):
+        a = rng.randint(0, 11, n)
+        states, rewards, dones, _ = env.step(a.tolist())
+        for i, o in enumerate(oracles):
+            o.step_autoreset(int(ACTION_KEYS[a[i]]))
+        if t == 30:
+            old = (states, [o.gray_image(st.status.value, True) for o in oracles])
+    live = env.images()
+    assert live.shape == (n, 4, 16, 32)
+    for i, o in enumerate(oracles):
+        assert np.array_equal(live[i], o.gray_image(st.status.value, True))
+        assert np.array_equal(st.expand(states[i]), live[i])
+    stale = st.expand_batch(old[0])  # snapshot of step 30: encoded from the snapshot itself, not from the device's current states
+    for i in range(n):
+        assert np.array_equal(stale[i], old[1][i])
+    sym = states[3].symbol_image(flag=1)
+    assert sym.shape == (44, 16, 32) and np.array_equal(sym, oracles[3].symbol_image(1, False))
+    assert states.status_vec(StatusFlag.FULL.value).tolist()[5] == oracles[5].status_vec(0x1FF)
+    env.close()
+
+
+def test_workload_counters(goldens):
+    import torch
+    from rogue_gym.envs import HipVecRogueEnv
+
+    n = 2048
+    env = HipVecRogueEnv([dict(goldens["configs"]["mini"], seed=i) for i in range(n)], max_steps=20)
+    env.counters(reset=True)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    resets = 0
+    for _ in range(60):
+        _, _, done = env.step(torch.randint(0, 11, (n,), generator=g).to(env.device))
+        resets += int(done.sum().item())
+    c = env.counters()
+    assert c["keys"] == 60 * n and c["resets"] == resets
+    assert c["spares_taken"] + c["inline_generations"] == c["resets"] + c["descents"]
+    assert c["redraws"] > 0 and c["dist_maps"] > 0
+    env.close()
+
+
+def test_step_keys_rejects_bad_tensors(goldens):
+    import torch
+    from rogue_gym.envs import HipVecRogueEnv
+
+    env = HipVecRogueEnv([dict(goldens["configs"]["mini"], seed=i) for i in range(8)])
+    good = torch.full((8,), ord("h"), dtype=torch.uint8, device=env.device)
+    env.step_keys(good)
+    for bad in (good.long(), good.cpu(), good[:4], torch.stack([good, good], 1)[:, 0]):
+        with pytest.raises(ValueError):
+            env.step_keys(bad)
+    assert env.all_gather_obs() is env.obs  # world 1: the f32 batch itself, the same type as the distributed result
+    env.close()

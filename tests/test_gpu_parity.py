@@ -417,3 +417,35 @@ def test_custom_enemy_presets(goldens):
     for o in oracles:
         seen.update(chr(65 + m["type"]) for m in o.monsters())
     assert {"G", "W"} <= seen  # the custom monsters actually spawn
+
+
+def test_config5_10000_seeds_default_dungeon(goldens):
+    """BASELINE config 5 at its own shape: 10 000 distinct seeds of the DEFAULT 80x24 dungeon, one env each -- first screen, history, status,
+    internals incl. RNG words vs the oracle, plus the observation the config names: status_vec(FULL) + gray image for every env."""
+    import torch
+    from rogue_gym.envs import DungeonType, HipVecRogueEnv, ImageSetting, StatusFlag
+
+    cfg = goldens["configs"]["default"]
+    seeds = list(range(10000))
+    hip = HipBatch(cfg, seeds)
+    oracles = make_oracles(cfg, seeds)
+    compare_mirrors(hip, oracles, "config5")
+    compare_internal(hip, oracles, range(0, 10000, 11), "config5")
+    gray = hip.obs(0, 0, False)
+    assert gray.shape == (10000, 1, 24, 80)
+    for i in range(0, 10000, 3):
+        assert np.array_equal(gray[i], oracles[i].gray_image(0, False)), "gray env %d" % i
+    del hip
+    venv = HipVecRogueEnv([dict(cfg, seed=s) for s in seeds], image_setting=ImageSetting(DungeonType.GRAY, StatusFlag.FULL, False))
+    sv = venv.status_vec(StatusFlag.FULL).cpu().numpy()
+    obs = venv.obs.cpu().numpy()
+    assert obs.shape == (10000, 10, 24, 80)
+    for i in range(0, 10000, 7):
+        assert sv[i].tolist() == oracles[i].status_vec(0x1FF)
+        assert np.array_equal(obs[i], oracles[i].gray_image(0x1FF, False))
+    # the compact records every rank would contribute to the one all-gather, expanded again: identical to the direct observation
+    packed = venv.packed_records()
+    out = venv.expand_records(packed)
+    torch.cuda.synchronize()
+    assert torch.equal(out, venv.obs)
+    venv.close()
