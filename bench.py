@@ -20,6 +20,12 @@ Before the warm-up there is a DISCLOSED, fixed-duration clock-warm phase ("clock
 envs (not the measured one) is stepped for --clock-warm-s seconds so that a cold GPU has ramped its shader clock before
 anything is timed -- `steps` / `warmup` keep their meaning.  The effective shader clock is probed (s_memtime vs the
 100 MHz s_memrealtime) before and after and reported.
+The metric is defined on the STEADY-STATE episode mix ("steady-state over >= 1000 lock-step batch steps after warm-up,
+including auto-resets"): right after creation all 65 536 envs are at step 0 of their first episode -- every monster of the start room wakes
+at once, every DistCache is cold, nobody resets -- a heavier, unrepresentative transient (measured: k_step 160 us vs 100 us; clocks and spares
+have nothing to do with it, see profiles/r02_driver_repro.txt).  A DISCLOSED pre-roll ("preroll" in the JSON: --preroll-steps untimed steps
+of the measured batch, default 1000 = one max_steps horizon) therefore precedes the W warm-up steps; the first K steps of that pre-roll are
+timed too and reported as "preroll.cold_start" so that the transient's own rate is on record next to `value`.
 
 Rank 0 prints ONE JSON line: the contract fields + "roofline" (dominant kernel, HIP-event timed on the launch stream,
 plus the end-to-end and per-kernel fractions and the on-box copy peak) + "workload_rates" (resets/s, descents/s,
@@ -173,6 +179,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the short extra_workloads runs (default / nohide-symbol)")
     ap.add_argument("--no-repeats", action="store_true", help="skip the 4 further runs of K steps (median)")
     ap.add_argument("--clock-warm-s", type=float, default=1.5, help="untimed fixed-duration stepping of a SCRATCH batch before anything else (0 = off)")
+    ap.add_argument("--preroll-steps", type=int, default=1000, help="untimed steps of the MEASURED batch before the warm-up: reach the steady-state episode mix "
+                    "the metric is defined on (the first --steps of them are timed and reported as preroll.cold_start); 0 = off")
     ap.add_argument("--time-every", type=int, default=8, help="bracket every N-th kernel launch with HIP events (every launch when steps < 64)")
     ap.add_argument("--gather-steps", type=int, default=50, help="extra steps timed WITH the observation all-gather (N>1)")
     args = ap.parse_args()
@@ -226,6 +234,25 @@ def main():
 
     hz = Harness(torch, args.workload, args.envs_per_gpu, rank, local_rank, K + W)
     n, env = hz.n, hz.env
+    preroll = None
+    if args.preroll_steps > 0:
+        kc = min(K, args.preroll_steps)
+        barrier()
+        c0 = time.perf_counter()
+        for _ in range(kc):
+            hz.step()
+        barrier()
+        cdt = torch.tensor([time.perf_counter() - c0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(cdt, op=dist.ReduceOp.MAX)
+        for _ in range(args.preroll_steps - kc):
+            hz.step()
+        torch.cuda.synchronize()
+        preroll = {"steps": args.preroll_steps,
+                   "why": "the metric is the steady-state rate (SURVEY.md 8d); a freshly created batch has every env at step 0 of its first episode "
+                          "(all start-room monsters awake, cold DistCaches, no resets), a heavier transient",
+                   "cold_start": {"steps": kc, "ms_per_step": float(cdt.item()) / kc * 1e3, "value": n * world * kc / float(cdt.item()),
+                                  "note": "the first %d steps after creation, no warm-up at all" % kc}}
     for _ in range(W):
         hz.step()
     every = 1 if K < 64 else args.time_every
@@ -316,6 +343,7 @@ def main():
                                    % (hz.desc, n, n * world, hz.obs_kind, env.channels, env.height, env.width), "envs_per_gpu": n,
                        "parallelism": "env-sharded x%d, no data-path collective" % world},
             "clock_warm": clock_warm,
+            "preroll": preroll,
             "sclk_mhz_after_timed_region": sclk_after,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic,

@@ -224,7 +224,7 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
         rgk_regen(&h->SP, &h->cfg, h->side);
         (void)hipEventRecord(h->ev_regen, h->side);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(h->side);
+        if (e == hipSuccess && !getenv("ROGUE_GYM_HIP_ASYNC_FIRST_SPARES")) e = hipStreamSynchronize(h->side);  // (knob: the round-1 behaviour, for A/B evidence)
         if (e != hipSuccess) { g_create_err = std::string("k_regen: ") + hipGetErrorString(e); free_all(h); delete h; return 1; }
     }
     *out = h;

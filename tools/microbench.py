@@ -65,7 +65,7 @@ GEN_PHASES = {8: "g.clear", 9: "g.rooms", 10: "g.paint", 11: "g.passages", 12: "
 TICK_US = 1.0 / 2350.0  # s_memtime ticks at the shader clock (~2.35 GHz under this load; calibrated against the HIP-event kernel duration)
 
 
-def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=False):
+def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=False, warm=150):
     """Per-wave phase trace of k_step (or k_build with do_reset): rows of (phase, ticks) records, aggregated here."""
     cfgs = [json.dumps(dict(cfg, seed=i)) for i in range(n)]
     h = inner._Handle(cfgs, max_steps, True)
@@ -75,7 +75,7 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
     table = torch.tensor(list(keys_table), dtype=torch.uint8, device=dev)
     gen = torch.Generator(device=dev).manual_seed(0)
     keys = table[torch.randint(0, len(keys_table), (64, n), generator=gen, device=dev)].contiguous()
-    for t in range(150):
+    for t in range(warm):
         L.rg_step(h.h, C.c_void_p(keys[t % 64].data_ptr()), 1)
     nw = (n + 15) // 16  # rows: one per wave of the launch (16..64 envs per wave); unused rows stay zero
     buf = np.zeros(((n + 15) // 16, 64), np.uint64)  # rg_prof copies one row per 16 envs (the smallest envs-per-wave)
@@ -134,6 +134,11 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
 
 if __name__ == "__main__" and "profd" in sys.argv[1:]:
     prof("k_step default 80x24 11-act, 32768 envs", G["configs"]["default"], b".hjklnbuy>s", n=32768)
+
+
+if __name__ == "__main__" and "profphase" in sys.argv[1:]:
+    for warm in (5, 150, 1500, 3000):
+        prof("k_step mini 11-act after %d steps" % warm, G["configs"]["mini"], b".hjklnbuy>s", warm=warm)
 
 
 if __name__ == "__main__" and "prof" in sys.argv[1:]:
