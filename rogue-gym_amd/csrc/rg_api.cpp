@@ -16,7 +16,7 @@
 
 extern "C" {
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st);
-void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, int use_spares, hipStream_t st);
+void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st);
 void rgk_probe_clock(unsigned long long *out, int spin, hipStream_t st);
 void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st);
 void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st);
@@ -48,6 +48,9 @@ struct rg_handle {
     std::vector<uint8_t> reseed;             // 0 = configured seed, 1 = fresh seed per build, 2 = fresh seed inside seed_range per build
     std::vector<uint64_t> range_lo, range_span;  // [2][n] low / high words; empty if no env has a seed_range
     unsigned long long *d_probe = nullptr;
+    size_t stat_rows = 0;        // workload counters: one row of 8 per k_step block (summed by rg_counters)
+    RgState *d_SP = nullptr;     // device-resident copy of SP: k_step reads the spare's pointers from it on the rare take path (one kernel argument
+                                 // instead of a second 60-pointer struct in SGPRs)
     std::string err;
     // per-kernel HIP-event timing (rg_timing_*)
     bool timing = false;
@@ -66,7 +69,8 @@ struct TimedLaunch {  // brackets one kernel launch with an event pair when timi
             on = true; (void)hipEventRecord(h->ev[k][h->ev_used[k]], h->stream);
         }
     }
-    ~TimedLaunch() { if (on) { (void)hipEventRecord(h->ev[k][h->ev_used[k] + 1], h->stream); h->ev_used[k] += 2; } }
+    void stop() { if (on) { (void)hipEventRecord(h->ev[k][h->ev_used[k] + 1], h->stream); h->ev_used[k] += 2; on = false; } }
+    ~TimedLaunch() { stop(); }
 };
 
 static thread_local std::string g_create_err;
@@ -171,6 +175,7 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
     // one DFS stack entry per maze node at most: nodes of the largest assigned area (maze rooms span the area minus one row / column, rooms.rs:240-247)
     const int maze_cap = ((h->cfg.width / h->cfg.room_num_x + 1) / 2) * ((h->cfg.height / h->cfg.room_num_y + 1) / 2) + 1;
     S.maze_cap = maze_cap;
+    h->stat_rows = 2048 + (n + 15) / 16;  // >= the largest k_step grid (descent + monster blocks + one block per 16 envs)
     bool ok = dev_alloc(h, &S.cell, n * hw) && dev_alloc(h, &S.screen, n * hw) && dev_alloc(h, &S.hist, n * hw) &&
               dev_alloc(h, &S.p_pos, n) && dev_alloc(h, &S.p_hp, n) && dev_alloc(h, &S.p_hpmax, n) && dev_alloc(h, &S.p_lvl, n) &&
               dev_alloc(h, &S.p_exp, n) && dev_alloc(h, &S.food, n) && dev_alloc(h, &S.quiet, n) && dev_alloc(h, &S.pack_gold, n) &&
@@ -180,7 +185,7 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
               dev_alloc(h, &S.mon_w0, RG_MAX_ROOMS * n) && dev_alloc(h, &S.mon_hp, RG_MAX_ROOMS * n) && dev_alloc(h, &S.mon_exp, RG_MAX_ROOMS * n) &&
               dev_alloc(h, &S.mon_cnt, n) && dev_alloc(h, &S.gold_pos, RG_MAX_ROOMS * n) && dev_alloc(h, &S.gold_amt, RG_MAX_ROOMS * n) &&
               dev_alloc(h, &S.edge_a, RG_MAX_EDGES * n) && dev_alloc(h, &S.edge_b, RG_MAX_EDGES * n) &&
-              dev_alloc(h, &S.maze_stack, (size_t)maze_cap * n) && dev_alloc(h, &S.build_ctr, n) && dev_alloc(h, &S.stats, 8) &&
+              dev_alloc(h, &S.maze_stack, (size_t)maze_cap * n) && dev_alloc(h, &S.build_ctr, n) && dev_alloc(h, &S.stats, 8 * h->stat_rows) && dev_alloc(h, &S.bin_list, 3 * n) && dev_alloc(h, &S.bin_cnt, 8) &&
               dev_alloc(h, &S.dc_map, h->cfg.n_enemies > 0 ? n * RG_DIST_SLOTS * hw : 16) && dev_alloc(h, &S.dc_key, RG_DIST_SLOTS * n) &&
               dev_alloc(h, &S.dc_head, n) && dev_alloc(h, &S.dc_len, n) && dev_alloc(h, &S.status, n * 10) &&
               dev_alloc(h, &h->d_err, 4) && dev_alloc(h, &h->d_keys, n);
@@ -209,7 +214,8 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
             h->err = "failed to create the background generation stream"; ok = false;
         }
     }
-    if (!ok) { g_create_err = h->err; free_all(h); delete h; return 1; }
+    ok = ok && dev_alloc(h, &h->d_SP, 1) && hipMemcpy(h->d_SP, &h->SP, sizeof(RgState), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { g_create_err = h->err.empty() ? "device allocation failed" : h->err; free_all(h); delete h; return 1; }
     // screen rows 0 and H-1 are never drawn: PlayerState::new fills the map with b' ' (python/src/lib.rs:41-50)
     if (hipMemset(S.screen, ' ', n * hw) != hipSuccess) { g_create_err = "hipMemset failed"; free_all(h); delete h; return 1; }
     if (upload_seeds(h, n)) { g_create_err = h->err; free_all(h); delete h; return 1; }
@@ -294,10 +300,15 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
         dk = h->d_keys;
     }
     h->S.n_keys = n_keys;
-    { TimedLaunch t(h, 0); rgk_step(&h->S, &h->SP, &h->cfg, dk, h->spares ? 1 : 0, h->stream); }
+    {   // ROGUE_GYM_HIP_BINS=1: k_classify sorts the envs of the step into descent / monster / plain lists and k_step takes its lanes from them
+        // (measured neutral against the index-order mapping, DESIGN.md section 5 -- kept as a tested option, off by default)
+        static const bool bins = getenv("ROGUE_GYM_HIP_BINS") != nullptr && atoi(getenv("ROGUE_GYM_HIP_BINS")) != 0;
+        TimedLaunch t(h, 0);
+        rgk_step(&h->S, h->d_SP, &h->cfg, dk, h->spares ? 1 : 0, bins ? (int)(h->step_count & 1) : -1, h->stream);
+    }
+    h->step_count++;
     HIPCHK(h, hipGetLastError());
-    static int regen_every = getenv("ROGUE_GYM_HIP_REGEN_EVERY") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_EVERY")) : 1;
-    if (h->spares && (++h->step_count % (uint64_t)(regen_every < 1 ? 1 : regen_every)) == 0) {
+    if (h->spares) {
         // refill the consumed spares behind this step on the side stream.  Purely stream-ordered (the host runs far ahead of
         // the GPU, so polling an event here would be meaningless); a launch that finds nothing to do costs ~10 us, concurrently.
         HIPCHK(h, hipEventRecord(h->ev_step, h->stream));
@@ -554,8 +565,15 @@ int rg_dump_history(rg_t *h, int env, int which, char *buf, size_t cap, size_t *
 int rg_counters(rg_t *h, uint64_t out[8], int reset) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (out) HIPCHK(h, hipMemcpy(out, h->S.stats, 64, hipMemcpyDeviceToHost));
-    if (reset) HIPCHK(h, hipMemset(h->S.stats, 0, 64));
+    if (!h->S.stats) { if (out) memset(out, 0, 64); return 0; }
+    if (out) {
+        std::vector<unsigned long long> rows(8 * h->stat_rows);
+        HIPCHK(h, hipMemcpy(rows.data(), h->S.stats, rows.size() * 8, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 8; k++) out[k] = 0;
+        for (size_t r = 0; r < h->stat_rows; r++)
+            for (int k = 0; k < 8; k++) out[k] += rows[r * 8 + k];
+    }
+    if (reset) HIPCHK(h, hipMemset(h->S.stats, 0, 64 * h->stat_rows));
     return 0;
 }
 

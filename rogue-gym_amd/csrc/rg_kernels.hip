@@ -1692,13 +1692,82 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
 // ---------------------------------------------------------------------------------------------
 // k_step: one key for every env
 // ---------------------------------------------------------------------------------------------
+// ThreadConductor's auto-reset (thread_impls.rs:69-79) for the lanes whose spare level-1 state is ready: spare -> live, memory to memory, at the
+// end of the wave.  Everything is requested before anything is stored, so the whole reset costs the wave about one memory round trip (the
+// round-1 form -- scalars into registers, tables, then the grid, each waiting for the one before -- cost ~25 us of dependent round trips in
+// every wave with a terminal lane, a third of the waves of a step).  The spare's pointers come from a device-resident RgState: one kernel
+// argument instead of a second 60-pointer struct held in SGPRs by a kernel that is already spilling them.
+__device__ __forceinline__ void take_spares(const RgState &S, const RgState *__restrict__ SPd, const RgConfig &c, int lane, int e, bool taken) {
+    const uint64_t tm = __ballot(taken);
+    if (!tm) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // pairs with k_regen's release of sp_ready = 1
+    const RgState &SP = *SPd;
+    const int HW = S.hw, n = S.n, nrooms = c.room_num_x * c.room_num_y;
+    // grids: the wave streams each taken env's 2 * HW bytes with 16-byte accesses (mini: one access per lane and env)
+    if ((HW & 7) == 0) {
+        const int q = HW / 8;
+        uint64_t mm = tm;
+        while (mm) {
+            const int s0 = __ffsll((long long)mm) - 1; mm &= mm - 1;
+            const int s1 = mm ? __ffsll((long long)mm) - 1 : -1; if (mm) mm &= mm - 1;  // two envs per round: their loads are in flight together
+            const int e0 = __shfl(e, s0), e1 = s1 >= 0 ? __shfl(e, s1) : e0;
+            const uint4 *a = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e0 * HW), *b = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e1 * HW);
+            uint4 *da = reinterpret_cast<uint4 *>(S.cell + (size_t)e0 * HW), *db = reinterpret_cast<uint4 *>(S.cell + (size_t)e1 * HW);
+            for (int i = lane; i < q; i += WAVE) {
+                const uint4 va = a[i];
+                uint4 vb = va;
+                if (s1 >= 0) vb = b[i];
+                da[i] = va;
+                if (s1 >= 0) db[i] = vb;
+            }
+        }
+    } else {
+        uint64_t mm = tm;
+        while (mm) {
+            const int src = __ffsll((long long)mm) - 1; mm &= mm - 1;
+            const int env_s = __shfl(e, src);
+            const uint16_t *sp = SP.cell + (size_t)env_s * HW;
+            uint16_t *dp = S.cell + (size_t)env_s * HW;
+            for (int i = lane; i < HW; i += WAVE) dp[i] = sp[i];
+        }
+    }
+    if (taken) {
+        uint32_t r[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) r[k] = SP.rng[k * n + e];
+        const uint16_t pp = SP.p_pos[e];
+        const int32_t hp = SP.p_hp[e], hpm = SP.p_hpmax[e], lv = SP.p_lvl[e];
+        const uint32_t ex = SP.p_exp[e], fd = SP.food[e], qu = SP.quiet[e], pg = SP.pack_gold[e], dl = SP.dlevel[e], mc = SP.mon_cnt[e];
+#pragma unroll
+        for (int k = 0; k < 12; k++) S.rng[k * n + e] = r[k];
+        S.p_pos[e] = pp; S.p_hp[e] = hp; S.p_hpmax[e] = hpm; S.p_lvl[e] = lv;
+        S.p_exp[e] = ex; S.food[e] = fd; S.quiet[e] = qu; S.pack_gold[e] = pg; S.dlevel[e] = dl; S.mon_cnt[e] = mc;
+        for (int s0 = 0; s0 < nrooms; s0 += 4) {  // tables, four slots per round
+            uint32_t rr[4], mw[4], me[4], gp[4], ga[4]; int32_t mh[4]; uint8_t rm[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const size_t g = (size_t)(s0 + k < nrooms ? s0 + k : s0) * n + e;
+                rr[k] = SP.room_rect[g]; rm[k] = SP.room_meta[g]; mw[k] = SP.mon_w0[g]; mh[k] = SP.mon_hp[g]; me[k] = SP.mon_exp[g]; gp[k] = SP.gold_pos[g]; ga[k] = SP.gold_amt[g];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (s0 + k < nrooms) {
+                    const size_t g = (size_t)(s0 + k) * n + e;
+                    S.room_rect[g] = rr[k]; S.room_meta[g] = rm[k]; S.mon_w0[g] = mw[k]; S.mon_hp[g] = mh[k]; S.mon_exp[g] = me[k]; S.gold_pos[g] = gp[k]; S.gold_amt[g] = ga[k];
+                }
+        }
+    }
+    __syncthreads();  // every lane's reads of the spares are complete (vmcnt drained) ...
+    if (taken) __hip_atomic_store(&S.sp_ready[e], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // ... before k_regen may refill them
+}
+
+// One wave's share of a step: lane i plays the key of env `e` (any env index -- the lanes of a wave need not hold consecutive envs), `valid`
+// lanes only; the other lanes still take part in the wave-cooperative services.
 template <int BW>
-__global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset, int epw) {
-    __builtin_amdgcn_s_setprio(3);  // issue-bound kernel: win VALU arbitration against the co-resident background k_regen waves
+__device__ __forceinline__ void step_wave(const RgState &S, const RgState *__restrict__ SPd, const RgConfig &c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset,
+                                          const int e, const bool valid) {
     uint16_t *lds_grid = reinterpret_cast<uint16_t *>(g_smem);
     const int lane = threadIdx.x;
-    const int e = blockIdx.x * epw + lane;  // epw envs per wave (64, or fewer when the batch would leave SIMDs without a wave)
-    const bool valid = lane < epw && e < S.n;
     Prof pf; pf.start(S.prof);
     Env E;
     E.err = 0;
@@ -1707,6 +1776,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
     int gold_before = 0;
     bool live = false;   // this lane processes a key this call
     bool ui_dead = false, terminal = false;
+    bool taken = false;  // terminal + auto-reset + spare ready: the spare becomes the live state at the end of the wave (take_spares)
     uint32_t n_bfs = 0, n_inline = 0, n_taken = 0;  // workload counters (S.stats)
     const bool has_key = valid && e < S.n_keys;  // ThreadConductor::step zips keys with envs (thread_impls.rs:62-64)
     if (valid) {
@@ -1759,40 +1829,10 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
         // pass 0: levels for descending lanes; pass 1: rebuilds for terminal lanes (ThreadConductor auto-reset)
         pf.mark(1);
         if (pass == 1 && use_spares) {
-            // take the pre-generated spare level when it is ready (k_regen); otherwise generate inline below
-            bool take = false;
-            if (need_gen && __hip_atomic_load(&S.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) take = true;
-            uint64_t tm = __ballot(take);
-            if (tm) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const int HW = S.hw, n = S.n, nrooms = c.room_num_x * c.room_num_y;
-                if (take) {
-                    uint16_t *gc = E.gcell;
-                    load_env(SP, E, e);
-                    E.cell = E.gcell = gc;
-                    for (int sl = 0; sl < nrooms; sl++) {
-                        S.room_rect[sl * n + e] = SP.room_rect[sl * n + e]; S.room_meta[sl * n + e] = SP.room_meta[sl * n + e];
-                        S.mon_w0[sl * n + e] = SP.mon_w0[sl * n + e]; S.mon_hp[sl * n + e] = SP.mon_hp[sl * n + e]; S.mon_exp[sl * n + e] = SP.mon_exp[sl * n + e];
-                        S.gold_pos[sl * n + e] = SP.gold_pos[sl * n + e]; S.gold_amt[sl * n + e] = SP.gold_amt[sl * n + e];
-                    }
-                    need_gen = false;
-                    n_taken++;
-                }
-                uint64_t mm = tm;
-                while (mm) {  // the wave streams each taken grid spare -> live with 16-byte accesses
-                    int src = __ffsll((long long)mm) - 1;
-                    mm &= mm - 1;
-                    int env_s = __shfl(e, src);
-                    const uint16_t *sp = SP.cell + (size_t)env_s * HW;
-                    uint16_t *dp = S.cell + (size_t)env_s * HW;
-                    if ((HW & 7) == 0) {
-                        for (int i = lane; i < HW / 8; i += WAVE) reinterpret_cast<uint4 *>(dp)[i] = reinterpret_cast<const uint4 *>(sp)[i];
-                    } else
-                        for (int i = lane; i < HW; i += WAVE) dp[i] = sp[i];
-                }
-                __syncthreads();
-                if (take) __hip_atomic_store(&S.sp_ready[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // consumed: k_regen refills it
-            }
+            // The env's pre-generated spare (k_regen) IS its post-reset state: if it is ready, nothing is generated here, and nothing of it is
+            // needed in registers either -- the lane only notes `taken`; the spare is moved into place at the very end of the wave in one
+            // batched memory-to-memory copy (take_spares).  Without a ready spare the level is generated inline below.
+            if (need_gen && __hip_atomic_load(&S.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) { taken = true; need_gen = false; n_taken++; }
         }
         const bool regenerated = descends && pass == 0;
         if (need_gen) n_inline++;
@@ -1873,38 +1913,127 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, RgState SP, RgConfig c
     }
     pf.mark(6);
     pf.finish();
-    if (S.stats) {  // one atomic per wave and non-zero counter
+    if (S.stats) {
+        // per-BLOCK rows, plain read-modify-write by the block's own lane 0 (launches of one handle are stream-ordered): no atomics.  (One
+        // atomicAdd per wave and counter on a shared 64-byte line -- 7 000 same-line atomics per launch -- cost the kernel 20 us, measured.)
         const uint32_t cnt[7] = {(uint32_t)__popcll(__ballot(live && terminal && c.auto_reset)), (uint32_t)__popcll(__ballot(descends)),
                                  wave_sum(n_bfs), wave_sum(n_inline), wave_sum(n_taken), (uint32_t)__popcll(__ballot(live && (react & R_REDRAW))),
                                  (uint32_t)__popcll(__ballot(live))};
-        if (lane == 0)
-            for (int k = 0; k < 7; k++)
-                if (cnt[k]) atomicAdd(&S.stats[k], (unsigned long long)cnt[k]);
+        if (lane < 7) {
+            uint32_t mine = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) mine = lane == k ? cnt[k] : mine;
+            if (mine) S.stats[(size_t)blockIdx.x * 8 + lane] += mine;
+        }
     }
-    if (!valid) return;
-    if (err) {
+    if (valid && err) {
         S.flags[e] = (old_flags & ~RG_FLAG_ERR_MASK) | err;
         S.reward[e] = 0.f;
         S.done[e] = (old_flags & RG_FLAG_TERMINAL) ? 1 : 0;
         atomicOr(S.err_any, err);
-        return;
+    } else if (valid && !live) {  // steps > max_steps / no key for this env: silent no-op
+        S.reward[e] = 0.f; S.done[e] = (old_flags & RG_FLAG_TERMINAL) ? 1 : 0;
+    } else if (valid) {
+        if (terminal && c.auto_reset) {
+            if (taken) {  // the status of a freshly built RunTime (GameConfig::build: level 1, Player::new + init_items, core/src/lib.rs:193-228)
+                E.dlevel = 1; E.gold = 0; E.hp = E.hpmax = c.init_hp; E.plvl = 1; E.exp = 0; E.food = c.hunger_time;
+            }
+            write_status(S, c, E);
+            S.dc_len[e] = 0; S.dc_head[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
+            steps = 0;
+            flags = RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY;
+            klog_new_episode(S, e);
+        }
+        if (E.err) { flags |= E.err; atomicOr(S.err_any, E.err); }
+        if (terminal) flags |= RG_FLAG_TERMINAL;
+        if (!taken) store_env(S, E);  // (a taken env's live scalars are the spare's: copied below)
+        S.steps[e] = steps;
+        S.flags[e] = flags;
+        S.done[e] = terminal ? 1 : 0;
+        int gold_after = S.status[(size_t)e * 10 + 1];
+        S.reward[e] = (float)(gold_after - gold_before > 0 ? gold_after - gold_before : 0);
     }
-    if (!live) { S.reward[e] = 0.f; S.done[e] = (old_flags & RG_FLAG_TERMINAL) ? 1 : 0; return; }  // steps > max_steps / no key for this env: silent no-op
-    if (terminal && c.auto_reset) {
-        write_status(S, c, E);
-        S.dc_len[e] = 0; S.dc_head[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
-        steps = 0;
-        flags = RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY;
-        klog_new_episode(S, e);
+    take_spares(S, SPd, c, lane, e, taken);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Binning.  A wave costs the UNION of its lanes' paths: with envs laid out in index order nearly every 64-env wave contains somebody with
+// awake monsters (5 % of the envs in the steady state: prepass + BFS + moves, ~18 us) and every 40th a descent (a 35-40 us level generation that
+// the other 63 lanes wait for) -- the launch lasts as long as its slowest wave, ~2.4x the mean.  k_classify therefore sorts the envs of this
+// step by what their key is about to do, and k_step takes its lanes from the three lists:
+//   descents      one env per wave, first in the grid: the 75 us chain (own turn + generation) starts at t = 0 and nobody else waits for it
+//   monster envs  8 .. 64 per wave (few lanes => few BFS rounds per wave), next in the grid
+//   plain envs    64 per wave in (nearly) index order -- their waves never enter the monster code at all
+// The classification is a scheduling hint only: every wave runs the full turn code, so an env whose monsters wake during this very step is
+// still played correctly by a "plain" wave.
+// ---------------------------------------------------------------------------------------------
+#define BIN_G_DESC 128   // blocks reserved for the descent list (grid-stride beyond that)
+#define BIN_G_MON 1024   // blocks reserved for the monster list
+__device__ __forceinline__ int bin_epw_mon(int n_mon) { return n_mon <= 8 * BIN_G_MON ? 8 : (n_mon <= 16 * BIN_G_MON ? 16 : (n_mon <= 32 * BIN_G_MON ? 32 : 64)); }
+
+#define CLS_THREADS 1024
+__global__ void __launch_bounds__(CLS_THREADS) k_classify(RgState S, RgConfig c, const uint8_t *__restrict__ keys, int parity) {
+    __shared__ uint32_t s_cnt[3][CLS_THREADS / 64];  // per wave and class
+    __shared__ uint32_t s_base[3];
+    const int e = blockIdx.x * CLS_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t *cnt = S.bin_cnt + 4 * parity;
+    if (e == 0) { uint32_t *nx = S.bin_cnt + 4 * (parity ^ 1); nx[0] = nx[1] = nx[2] = 0; }  // the other set is idle during this step: ready for the next one
+    int cls = -1;  // 0 descent, 1 awake monsters, 2 plain
+    if (e < S.n) {
+        cls = 2;
+        const uint32_t fl = S.flags[e];
+        if (e < S.n_keys && !(S.steps[e] > c.max_steps) && !(fl & RG_FLAG_DEAD)) {
+            int dir;
+            const int act = decode_key(keys[e], dir);
+            if (act == ACT_DOWNSTAIR) {
+                const uint32_t p = S.p_pos[e];
+                if ((S.cell[(size_t)e * S.hw + POS_Y(p) * c.width + POS_X(p)] & C_SURF_MASK) == S_STAIR) cls = 0;
+            }
+            if (cls == 2 && act != ACT_INVALID && act != ACT_NOOP && ((S.mon_cnt[e] >> 8) & 0xff) != 0) cls = 1;  // NoOp costs no turn
+        }
     }
-    if (E.err) { flags |= E.err; atomicOr(S.err_any, E.err); }
-    if (terminal) flags |= RG_FLAG_TERMINAL;
-    store_env(S, E);
-    S.steps[e] = steps;
-    S.flags[e] = flags;
-    S.done[e] = terminal ? 1 : 0;
-    int gold_after = S.status[(size_t)e * 10 + 1];
-    S.reward[e] = (float)(gold_after - gold_before > 0 ? gold_after - gold_before : 0);
+    // block-level compaction: three atomics per 1024 envs (same-line atomics are what a classification pass must not be made of); inside a
+    // block the lists keep the index order, which is what lets the plain waves load their lanes' state coalesced
+    uint64_t m[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { m[k] = __ballot(cls == k); if (lane == 0) s_cnt[k][wv] = (uint32_t)__popcll(m[k]); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t tot = 0;
+        for (int w = 0; w < CLS_THREADS / 64; w++) { const uint32_t v = s_cnt[threadIdx.x][w]; s_cnt[threadIdx.x][w] = tot; tot += v; }  // exclusive prefix
+        s_base[threadIdx.x] = tot ? atomicAdd(&cnt[threadIdx.x], tot) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (cls == k) S.bin_list[(size_t)k * S.n + s_base[k] + s_cnt[k][wv] + __popcll(m[k] & ((1ull << lane) - 1ull))] = e;
+}
+
+template <int BW>
+__global__ void __launch_bounds__(WAVE) k_step(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset, int epw,
+                                               int parity) {
+    __builtin_amdgcn_s_setprio(3);  // issue-bound kernel: win VALU arbitration against the co-resident background k_regen waves
+    const int lane = threadIdx.x;
+    // this block's work: items [first, first + per), [first + stride, ...) ... of one list (nullptr: the envs in index order); ONE call site
+    // of the turn code below, whatever the role
+    const int32_t *list = nullptr;
+    int first = blockIdx.x * epw, stride = 0, per = epw, items = S.n;
+    if (parity >= 0) {
+        const uint32_t *cnt = S.bin_cnt + 4 * parity;
+        const int n_desc = (int)cnt[0], n_mon = (int)cnt[1], n_plain = (int)cnt[2];
+        int b = blockIdx.x;
+        if (b < BIN_G_DESC) { list = S.bin_list; first = b; stride = BIN_G_DESC; per = 1; items = n_desc; }
+        else if ((b -= BIN_G_DESC) < BIN_G_MON) { per = bin_epw_mon(n_mon); list = S.bin_list + S.n; first = b * per; stride = BIN_G_MON * per; items = n_mon; }
+        else { b -= BIN_G_MON; list = S.bin_list + 2 * (size_t)S.n; first = b * epw; items = n_plain; }
+    }
+    for (int i0 = first; i0 < items; i0 += stride) {
+        const bool v = lane < per && i0 + lane < items;
+        const int e = v ? (list ? list[i0 + lane] : i0 + lane) : 0;
+        step_wave<BW>(S, SPd, c, keys, use_spares, mc_offset, e, v);
+        if (stride == 0) break;
+        __syncthreads();  // the next item reuses the wave's LDS
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1916,7 +2045,7 @@ void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
     size_t smem = GEN_SLOT_BYTES(hw);  // one level at a time per wave: one staging grid + the generator's tables
     hipLaunchKernelGGL(k_build, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), smem, st, *S, *c);
 }
-void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint8_t *keys, int use_spares, hipStream_t st) {
+void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st) {
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw);  // the generator's staging grid + tables (inline descents, spare misses), shared with ...
     const size_t bfs_hi = c->width <= 32 ? 0 : (size_t)10 * ((c->width + 63) / 64) * WAVE * 8;  // ... the BFS high distance planes
@@ -1930,11 +2059,14 @@ void rgk_step(const RgState *S, const RgState *SP, const RgConfig *c, const uint
     int epw = WAVE;
     while (epw > 16 && (S->n + epw - 1) / epw < 1024) epw >>= 1;
     if (epw_env == 16 || epw_env == 32 || epw_env == 64) epw = epw_env;
-    const dim3 grid((S->n + epw - 1) / epw), block(WAVE);
-    if (c->width <= 32) hipLaunchKernelGGL(k_step<0>, grid, block, smem, st, *S, *SP, *c, keys, use_spares, mc_offset, epw);
-    else if (c->width <= 64) hipLaunchKernelGGL(k_step<1>, grid, block, smem, st, *S, *SP, *c, keys, use_spares, mc_offset, epw);
-    else if (c->width <= 128) hipLaunchKernelGGL(k_step<2>, grid, block, smem, st, *S, *SP, *c, keys, use_spares, mc_offset, epw);
-    else hipLaunchKernelGGL(k_step<3>, grid, block, smem, st, *S, *SP, *c, keys, use_spares, mc_offset, epw);
+    // parity >= 0: binned (k_classify sorts the envs of this step into the descent / monster / plain lists of counter set `parity` first)
+    const int nb = (S->n + epw - 1) / epw;
+    if (parity >= 0) hipLaunchKernelGGL(k_classify, dim3((S->n + CLS_THREADS - 1) / CLS_THREADS), dim3(CLS_THREADS), 0, st, *S, *c, keys, parity);
+    const dim3 grid(parity >= 0 ? BIN_G_DESC + BIN_G_MON + nb : nb), block(WAVE);
+    if (c->width <= 32) hipLaunchKernelGGL(k_step<0>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
+    else if (c->width <= 64) hipLaunchKernelGGL(k_step<1>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
+    else if (c->width <= 128) hipLaunchKernelGGL(k_step<2>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
+    else hipLaunchKernelGGL(k_step<3>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
 }
 void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;

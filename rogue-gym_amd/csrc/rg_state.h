@@ -94,6 +94,10 @@ struct RgState {
     // workload counters (bench.py: resets/s, descents/s, BFS maps/s): [0] auto-resets [1] descents [2] dist maps built [3] inline level
     // generations [4] spare levels taken [5] Redraw reactions [6] keys processed; one atomicAdd per wave and counter
     unsigned long long *stats;
+    // per-step binning of the envs (k_classify -> k_step): [3][n] env indices of the descent / monster / plain lists, and two sets of
+    // {n_desc, n_mon, n_plain, -} counters used alternately (the idle set is zeroed by k_classify for the step after)
+    int32_t *bin_list;
+    uint32_t *bin_cnt;
     uint32_t *err_any;  // [1] OR of every error bit raised since the last rg_sync
     // ThreadConductor::step zips keys with envs (thread_impls.rs:62-64): envs >= n_keys receive no key this call
     int32_t n_keys;

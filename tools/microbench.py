@@ -116,6 +116,11 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
         if pid in sums:
             print("   %-18s avg/wave %7.2f us   max wave %7.2f us" % (nm, sums[pid] / max(n_waves, 1) / nl * TICK_US, maxs[pid] * TICK_US))
     if not do_reset:
+        last = buf[:, 63].astype(np.float64) * TICK_US
+        for nm, lo, hi in (("desc blocks", 0, 128), ("mon blocks", 128, 1152), ("plain blocks", 1152, len(last))):
+            seg = last[lo:hi]; seg = seg[seg > 0]
+            if len(seg):
+                print("   %-12s (last launch) n=%d mean %.1f us p50 %.1f p90 %.1f max %.1f" % (nm, len(seg), seg.mean(), np.percentile(seg, 50), np.percentile(seg, 90), seg.max()))
         hist = np.histogram(tot * TICK_US, bins=np.arange(0, 260, 10))[0] / nl
         print("   wave-duration histogram (10 us buckets, waves per launch): " + " ".join("%.0f" % v for v in hist))
         # which phase makes the slowest waves slow: phase sums over the slowest 1 % of waves of the last launch
@@ -134,6 +139,10 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
 
 if __name__ == "__main__" and "profd" in sys.argv[1:]:
     prof("k_step default 80x24 11-act, 32768 envs", G["configs"]["default"], b".hjklnbuy>s", n=32768)
+
+
+if __name__ == "__main__" and "prof1" in sys.argv[1:]:
+    prof("k_step mini 11-act after 1500 steps", G["configs"]["mini"], b".hjklnbuy>s", warm=1500)
 
 
 if __name__ == "__main__" and "profphase" in sys.argv[1:]:
