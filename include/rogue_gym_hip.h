@@ -44,7 +44,8 @@ typedef struct rg_handle rg_t;
 
 /* Replaces GameState::__new__ / ParallelGameState::new (python/src/lib.rs:217-225,270-294) and
  * ThreadConductor::new (thread_impls.rs:14-34): parses one GameConfig JSON per env
- * (core/src/lib.rs:42-86; all envs must agree on everything except `seed`), allocates the SoA
+ * (core/src/lib.rs:42-86).  Envs may differ in anything but width / height: envs with equal configs (seeds aside) form a group that is
+ * stepped as one homogeneous batch, and the handle presents all groups in the caller's env order.  Allocates the SoA
  * state for n_env environments on HIP device `device`, generates every level-1 dungeon and
  * draws the first screens.  auto_reset != 0 selects ThreadConductor::step semantics (terminal
  * envs are rebuilt inside rg_step and report the post-reset state with is_terminal forced
@@ -57,6 +58,9 @@ const char *rg_last_error(const rg_t *h);
 
 /* GameState::screen_size / symbols (python/src/lib.rs:226-228,255-257,295-300) */
 int rg_dims(const rg_t *h, int *height, int *width, int *symbols, int *n_env);
+/* `symbols` of every env's own config (GameStateImpl::new computes it per env, state_impls.rs:21-25; PlayerState.symbols): out_host = i32 [n_env].
+ * rg_dims reports env 0's, like ParallelGameState::symbols (python/src/lib.rs:281-285,298-300). */
+int rg_env_symbols(const rg_t *h, int32_t *out_host);
 /* Run all later work of this handle on `hip_stream` (a hipStream_t; NULL = default stream). */
 int rg_set_stream(rg_t *h, void *hip_stream);
 

@@ -22,9 +22,11 @@ void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st);
 void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st);
 void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st);
 void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, size_t rs, size_t rst,
-                int symbols, uint32_t sflag, int with_hist, int kind, float *out, hipStream_t st);
+                int symbols, int planes_sym, uint32_t sflag, int with_hist, int kind, float *out, const int32_t *ext, hipStream_t st);
 void rgk_pack(const RgState *S, int with_hist, uint8_t *out, hipStream_t st);
-int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, hipStream_t st);
+void rgk_scatter_rows(const void *src, void *dst, const int32_t *ext, int n, int row_bytes, hipStream_t st);
+void rgk_gather_keys(const uint8_t *keys, const int32_t *ext, uint8_t *dst, int n, hipStream_t st);
+int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, int planes_sym, hipStream_t st);
 }
 
 struct rg_handle {
@@ -48,6 +50,16 @@ struct rg_handle {
     std::vector<uint8_t> reseed;             // 0 = configured seed, 1 = fresh seed per build, 2 = fresh seed inside seed_range per build
     std::vector<uint64_t> range_lo, range_span;  // [2][n] low / high words; empty if no env has a seed_range
     unsigned long long *d_probe = nullptr;
+    // ---- per-env configs that differ in more than the seed (python/src/lib.rs:270-294 takes one GameConfig per env): the handle is then a
+    // PARENT over one sub-handle per distinct config ("group").  Every group is an ordinary homogeneous batch with its own state and
+    // kernels; the parent owns the mirrors in the handle's env order (S.screen .. S.done, assembled from the groups') and routes the calls.
+    std::vector<rg_handle *> sub;      // empty for an ordinary handle
+    std::vector<int> g_of, l_of;       // env -> (group, index inside the group); groups keep the env order
+    int32_t *d_ext = nullptr;          // (sub-handle) device copy of its local -> handle env index map
+    std::vector<int32_t> ext;          // (sub-handle) the same on the host
+    uint8_t *d_keys_sub = nullptr;     // (sub-handle) keys of its envs gathered from the handle's key vector
+    int planes_sym = 0;                // one-hot depth of the handle's symbol image (= symbols of env 0's config, like ParallelGameState::symbols)
+    bool screens_stale = true;         // (parent) S.screen / S.hist / S.flags need assembling
     size_t stat_rows = 0;        // workload counters: one row of 8 per k_step block (summed by rg_counters)
     RgState *d_SP = nullptr;     // device-resident copy of SP: k_step reads the spare's pointers from it on the rare take path (one kernel argument
                                  // instead of a second 60-pointer struct in SGPRs)
@@ -121,8 +133,7 @@ extern "C" {
 
 const char *rg_last_error(const rg_t *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
-int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int device, int auto_reset, rg_t **out) {
-    if (!out || n_env <= 0) { g_create_err = "rg_create: invalid arguments"; return 1; }
+static int create_homog(const char *const *cfg_json, int n_env, uint64_t max_steps, int device, int auto_reset, rg_handle **out) {
     *out = nullptr;
     rg_handle *h = new rg_handle();
     std::random_device rd;
@@ -159,6 +170,7 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
         }
     }
     h->cfg = h->parsed.cfg;
+    h->planes_sym = h->cfg.symbols;
     h->cfg.max_steps = max_steps > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)max_steps;
     h->cfg.auto_reset = auto_reset ? 1 : 0;
     h->device = device;
@@ -237,9 +249,111 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
     return 0;
 }
 
-void rg_destroy(rg_t *h) {
+// ---------------------------------------------------------------------------------------------
+// handles whose envs differ in more than the seed: parent over one homogeneous sub-handle per distinct config
+// ---------------------------------------------------------------------------------------------
+#define SUBCHK(h, sh, call) do { if (call) { (h)->err = (sh)->err; return 1; } } while (0)
+
+static void destroy_handle(rg_handle *h);
+
+// status / flags / reward / done of every group -> the parent's arrays in env order (44 + 5 bytes per env); after every step and reset, so that
+// device pointers handed out once (rg_reward, rg_done, rg_status ...) stay current
+static int assemble_small(rg_handle *h) {
+    for (rg_handle *sh : h->sub) {
+        const int m = sh->S.n;
+        rgk_scatter_rows(sh->S.status, h->S.status, sh->d_ext, m, 40, h->stream);
+        rgk_scatter_rows(sh->S.reward, h->S.reward, sh->d_ext, m, 4, h->stream);
+        rgk_scatter_rows(sh->S.done, h->S.done, sh->d_ext, m, 1, h->stream);
+        rgk_scatter_rows(sh->S.flags, h->S.flags, sh->d_ext, m, 4, h->stream);
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+// screens, history planes (and the flag words, which the render pass updates) on demand
+static int assemble_screens(rg_handle *h) {
+    if (!h->screens_stale) return 0;
+    for (rg_handle *sh : h->sub) {
+        SUBCHK(h, sh, flush_render(sh));
+        const int m = sh->S.n;
+        rgk_scatter_rows(sh->S.screen, h->S.screen, sh->d_ext, m, h->S.hw, h->stream);
+        rgk_scatter_rows(sh->S.hist, h->S.hist, sh->d_ext, m, h->S.hw, h->stream);
+        rgk_scatter_rows(sh->S.flags, h->S.flags, sh->d_ext, m, 4, h->stream);
+    }
+    HIPCHK(h, hipGetLastError());
+    h->screens_stale = false;
+    return 0;
+}
+
+int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int device, int auto_reset, rg_t **out) {
+    if (!out || n_env <= 0) { g_create_err = "rg_create: invalid arguments"; return 1; }
+    *out = nullptr;
+    // group the envs by parsed config (everything the device code reads; seeds and seed ranges stay per env)
+    std::vector<RgConfig> reps;
+    std::vector<int> g_of(n_env), l_of(n_env);
+    std::vector<std::vector<int>> members;
+    {
+        const char *prev = nullptr; int prev_g = -1;
+        RgParsed p;
+        for (int i = 0; i < n_env; i++) {
+            const char *js = cfg_json ? cfg_json[i] : nullptr;
+            const bool same_text = i > 0 && ((js == nullptr && prev == nullptr) || (js && prev && strcmp(js, prev) == 0));
+            int g = prev_g;
+            if (!same_text) {
+                std::string e = rg_parse_config(js, &p);
+                if (!e.empty()) { g_create_err = "Failed to parse config: " + e; return 1; }
+                g = -1;
+                for (size_t k = 0; k < reps.size(); k++) if (rg_config_equal(reps[k], p.cfg)) { g = (int)k; break; }
+                if (g < 0) { g = (int)reps.size(); reps.push_back(p.cfg); members.emplace_back(); }
+                prev = js; prev_g = g;
+            }
+            g_of[i] = g; l_of[i] = (int)members[g].size(); members[g].push_back(i);
+        }
+    }
+    if (reps.size() == 1) return create_homog(cfg_json, n_env, max_steps, device, auto_reset, out);
+    for (size_t k = 1; k < reps.size(); k++)
+        if (reps[k].width != reps[0].width || reps[k].height != reps[0].height) {
+            g_create_err = "configs of one batch must share width and height (env " + std::to_string(members[k][0]) + " is " + std::to_string(reps[k].width) + "x" +
+                           std::to_string(reps[k].height) + ", env 0 is " + std::to_string(reps[0].width) + "x" + std::to_string(reps[0].height) +
+                           "): the batch is exposed as [n_env][H][W] tensors";
+            return 1;
+        }
+    rg_handle *h = new rg_handle();
+    h->device = device;
+    h->g_of = g_of; h->l_of = l_of;
+    for (size_t k = 0; k < reps.size(); k++) {
+        std::vector<const char *> js(members[k].size());
+        for (size_t j = 0; j < members[k].size(); j++) js[j] = cfg_json ? cfg_json[members[k][j]] : nullptr;
+        rg_handle *sh = nullptr;
+        if (create_homog(js.data(), (int)js.size(), max_steps, device, auto_reset, &sh)) { destroy_handle(h); return 1; }
+        h->sub.push_back(sh);
+        sh->ext.assign(members[k].begin(), members[k].end());
+        bool ok = dev_alloc(sh, &sh->d_ext, js.size()) && dev_alloc(sh, &sh->d_keys_sub, js.size()) &&
+                  hipMemcpy(sh->d_ext, sh->ext.data(), js.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+        if (!ok) { g_create_err = "device allocation failed"; destroy_handle(h); return 1; }
+        sh->S.ext = sh->d_ext;
+    }
+    rg_handle *first = h->sub[g_of[0]];
+    h->parsed = first->parsed; h->cfg = first->cfg;
+    h->planes_sym = first->cfg.symbols;  // ParallelGameState::new takes `symbols` from configs[0] (python/src/lib.rs:281-285)
+    for (rg_handle *sh : h->sub) sh->planes_sym = h->planes_sym;
+    RgState &S = h->S;
+    memset(&S, 0, sizeof S);
+    const size_t n = (size_t)n_env, hw = (size_t)h->cfg.width * h->cfg.height;
+    S.n = n_env; S.hw = (int)hw; S.n_keys = n_env;
+    bool ok = dev_alloc(h, &S.screen, n * hw) && dev_alloc(h, &S.hist, n * hw) && dev_alloc(h, &S.status, n * 10) && dev_alloc(h, &S.flags, n) &&
+              dev_alloc(h, &S.reward, n) && dev_alloc(h, &S.done, n) && dev_alloc(h, &h->d_err, 4) && dev_alloc(h, &h->d_probe, 4);
+    if (!ok) { g_create_err = h->err; destroy_handle(h); return 1; }
+    S.err_any = h->d_err;
+    if (assemble_small(h) || hipStreamSynchronize(h->stream) != hipSuccess) { g_create_err = h->err.empty() ? "assemble failed" : h->err; destroy_handle(h); return 1; }
+    *out = h;
+    return 0;
+}
+
+static void destroy_handle(rg_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    for (rg_handle *sh : h->sub) destroy_handle(sh);
+    h->sub.clear();
     (void)hipStreamSynchronize(h->stream);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->ev_step) (void)hipEventDestroy(h->ev_step);
@@ -250,15 +364,24 @@ void rg_destroy(rg_t *h) {
     delete h;
 }
 
+void rg_destroy(rg_t *h) { destroy_handle(h); }
+
 int rg_dims(const rg_t *h, int *height, int *width, int *symbols, int *n_env) {
     if (height) *height = h->cfg.height;
     if (width) *width = h->cfg.width;
-    if (symbols) *symbols = h->cfg.symbols;
+    if (symbols) *symbols = h->planes_sym;
     if (n_env) *n_env = h->S.n;
     return 0;
 }
 
+int rg_env_symbols(const rg_t *h, int32_t *out_host) {
+    if (h->sub.empty()) { for (int i = 0; i < h->S.n; i++) out_host[i] = h->cfg.symbols; return 0; }
+    for (int i = 0; i < h->S.n; i++) out_host[i] = h->sub[h->g_of[i]]->cfg.symbols;
+    return 0;
+}
+
 int rg_set_stream(rg_t *h, void *hip_stream) {
+    for (rg_handle *sh : h->sub) SUBCHK(h, sh, rg_set_stream(sh, hip_stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
     h->stream = (hipStream_t)hip_stream;
@@ -269,6 +392,14 @@ int rg_seed(rg_t *h, const uint64_t *seed_lo, const uint64_t *seed_hi, int n) {
     if (n > h->S.n) n = h->S.n;
     if (n <= 0) return 0;
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->sub.empty()) {  // the first n envs of the handle are a prefix of every group (groups keep the env order)
+        for (rg_handle *sh : h->sub) {
+            std::vector<uint64_t> lo, hi;
+            for (int l = 0; l < sh->S.n && sh->ext[l] < n; l++) { lo.push_back(seed_lo[sh->ext[l]]); hi.push_back(seed_hi ? seed_hi[sh->ext[l]] : 0); }
+            if (!lo.empty()) SUBCHK(h, sh, rg_seed(sh, lo.data(), hi.data(), (int)lo.size()));
+        }
+        return 0;
+    }
     for (int i = 0; i < n; i++) { h->seed_lo[i] = seed_lo[i]; h->seed_hi[i] = seed_hi ? seed_hi[i] : 0; h->reseed[i] = 0; }
     if (h->spares) {
         // the spares of these envs were generated from the old seeds: drop them (k_step generates inline until k_regen has refilled them).
@@ -281,6 +412,11 @@ int rg_seed(rg_t *h, const uint64_t *seed_lo, const uint64_t *seed_hi, int n) {
 
 int rg_reset(rg_t *h) {
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->sub.empty()) {
+        for (rg_handle *sh : h->sub) SUBCHK(h, sh, rg_reset(sh));
+        h->screens_stale = true;
+        return assemble_small(h);
+    }
     { TimedLaunch t(h, 3); rgk_build(&h->S, &h->cfg, h->stream); }  // (k_build and a k_regen in flight share only the atomically advanced build counters)
     HIPCHK(h, hipGetLastError());
     h->render_pending = true;
@@ -293,6 +429,23 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
     HIPCHK(h, hipSetDevice(h->device));
     if (n_keys < 0) { h->err = "rg_step_prefix: negative key count"; return 1; }
     if (n_keys > h->S.n) n_keys = h->S.n;  // zip: surplus keys are dropped
+    if (!h->sub.empty()) {
+        const uint8_t *dkeys = keys;
+        if (!keys_on_device) {
+            if (!h->d_keys && !dev_alloc(h, &h->d_keys, (size_t)h->S.n)) return 1;
+            HIPCHK(h, hipMemcpyAsync(h->d_keys, keys, (size_t)n_keys, hipMemcpyHostToDevice, h->stream));
+            dkeys = h->d_keys;
+        }
+        for (rg_handle *sh : h->sub) {
+            int m = 0;  // the keyed envs of the group: a prefix of it
+            while (m < sh->S.n && sh->ext[m] < n_keys) m++;
+            if (m) rgk_gather_keys(dkeys, sh->d_ext, sh->d_keys_sub, m, h->stream);
+            SUBCHK(h, sh, rg_step_prefix(sh, sh->d_keys_sub, m, 1));
+        }
+        HIPCHK(h, hipGetLastError());
+        h->screens_stale = true;
+        return assemble_small(h);
+    }
     if (flush_render(h)) return 1;
     const uint8_t *dk = keys;
     if (!keys_on_device) {
@@ -323,6 +476,12 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
 
 int rg_sync(rg_t *h) {
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->sub.empty()) {
+        int rc = 0;
+        for (rg_handle *sh : h->sub)
+            if (rg_sync(sh) && !rc) { rc = 1; h->err = sh->err; }  // (every group is drained and its error word cleared)
+        if (rc) return rc;
+    }
     uint32_t err = 0;
     HIPCHK(h, hipMemcpyAsync(&err, h->d_err, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -338,22 +497,35 @@ int rg_sync(rg_t *h) {
     return 0;
 }
 
-int rg_screen(rg_t *h, uint8_t **dev) { HIPCHK(h, hipSetDevice(h->device)); if (flush_render(h)) return 1; *dev = h->S.screen; return 0; }
-int rg_hist(rg_t *h, uint8_t **dev) { HIPCHK(h, hipSetDevice(h->device)); if (flush_render(h)) return 1; *dev = h->S.hist; return 0; }
+// mirrors up to date: the pending render of an ordinary handle, the assembly of a parent's
+static int flush_mirrors(rg_handle *h) { return h->sub.empty() ? flush_render(h) : assemble_screens(h); }
+int rg_screen(rg_t *h, uint8_t **dev) { HIPCHK(h, hipSetDevice(h->device)); if (flush_mirrors(h)) return 1; *dev = h->S.screen; return 0; }
+int rg_hist(rg_t *h, uint8_t **dev) { HIPCHK(h, hipSetDevice(h->device)); if (flush_mirrors(h)) return 1; *dev = h->S.hist; return 0; }
 int rg_status(rg_t *h, int32_t **dev) { *dev = h->S.status; return 0; }
-int rg_flags(rg_t *h, uint32_t **dev) { HIPCHK(h, hipSetDevice(h->device)); if (flush_render(h)) return 1; *dev = h->S.flags; return 0; }
+int rg_flags(rg_t *h, uint32_t **dev) { HIPCHK(h, hipSetDevice(h->device)); if (flush_mirrors(h)) return 1; *dev = h->S.flags; return 0; }
 int rg_reward(rg_t *h, float **dev) { *dev = h->S.reward; return 0; }
 int rg_done(rg_t *h, uint8_t **dev) { *dev = h->S.done; return 0; }
 
 int rg_obs_channels(const rg_t *h, int symbol, uint32_t status_flag, int with_hist) {
-    return (symbol ? h->cfg.symbols : 1) + __builtin_popcount(status_flag & 0x1ffu) + (with_hist ? 1 : 0);
+    return (symbol ? h->planes_sym : 1) + __builtin_popcount(status_flag & 0x1ffu) + (with_hist ? 1 : 0);
 }
 
 static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, float *out_dev) {
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->sub.empty()) {  // every group encodes its envs straight into the handle's tensor (RgState::ext)
+        for (rg_handle *sh : h->sub) {
+            if (kind && sh->cfg.symbols > h->planes_sym) {
+                h->err = "symbol image: a config of the batch has more symbols (" + std::to_string(sh->cfg.symbols) + ") than env 0's (" + std::to_string(h->planes_sym) +
+                         "), which sets the channel count (python/src/lib.rs:281-285)";
+                return 1;
+            }
+            SUBCHK(h, sh, obs_common(sh, status_flag, with_hist, kind, out_dev));
+        }
+        return 0;
+    }
     {   // steady state: one fused pass refreshes the mirrors of Redraw envs and encodes every env
         TimedLaunch t(h, 2);
-        if (rgk_obs(&h->S, &h->cfg, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->d_err, h->stream)) {
+        if (rgk_obs(&h->S, &h->cfg, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->d_err, h->planes_sym, h->stream)) {
             HIPCHK(h, hipGetLastError());
             h->render_pending = false;
             return 0;
@@ -363,8 +535,8 @@ static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, fl
     if (flush_render(h)) return 1;
     {
         TimedLaunch t(h, 2);
-        rgk_encode(h->S.screen, h->S.hist, h->S.status, h->S.flags, h->d_err, h->S.n, h->S.hw, (size_t)h->S.hw, 10, h->cfg.symbols, status_flag & 0x1ffu,
-                   with_hist ? 1 : 0, kind, out_dev, h->stream);
+        rgk_encode(h->S.screen, h->S.hist, h->S.status, h->S.flags, h->d_err, h->S.n, h->S.hw, (size_t)h->S.hw, 10, h->cfg.symbols, h->planes_sym,
+                   status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->S.ext, h->stream);
     }
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -374,7 +546,7 @@ int rg_obs_symbol(rg_t *h, uint32_t status_flag, int with_hist, float *out_dev) 
 
 int rg_fetch_states(rg_t *h, uint8_t *screen, uint8_t *hist, int32_t *status, uint32_t *flags) {
     HIPCHK(h, hipSetDevice(h->device));
-    if (flush_render(h)) return 1;
+    if (flush_mirrors(h)) return 1;
     size_t n = (size_t)h->S.n, hw = (size_t)h->S.hw;
     if (screen) HIPCHK(h, hipMemcpyAsync(screen, h->S.screen, n * hw, hipMemcpyDeviceToHost, h->stream));
     if (hist) HIPCHK(h, hipMemcpyAsync(hist, h->S.hist, n * hw, hipMemcpyDeviceToHost, h->stream));
@@ -423,8 +595,8 @@ int rg_encode_host_batch(int device, int n, const uint8_t *screen, const uint8_t
               hipMemcpy(sc.buf + o_st, status, (size_t)n * 40, hipMemcpyHostToDevice) == hipSuccess && hipMemset(sc.err, 0, 4) == hipSuccess &&
               (!with_hist || hipMemcpy2D(sc.buf + o_hist, hw4, hist, hw, hw, (size_t)n, hipMemcpyHostToDevice) == hipSuccess);
     if (!ok) { g_create_err = "hipMemcpy failed"; return 1; }
-    rgk_encode(sc.buf + o_scr, sc.buf + o_hist, reinterpret_cast<const int32_t *>(sc.buf + o_st), nullptr, sc.err, n, (int)hw, hw4, 10, symbols, status_flag,
-               with_hist ? 1 : 0, kind, reinterpret_cast<float *>(sc.buf + o_out), nullptr);
+    rgk_encode(sc.buf + o_scr, sc.buf + o_hist, reinterpret_cast<const int32_t *>(sc.buf + o_st), nullptr, sc.err, n, (int)hw, hw4, 10, symbols, symbols, status_flag,
+               with_hist ? 1 : 0, kind, reinterpret_cast<float *>(sc.buf + o_out), nullptr, nullptr);
     if (hipMemcpy(out_host, sc.buf + o_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&err, sc.err, 4, hipMemcpyDeviceToHost) != hipSuccess) {
         g_create_err = "encode kernel failed"; return 1;
     }
@@ -464,7 +636,7 @@ int rg_compact_record_bytes(const rg_t *h, int with_hist) { return h->S.hw + 40 
 int rg_pack_compact(rg_t *h, int with_hist, uint8_t *out_dev) {
     HIPCHK(h, hipSetDevice(h->device));
     if (h->S.hw & 3) { h->err = "rg_pack_compact needs H*W divisible by 4"; return 1; }
-    if (flush_render(h)) return 1;
+    if (flush_mirrors(h)) return 1;
     rgk_pack(&h->S, with_hist ? 1 : 0, out_dev, h->stream);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -476,7 +648,7 @@ int rg_expand_compact(rg_t *h, const uint8_t *packed_dev, int n, int packed_has_
     if (with_hist && !packed_has_hist) { h->err = "rg_expand_compact: the packed batch carries no history plane"; return 1; }
     const size_t hw = (size_t)h->S.hw, rec = hw + 40 + (packed_has_hist ? hw : 0);
     rgk_encode(packed_dev, packed_dev + hw + 40, reinterpret_cast<const int32_t *>(packed_dev + hw), nullptr, h->d_err, n, (int)hw, rec, rec / 4, h->cfg.symbols,
-               status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->stream);
+               h->cfg.symbols, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, nullptr, h->stream);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -498,6 +670,7 @@ int rg_status_vec(rg_t *h, uint32_t status_flag, int32_t *out_host) {
 // ---- action-history log (GameState::dump_history, python/src/lib.rs:245-250 -> RunTime::saved_inputs_as_json, core/src/lib.rs:357-375) ----
 int rg_history_enable(rg_t *h, int cap_per_env) {
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->sub.empty()) { for (rg_handle *sh : h->sub) SUBCHK(h, sh, rg_history_enable(sh, cap_per_env)); return 0; }
     if (cap_per_env <= 0) { h->err = "rg_history_enable: capacity must be positive"; return 1; }
     if (h->S.klog) { h->err = "rg_history_enable: already enabled"; return 1; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -512,6 +685,13 @@ int rg_history_enable(rg_t *h, int cap_per_env) {
 
 int rg_history_keys(rg_t *h, int env, int which, uint8_t *keys, size_t cap, uint32_t *len) {
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->sub.empty()) {
+        if (env < 0 || env >= h->S.n) { h->err = "rg_history_keys: env / which out of range"; return 1; }
+        rg_handle *sh = h->sub[h->g_of[env]];
+        const int rc = rg_history_keys(sh, h->l_of[env], which, keys, cap, len);
+        if (rc) h->err = sh->err;
+        return rc;
+    }
     if (!h->S.klog) { h->err = "the action history is not enabled (rg_history_enable)"; return 1; }
     if (env < 0 || env >= h->S.n || (which != 0 && which != 1)) { h->err = "rg_history_keys: env / which out of range"; return 1; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -564,6 +744,15 @@ int rg_dump_history(rg_t *h, int env, int which, char *buf, size_t cap, size_t *
 
 int rg_counters(rg_t *h, uint64_t out[8], int reset) {
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->sub.empty()) {
+        if (out) for (int k = 0; k < 8; k++) out[k] = 0;
+        for (rg_handle *sh : h->sub) {
+            uint64_t o[8];
+            SUBCHK(h, sh, rg_counters(sh, o, reset));
+            if (out) for (int k = 0; k < 8; k++) out[k] += o[k];
+        }
+        return 0;
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (!h->S.stats) { if (out) memset(out, 0, 64); return 0; }
     if (out) {
@@ -592,6 +781,7 @@ int rg_probe_sclk(rg_t *h, double *mhz) {
 // (word 0 = record count, words 1.. = phase << 48 | ticks, word 63 = whole-wave ticks)
 int rg_prof(rg_t *h, int enable, unsigned long long *out) {
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->sub.empty()) { h->err = "rg_prof: not available for a batch with several config groups"; return 1; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const size_t words = (size_t)((h->S.n + 15) / 16) * 64;  // k_step runs 16..64 envs per wave
     if (out && h->S.prof) HIPCHK(h, hipMemcpy(out, h->S.prof, words * 8, hipMemcpyDeviceToHost));
@@ -603,6 +793,7 @@ int rg_prof(rg_t *h, int enable, unsigned long long *out) {
 
 int rg_timing_enable(rg_t *h, int on) {
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->sub.empty()) { for (rg_handle *sh : h->sub) SUBCHK(h, sh, rg_timing_enable(sh, on)); return 0; }
     if (on && h->ev[0].empty())
         for (int k = 0; k < 4; k++) {
             h->ev[k].resize(2 * RG_TIMING_MAX);
@@ -617,6 +808,15 @@ int rg_timing_enable(rg_t *h, int on) {
 
 int rg_timing_read(rg_t *h, double ms[4], uint64_t launches[4]) {
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->sub.empty()) {  // sums over the groups: `launches` then counts group launches
+        for (int k = 0; k < 4; k++) { ms[k] = 0; launches[k] = 0; }
+        for (rg_handle *sh : h->sub) {
+            double m[4]; uint64_t l[4];
+            SUBCHK(h, sh, rg_timing_read(sh, m, l));
+            for (int k = 0; k < 4; k++) { ms[k] += m[k]; launches[k] += l[k]; }
+        }
+        return 0;
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int k = 0; k < 4; k++) {
         double sum = 0;
@@ -633,6 +833,7 @@ int rg_timing_read(rg_t *h, double ms[4], uint64_t launches[4]) {
 
 int rg_dump_config(const rg_t *h, int env, char *buf, size_t cap) {
     if (env < 0 || env >= h->S.n) return 1;
+    if (!h->sub.empty()) return rg_dump_config(h->sub[h->g_of[env]], h->l_of[env], buf, cap);
     std::string s = rg_dump_config_json(h->parsed, h->seed_lo[env], h->seed_hi[env], !h->reseed[env]);
     if (s.size() + 1 > cap) return 1;
     memcpy(buf, s.c_str(), s.size() + 1);
@@ -651,6 +852,11 @@ int rg_config_canonical(const char *cfg_json, char *buf, size_t cap) {
 
 int rg_debug_descend(rg_t *h) {
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->sub.empty()) {
+        for (rg_handle *sh : h->sub) SUBCHK(h, sh, rg_debug_descend(sh));
+        h->screens_stale = true;
+        return assemble_small(h);
+    }
     if (flush_render(h)) return 1;
     rgk_debug_descend(&h->S, &h->cfg, h->stream);
     HIPCHK(h, hipGetLastError());
@@ -661,6 +867,11 @@ int rg_debug_descend(rg_t *h) {
 int rg_debug_fetch(rg_t *h, int env, rg_debug_state *out, uint16_t *cells) {
     HIPCHK(h, hipSetDevice(h->device));
     if (env < 0 || env >= h->S.n) { h->err = "env out of range"; return 1; }
+    if (!h->sub.empty()) {
+        rg_handle *sh = h->sub[h->g_of[env]];
+        SUBCHK(h, sh, rg_debug_fetch(sh, h->l_of[env], out, cells));
+        return 0;
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const RgState &S = h->S;
     const size_t n = (size_t)S.n, e = (size_t)env;

@@ -93,7 +93,8 @@ __device__ __constant__ uint8_t kStatusIdx[9] = {0, 2, 3, 4, 5, 6, 7, 8, 9};
 // rs / rst: distance between two envs' records in bytes (screen, hist) and in i32 words (status): hw and 10 for the mirrors, the record size for
 // a packed compact batch (rg_pack_compact)
 __global__ void __launch_bounds__(256) k_gray(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status,
-                                              int n, int hw, size_t rs, size_t rst, int symbols, uint32_t sflag, int with_hist, float *__restrict__ out) {
+                                              int n, int hw, size_t rs, size_t rst, int symbols, uint32_t sflag, int with_hist, float *__restrict__ out,
+                                              const int32_t *__restrict__ ext) {
     const int q = hw >> 2;  // quads per env (hw % 4 == 0 checked on the host)
     const size_t total = (size_t)n * q;
     const int nplanes = 1 + __popc(sflag) + (with_hist ? 1 : 0);
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(256) k_gray(const uint8_t *__restrict__ screen
         v.y = (float)(uint8_t)tile_to_sym((s4 >> 8) & 0xff) / fsym;
         v.z = (float)(uint8_t)tile_to_sym((s4 >> 16) & 0xff) / fsym;
         v.w = (float)(uint8_t)tile_to_sym(s4 >> 24) / fsym;
-        float4 *o = reinterpret_cast<float4 *>(out + (size_t)e * nplanes * hw) + i;
+        float4 *o = reinterpret_cast<float4 *>(out + (size_t)(ext ? ext[e] : e) * nplanes * hw) + i;
         o[0] = v;
         int p = 1;
         for (int b = 0; b < 9; b++)
@@ -127,10 +128,11 @@ __global__ void __launch_bounds__(256) k_gray(const uint8_t *__restrict__ screen
 
 __global__ void __launch_bounds__(256) k_symbol(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status,
                                                 uint32_t *__restrict__ flags, uint32_t *__restrict__ err_any,
-                                                int n, int hw, size_t rs, size_t rst, int symbols, uint32_t sflag, int with_hist, float *__restrict__ out) {
+                                                int n, int hw, size_t rs, size_t rst, int symbols, int planes_sym, uint32_t sflag, int with_hist, float *__restrict__ out,
+                                                const int32_t *__restrict__ ext) {
     const int q = hw >> 2;
     const size_t total = (size_t)n * q;
-    const int nplanes = symbols + __popc(sflag) + (with_hist ? 1 : 0);
+    const int nplanes = planes_sym + __popc(sflag) + (with_hist ? 1 : 0);  // planes_sym >= symbols: the handle's one-hot depth (groups of a handle may differ)
     const uint32_t symbol_max = (uint32_t)symbols - 1;  // construct_symbol_map fills channels 0..symbols-2 (symbol.rs:51-71)
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
         int e = (int)(g / q), i = (int)(g - (size_t)e * q);
@@ -140,14 +142,14 @@ __global__ void __launch_bounds__(256) k_symbol(const uint8_t *__restrict__ scre
             if (flags) atomicOr(&flags[e], RG_FLAG_ERR_TILE);
             atomicOr(err_any, RG_FLAG_ERR_TILE);
         }
-        float4 *o = reinterpret_cast<float4 *>(out + (size_t)e * nplanes * hw) + i;
-        for (uint32_t ch = 0; ch < (uint32_t)symbols; ch++) {
+        float4 *o = reinterpret_cast<float4 *>(out + (size_t)(ext ? ext[e] : e) * nplanes * hw) + i;
+        for (uint32_t ch = 0; ch < (uint32_t)planes_sym; ch++) {
             float4 v;
             v.x = a == ch ? 1.f : 0.f; v.y = b == ch ? 1.f : 0.f; v.z = cc == ch ? 1.f : 0.f; v.w = d == ch ? 1.f : 0.f;
             if (ch >= symbol_max) v.x = v.y = v.z = v.w = 0.f;
             o[(size_t)ch * q] = v;
         }
-        int p = symbols;
+        int p = planes_sym;
         for (int bb = 0; bb < 9; bb++)
             if (sflag & (1u << bb)) {
                 float f = (float)status[(size_t)e * rst + kStatusIdx[bb]];
@@ -193,7 +195,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 template <int KIND>
 __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint32_t sflag, int with_hist, float *__restrict__ out,
-                                                    uint32_t *__restrict__ err_any, int tpe, int epb) {
+                                                    uint32_t *__restrict__ err_any, int tpe, int epb, int planes_sym) {
     extern __shared__ __align__(16) uint8_t smem[];
     float *lutf = reinterpret_cast<float *>(smem);        // glyph -> gray value (KIND 0)
     uint8_t *luts = smem + 512;                            // glyph -> symbol id
@@ -209,7 +211,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
     }
     for (int g = tid; g < RG_MAX_ENEMY_KINDS + 6; g += blockDim.x) mtile[g] = c.mon[g].tile;
     const int le = tid / tpe, lt = tid - le * tpe;
-    const int base_planes = KIND ? symbols : 1;
+    const int base_planes = KIND ? planes_sym : 1;  // planes_sym >= symbols: the handle's one-hot depth (config groups of one handle may differ)
     const int nplanes = base_planes + __popc(sflag) + (with_hist ? 1 : 0);
     uint8_t *scr = envs + (size_t)le * OBS_ENV_BYTES(HW);
     ObsTabs *tb = reinterpret_cast<ObsTabs *>(scr + HW);
@@ -327,7 +329,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
             uint32_t *m4 = reinterpret_cast<uint32_t *>(S.screen + (size_t)e * HW);
             const uint32_t *scr4 = reinterpret_cast<const uint32_t *>(scr);
             const uint32_t *hist4 = reinterpret_cast<const uint32_t *>(S.hist + (size_t)e * HW);
-            float4 *o = reinterpret_cast<float4 *>(out + (size_t)e * nplanes * HW);
+            float4 *o = reinterpret_cast<float4 *>(out + (size_t)(S.ext ? S.ext[e] : e) * nplanes * HW);
             const int q4 = HW >> 2;
             const uint32_t smax = (uint32_t)symbols - 1;  // construct_symbol_map fills channels 0..symbols-2 (symbol.rs:51-71)
             float stf[9];
@@ -351,7 +353,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                         store_obs(&o[(size_t)ch * q4 + q], v);
                     }
                     float4 z; z.x = z.y = z.z = z.w = 0.f;
-                    store_obs(&o[(size_t)smax * q4 + q], z);  // the last channel is never set
+                    for (uint32_t ch = smax; ch < (uint32_t)planes_sym; ch++) store_obs(&o[(size_t)ch * q4 + q], z);  // the last channel is never set
                 }
                 int p = base_planes;
                 for (int b = 0; b < nst; b++, p++) {
@@ -388,6 +390,27 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ screen
     }
 }
 
+__global__ void __launch_bounds__(256) k_scatter_rows(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int32_t *__restrict__ ext, int n, int row_bytes) {
+    if ((row_bytes & 3) == 0) {
+        const int rw = row_bytes >> 2;
+        const size_t total = (size_t)n * rw;
+        for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+            const int e = (int)(g / rw), i = (int)(g - (size_t)e * rw);
+            reinterpret_cast<uint32_t *>(dst)[(size_t)ext[e] * rw + i] = reinterpret_cast<const uint32_t *>(src)[g];
+        }
+    } else {
+        const size_t total = (size_t)n * row_bytes;
+        for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+            const int e = (int)(g / row_bytes), i = (int)(g - (size_t)e * row_bytes);
+            dst[(size_t)ext[e] * row_bytes + i] = src[g];
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_gather_keys(const uint8_t *__restrict__ keys, const int32_t *__restrict__ ext, uint8_t *__restrict__ dst, int n) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n) dst[e] = keys[ext[e]];
+}
+
 __global__ void k_probe_clock(unsigned long long *out, int spin) {
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     uint32_t x = threadIdx.x + 1u;
@@ -399,18 +422,18 @@ __global__ void k_probe_clock(unsigned long long *out, int spin) {
 // scalar fallbacks for H*W not divisible by 4 (never the case for the benchmark sizes)
 __global__ void __launch_bounds__(256) k_encode_scalar(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status,
                                                        uint32_t *__restrict__ flags, uint32_t *__restrict__ err_any, int n, int hw, size_t rs, size_t rst, int symbols,
-                                                       uint32_t sflag, int with_hist, int kind, float *__restrict__ out) {
+                                                       int planes_sym, uint32_t sflag, int with_hist, int kind, float *__restrict__ out, const int32_t *__restrict__ ext) {
     const size_t total = (size_t)n * hw;
-    const int base = kind ? symbols : 1;
+    const int base = kind ? planes_sym : 1;
     const int nplanes = base + __popc(sflag) + (with_hist ? 1 : 0);
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
         int e = (int)(g / hw), i = (int)(g - (size_t)e * hw);
         uint32_t sym = tile_to_sym(screen[(size_t)e * rs + i]);
-        float *o = out + (size_t)e * nplanes * hw + i;
+        float *o = out + (size_t)(ext ? ext[e] : e) * nplanes * hw + i;
         if (!kind) o[0] = (float)(uint8_t)sym / (float)(uint8_t)symbols;
         else {
             if (sym >= (uint32_t)symbols - 1) { if (flags) atomicOr(&flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
-            for (int ch = 0; ch < symbols; ch++) o[(size_t)ch * hw] = (sym == (uint32_t)ch && ch < symbols - 1) ? 1.f : 0.f;
+            for (int ch = 0; ch < planes_sym; ch++) o[(size_t)ch * hw] = (sym == (uint32_t)ch && ch < symbols - 1) ? 1.f : 0.f;
         }
         int p = base;
         for (int b = 0; b < 9; b++)
@@ -428,7 +451,7 @@ void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st) {
     hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RENDER_THREADS), 0, st, *S, *c);
 }
 // fused mirror refresh + encode; returns 0 if the geometry is not supported (caller falls back to k_render + encode)
-int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, hipStream_t st) {
+int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, int planes_sym, hipStream_t st) {
     int hw = c->width * c->height;
     if (hw & 7) return 0;
     int q8 = hw / 8;
@@ -439,22 +462,22 @@ int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, 
     int blocks = (S->n + epb - 1) / epb;
     // persistent grid: launching one tiny workgroup per env is dispatch-rate bound (65 536 one-wave blocks: 71 us; 16 384 looping blocks: 51 us)
     { const char *ev = getenv("RG_OBS_BLOCKS"); int cap = ev ? atoi(ev) : (bthreads <= 64 ? 16384 : 8192); if (blocks > cap) blocks = cap; }
-    if (!kind) hipLaunchKernelGGL(k_obs<0>, dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb);
-    else hipLaunchKernelGGL(k_obs<1>, dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb);
+    if (!kind) hipLaunchKernelGGL(k_obs<0>, dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym);
+    else hipLaunchKernelGGL(k_obs<1>, dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym);
     return 1;
 }
 void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, size_t rs, size_t rst,
-                int symbols, uint32_t sflag, int with_hist, int kind, float *out, hipStream_t st) {
+                int symbols, int planes_sym, uint32_t sflag, int with_hist, int kind, float *out, const int32_t *ext, hipStream_t st) {
     if ((hw & 3) == 0 && (rs & 3) == 0) {
         size_t total = (size_t)n * (hw >> 2);
         int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
         if (blocks < 1) blocks = 1;
-        if (!kind) hipLaunchKernelGGL(k_gray, dim3(blocks), dim3(256), 0, st, screen, hist, status, n, hw, rs, rst, symbols, sflag, with_hist, out);
-        else hipLaunchKernelGGL(k_symbol, dim3(blocks), dim3(256), 0, st, screen, hist, status, flags, err_any, n, hw, rs, rst, symbols, sflag, with_hist, out);
+        if (!kind) hipLaunchKernelGGL(k_gray, dim3(blocks), dim3(256), 0, st, screen, hist, status, n, hw, rs, rst, symbols, sflag, with_hist, out, ext);
+        else hipLaunchKernelGGL(k_symbol, dim3(blocks), dim3(256), 0, st, screen, hist, status, flags, err_any, n, hw, rs, rst, symbols, planes_sym, sflag, with_hist, out, ext);
     } else {
         size_t total = (size_t)n * hw;
         int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-        hipLaunchKernelGGL(k_encode_scalar, dim3(blocks), dim3(256), 0, st, screen, hist, status, flags, err_any, n, hw, rs, rst, symbols, sflag, with_hist, kind, out);
+        hipLaunchKernelGGL(k_encode_scalar, dim3(blocks), dim3(256), 0, st, screen, hist, status, flags, err_any, n, hw, rs, rst, symbols, planes_sym, sflag, with_hist, kind, out, ext);
     }
 }
 // compact observation record of every env: {screen u8[hw], status i32[10], hist u8[hw] (optional)}, back to back -- the payload of the ONE
@@ -466,6 +489,16 @@ void rgk_pack(const RgState *S, int with_hist, uint8_t *out, hipStream_t st) {
     int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, st, S->screen, S->hist, S->status, S->n, hw, with_hist, reinterpret_cast<uint32_t *>(out));
+}
+// handle with several config groups: rows of a group's array -> the handle's array at the group's env indices (row_words 4-byte words per env)
+void rgk_scatter_rows(const void *src, void *dst, const int32_t *ext, int n, int row_bytes, hipStream_t st) {
+    const size_t total = (size_t)n * row_bytes;
+    int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_scatter_rows, dim3(blocks), dim3(256), 0, st, (const uint8_t *)src, (uint8_t *)dst, ext, n, row_bytes);
+}
+void rgk_gather_keys(const uint8_t *keys, const int32_t *ext, uint8_t *dst, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_gather_keys, dim3((n + 255) / 256), dim3(256), 0, st, keys, ext, dst, n);
 }
 // shader-clock probe: one wave spins for `spin` iterations and reports {s_memtime ticks (shader clock), s_memrealtime ticks (constant 100 MHz)}
 void rgk_probe_clock(unsigned long long *out, int spin, hipStream_t st) { hipLaunchKernelGGL(k_probe_clock, dim3(1), dim3(64), 0, st, out, spin); }

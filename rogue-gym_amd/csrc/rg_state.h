@@ -98,6 +98,9 @@ struct RgState {
     // {n_desc, n_mon, n_plain, -} counters used alternately (the idle set is zeroed by k_classify for the step after)
     int32_t *bin_list;
     uint32_t *bin_cnt;
+    // handle with per-env configs that differ in more than the seed: this RgState is one config GROUP, and env e of the group is env ext[e] of the
+    // handle (observation tensors are written at the handle's index); NULL = the group is the whole handle
+    const int32_t *ext;
     uint32_t *err_any;  // [1] OR of every error bit raised since the last rg_sync
     // ThreadConductor::step zips keys with envs (thread_impls.rs:62-64): envs >= n_keys receive no key this call
     int32_t n_keys;

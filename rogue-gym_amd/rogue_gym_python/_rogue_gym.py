@@ -40,7 +40,7 @@ class RgDebugState(C.Structure):
 _lib = None
 
 _INT_FUNCS = (
-    "rg_create", "rg_dims", "rg_set_stream", "rg_seed", "rg_reset", "rg_step", "rg_step_prefix", "rg_sync", "rg_screen", "rg_hist", "rg_status", "rg_flags",
+    "rg_create", "rg_dims", "rg_env_symbols", "rg_set_stream", "rg_seed", "rg_reset", "rg_step", "rg_step_prefix", "rg_sync", "rg_screen", "rg_hist", "rg_status", "rg_flags",
     "rg_reward", "rg_done", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_encode_host_batch", "rg_obs_host",
     "rg_host_alloc", "rg_compact_record_bytes", "rg_pack_compact", "rg_expand_compact", "rg_status_vec", "rg_history_enable", "rg_history_keys",
     "rg_dump_history", "rg_counters", "rg_probe_sclk", "rg_dump_config", "rg_config_canonical", "rg_debug_fetch", "rg_debug_descend", "rg_timing_enable", "rg_timing_read",
@@ -71,6 +71,7 @@ def load_library():
         "rg_destroy": [vp],
         "rg_last_error": [vp],
         "rg_dims": [vp] + [C.POINTER(i32)] * 4,
+        "rg_env_symbols": [vp, vp],
         "rg_set_stream": [vp, vp],
         "rg_seed": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i32],
         "rg_reset": [vp],
@@ -166,6 +167,9 @@ class _Handle:
         hh, ww, ss, nn = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         L.rg_dims(h, C.byref(hh), C.byref(ww), C.byref(ss), C.byref(nn))
         self.height, self.width, self.symbols, self.n = hh.value, ww.value, ss.value, nn.value
+        self.env_symbols = np.empty(self.n, np.int32)  # per env: configs of one batch may differ (PlayerState.symbols is the env's own)
+        L.rg_env_symbols(h, self.env_symbols.ctypes.data)
+        self.uniform_symbols = bool((self.env_symbols == self.symbols).all())
         self.pool = _PinnedPool(L)
         self.epoch = 0  # bumped by every call that changes the device-side states (a StateBatch remembers the epoch it was taken at)
 
@@ -267,7 +271,8 @@ class StateBatch:
             raise IndexError(i)
         st = self._items.get(i)
         if st is None:
-            st = self._items[i] = PlayerState(self.screen[i], self.hist[i], self.status[i], self.symbols, int(self.flags[i]), self._hd.device, batch=self, index=i)
+            st = self._items[i] = PlayerState(self.screen[i], self.hist[i], self.status[i], int(self._hd.env_symbols[i]), int(self.flags[i]), self._hd.device,
+                                              batch=self if (self._hd.uniform_symbols) else None, index=i)
         return st
 
     def __iter__(self):
@@ -307,11 +312,16 @@ class StateBatch:
         img = np.empty((self.n, c, h, w), np.float32)
         if hd.h is not None and hd.epoch == self._epoch:
             hd.check(L.rg_obs_host(hd.h, int(kind), flag, int(with_hist), img.ctypes.data))  # the device still holds exactly these states
-        else:  # the envs have moved on: encode the snapshot itself
+        elif hd.uniform_symbols:  # the envs have moved on: encode the snapshot itself
             rc = L.rg_encode_host_batch(hd.device, self.n, self.screen.ctypes.data, self.hist.ctypes.data, self.status.ctypes.data, h, w, self.symbols, flag,
                                         int(with_hist), int(kind), img.ctypes.data)
             if rc:
                 raise RuntimeError("Error in rogue-gym: " + L.rg_last_error(None).decode())
+        else:  # configs with different `symbols` in one batch: env by env, each with its own (gray values divide by the env's symbols)
+            if kind:
+                raise RuntimeError("Error in rogue-gym: a batch whose configs differ in `symbols` has no common symbol-image shape once the envs moved on")
+            for i in range(self.n):
+                img[i] = self[i]._image(kind, flag, with_hist)
         if img.nbytes <= _IMAGE_BATCH_LIMIT:
             self._images[key] = img
         return img

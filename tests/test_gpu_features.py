@@ -335,3 +335,104 @@ def test_step_keys_rejects_bad_tensors(goldens):
             env.step_keys(bad)
     assert env.all_gather_obs() is env.obs  # world 1: the f32 batch itself, the same type as the distributed result
     env.close()
+
+
+def _mixed_configs(goldens, n):
+    """One GameConfig per env (python/src/lib.rs:270-294), differing in far more than the seed: monsters or none, room grids, rates, gold, hunger."""
+    mini = goldens["configs"]["mini"]
+    variants = [
+        dict(mini),
+        dict(mini, enemies={"enemies": []}),
+        dict(mini, dungeon={"style": "rogue", "room_num_x": 1, "room_num_y": 2, "dark_level": 2, "maze_rate_inv": 3, "max_extra_edges": 2}),
+        dict(mini, **VARIED["rich_dark_mazy"]),
+        dict(mini, **VARIED["poor_bright"]),
+        dict(mini, enemies={"enemies": [1, 18, 10], "appear_rate_gold": 95, "appear_rate_nogold": 70}, hide_dungeon=False),
+    ]
+    order = np.random.RandomState(3).randint(0, len(variants), n)  # groups interleaved in the env order
+    return [dict(variants[k], seed=4000 + i) for i, k in enumerate(order)]
+
+
+def test_heterogeneous_configs_per_env(goldens):
+    """8f-3 / VERDICT r1: ParallelGameState takes one config PER ENV.  Six different configs interleaved over 240 envs behind one handle, lock step
+    against one oracle per env: mirrors, flags, rewards, images, history log, prefix stepping and per-env seeding all in the caller's env order."""
+    from oracle.pyoracle import OracleEnv
+    from rogue_gym.envs import DungeonType, HipVecRogueEnv, ImageSetting, ParallelRogueEnv, StatusFlag
+
+    n = 240
+    cfgs = _mixed_configs(goldens, n)
+    st = ImageSetting(DungeonType.GRAY, StatusFlag.FULL, True)
+    env = ParallelRogueEnv(cfgs, max_steps=60, image_setting=st)
+    env.game.enable_history(64)
+    oracles = [OracleEnv(c, max_steps=60) for c in cfgs]
+    assert env.game.symbols() == oracles[0].symbols
+    for i in (0, 1, 2, 3, 7, 100):
+        assert json.loads(env.game.dump_config(i)) == json.loads(json.dumps(cfgs[i])) or json.loads(env.game.dump_config(i))["seed"] == cfgs[i]["seed"]
+
+    def check(states, where):
+        for i, o in enumerate(oracles):
+            assert states[i].dungeon == o.dungeon(), "%s env %d screen" % (where, i)
+            assert [int(v) for v in states.status[i].astype(np.uint32)] == [int(v) for v in o.status_arr()], "%s env %d status" % (where, i)
+            assert bool(states.is_terminal[i]) == o.flags()["is_terminal"], "%s env %d terminal" % (where, i)
+            assert np.array_equal(states.hist[i], o.hist()), "%s env %d hist" % (where, i)
+            assert states[i].symbols == o.symbols
+
+    check(env.states, "t=0")
+    rng = np.random.RandomState(12)
+    for t in range(150):
+        keys = ALL_KEYS[rng.randint(0, len(ALL_KEYS), n)]
+        before = [int(o.status_arr()[1]) for o in oracles]
+        states, rewards, dones, _ = env.step(bytes(keys).decode("latin-1"))
+        for i, o in enumerate(oracles):
+            o.step_autoreset(int(keys[i]))
+        check(states, "t=%d" % (t + 1))
+        assert rewards == [max(0, int(o.status_arr()[1]) - b) for o, b in zip(oracles, before)]
+        if t % 30 == 29:
+            img = env.images()
+            for i in range(0, n, 5):
+                assert np.array_equal(img[i], oracles[i].gray_image(0x1FF, True)), "image env %d" % i
+    # prefix stepping and per-env seeding route through the groups in env order
+    states = env.game.step(b"h" * 100)
+    for i, o in enumerate(oracles[:100]):
+        o.step_autoreset(ord("h"))
+    check(states, "prefix")
+    env.seed([9000 + i for i in range(50)])
+    states = env.reset()
+    for i, o in enumerate(oracles):
+        if i < 50:
+            o.set_seed(9000 + i)
+        o.reset()
+    check(states, "reseeded")
+    assert keys_of_history(env.game.dump_history(3)) == ""
+    env.close()
+    # the device-tensor path over the same mixed batch
+    venv = HipVecRogueEnv(cfgs, max_steps=60, image_setting=st)
+    oracles = [OracleEnv(c, max_steps=60) for c in cfgs]
+    import torch
+    for t in range(80):
+        keys = ALL_KEYS[rng.randint(0, len(ALL_KEYS), n)]
+        obs, rew, done = venv.step_keys(torch.from_numpy(keys.copy()).to(venv.device))
+        for i, o in enumerate(oracles):
+            o.step_autoreset(int(keys[i]))
+    torch.cuda.synchronize()
+    host = obs.cpu().numpy()
+    for i, o in enumerate(oracles):
+        assert np.array_equal(host[i], o.gray_image(0x1FF, True)), "tensor obs env %d" % i
+        assert bool(done[i].item()) == o.flags()["is_terminal"]
+    assert venv.counters()["keys"] == 80 * n
+    with pytest.raises(RuntimeError, match="share width and height"):
+        ParallelRogueEnv([cfgs[0], dict(goldens["configs"]["default"], seed=1)])
+    venv.close()
+
+
+def test_binned_lane_mapping_is_bit_exact(goldens):
+    """The optional k_classify -> list-driven k_step mapping (ROGUE_GYM_HIP_BINS=1) plays every env exactly like the index-order mapping:
+    the lock-step parity tests again, in a process with the knob set."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, ROGUE_GYM_HIP_BINS="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "lockstep_random_policy or lockstep_run_keys or stair_seekers_with or frequent_descents or inline_generation"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in r.stdout
