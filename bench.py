@@ -24,7 +24,8 @@ The metric is defined on the STEADY-STATE episode mix ("steady-sta
 including auto-resets"): right after creation all 65 536 envs are at step 0 of their first episode -- every monster of the start room wakes
 at once, every DistCache is cold, nobody resets -- a heavier, unrepresentative transient (measured: k_step 160 us vs 100 us; clocks and spares
 have nothing to do with it, see profiles/r02_driver_repro.txt).  A DISCLOSED pre-roll ("preroll" in the JSON: --preroll-steps untimed steps
-of the measured batch, default 1000 = one max_steps horizon) therefore precedes the W warm-up steps; the first K steps of that pre-roll are
+of the measured batch, default 1500 = 1.5 max_steps horizons -- at step 1000 the 40 % of the envs that survived their first episode hit max_steps together
+and the next few dozen steps are a second such transient, so the window must not sit on a multiple of max_steps) therefore precedes the W warm-up steps; the first K steps of that pre-roll are
 timed too and reported as "preroll.cold_start" so that the transient's own rate is on record next to `value`.
 
 Rank 0 prints ONE JSON line: the contract fields + "roofline" (dominant kernel, HIP-event timed on the launch stream,
@@ -179,8 +180,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the short extra_workloads runs (default / nohide-symbol)")
     ap.add_argument("--no-repeats", action="store_true", help="skip the 4 further runs of K steps (median)")
     ap.add_argument("--clock-warm-s", type=float, default=1.5, help="untimed fixed-duration stepping of a SCRATCH batch before anything else (0 = off)")
-    ap.add_argument("--preroll-steps", type=int, default=1000, help="untimed steps of the MEASURED batch before the warm-up: reach the steady-state episode mix "
-                    "the metric is defined on (the first --steps of them are timed and reported as preroll.cold_start); 0 = off")
+    ap.add_argument("--preroll-steps", type=int, default=1500, help="untimed steps of the MEASURED batch before the warm-up: reach the steady-state episode mix "
+                    "the metric is defined on (the first --steps of them are timed and reported as preroll.cold_start); 0 = off.  1.5 x max_steps: "
+                    "not on a multiple of max_steps, where the survivors of the synchronised first episodes all reset at once")
     ap.add_argument("--time-every", type=int, default=8, help="bracket every N-th kernel launch with HIP events (every launch when steps < 64)")
     ap.add_argument("--gather-steps", type=int, default=50, help="extra steps timed WITH the observation all-gather (N>1)")
     args = ap.parse_args()

@@ -44,6 +44,7 @@ struct rg_handle {
     uint32_t *d_err = nullptr;
     uint8_t *d_keys = nullptr;
     bool render_pending = false;
+    bool stair_valid = false;    // a render / observation pass has listed the on-stairs envs since the last change of any player position
     float *obs_scratch = nullptr;  // rg_obs_host: device-side observation buffer, kept between calls
     size_t obs_scratch_cap = 0;
     std::vector<uint64_t> seed_lo, seed_hi;  // host copy of the seeds the next reset will use (reseed envs: the base of the per-build hash)
@@ -113,8 +114,12 @@ static void free_all(rg_handle *h) {
     h->allocs.clear();
 }
 
+// every render / observation pass lists the envs whose player stands on the stairs into the stair set it is given (alternating) for the k_step after it
+static void next_stair_set(rg_handle *h) { h->S.stair_parity ^= 1; h->stair_valid = true; }
+
 static int flush_render(rg_handle *h) {
     if (h->render_pending) {
+        next_stair_set(h);
         { TimedLaunch t(h, 1); rgk_render(&h->S, &h->cfg, h->stream); }
         HIPCHK(h, hipGetLastError());
         h->render_pending = false;
@@ -197,7 +202,7 @@ static int create_homog(const char *const *cfg_json, int n_env, uint64_t max_ste
               dev_alloc(h, &S.mon_w0, RG_MAX_ROOMS * n) && dev_alloc(h, &S.mon_hp, RG_MAX_ROOMS * n) && dev_alloc(h, &S.mon_exp, RG_MAX_ROOMS * n) &&
               dev_alloc(h, &S.mon_cnt, n) && dev_alloc(h, &S.gold_pos, RG_MAX_ROOMS * n) && dev_alloc(h, &S.gold_amt, RG_MAX_ROOMS * n) &&
               dev_alloc(h, &S.edge_a, RG_MAX_EDGES * n) && dev_alloc(h, &S.edge_b, RG_MAX_EDGES * n) &&
-              dev_alloc(h, &S.maze_stack, (size_t)maze_cap * n) && dev_alloc(h, &S.build_ctr, n) && dev_alloc(h, &S.stats, 8 * h->stat_rows) && dev_alloc(h, &S.bin_list, 3 * n) && dev_alloc(h, &S.bin_cnt, 8) &&
+              dev_alloc(h, &S.maze_stack, (size_t)maze_cap * n) && dev_alloc(h, &S.build_ctr, n) && dev_alloc(h, &S.stats, 8 * h->stat_rows) && dev_alloc(h, &S.stair_list, 2 * n) && dev_alloc(h, &S.stair_cnt, 4) &&
               dev_alloc(h, &S.dc_map, h->cfg.n_enemies > 0 ? n * RG_DIST_SLOTS * hw : 16) && dev_alloc(h, &S.dc_key, RG_DIST_SLOTS * n) &&
               dev_alloc(h, &S.dc_head, n) && dev_alloc(h, &S.dc_len, n) && dev_alloc(h, &S.status, n * 10) &&
               dev_alloc(h, &h->d_err, 4) && dev_alloc(h, &h->d_keys, n);
@@ -453,11 +458,10 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
         dk = h->d_keys;
     }
     h->S.n_keys = n_keys;
-    {   // ROGUE_GYM_HIP_BINS=1: k_classify sorts the envs of the step into descent / monster / plain lists and k_step takes its lanes from them
-        // (measured neutral against the index-order mapping, DESIGN.md section 5 -- kept as a tested option, off by default)
-        static const bool bins = getenv("ROGUE_GYM_HIP_BINS") != nullptr && atoi(getenv("ROGUE_GYM_HIP_BINS")) != 0;
+    {   // stair isolation (rg_kernels.hip, k_step): on unless ROGUE_GYM_HIP_NO_STAIR_WAVES is set (the A/B knob of DESIGN.md's measurement)
+        static const bool no_stair_waves = getenv("ROGUE_GYM_HIP_NO_STAIR_WAVES") != nullptr;
         TimedLaunch t(h, 0);
-        rgk_step(&h->S, h->d_SP, &h->cfg, dk, h->spares ? 1 : 0, bins ? (int)(h->step_count & 1) : -1, h->stream);
+        rgk_step(&h->S, h->d_SP, &h->cfg, dk, h->spares ? 1 : 0, (h->stair_valid && !no_stair_waves) ? h->S.stair_parity : -1, h->stream);
     }
     h->step_count++;
     HIPCHK(h, hipGetLastError());
@@ -525,12 +529,15 @@ static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, fl
     }
     {   // steady state: one fused pass refreshes the mirrors of Redraw envs and encodes every env
         TimedLaunch t(h, 2);
+        const int parity_before = h->S.stair_parity; const bool valid_before = h->stair_valid;
+        next_stair_set(h);
         if (rgk_obs(&h->S, &h->cfg, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->d_err, h->planes_sym, h->stream)) {
             HIPCHK(h, hipGetLastError());
             h->render_pending = false;
             return 0;
         }
         t.on = false;
+        h->S.stair_parity = parity_before; h->stair_valid = valid_before;  // geometry without the fused pass: nothing was launched
     }
     if (flush_render(h)) return 1;
     {

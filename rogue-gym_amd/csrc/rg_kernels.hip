@@ -1765,7 +1765,8 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
 // lanes only; the other lanes still take part in the wave-cooperative services.
 template <int BW>
 __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__restrict__ SPd, const RgConfig &c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset,
-                                          const int e, const bool valid) {
+                                          const int e, const bool valid_in, const int stair_role) {
+    // stair_role: 0 = no stair isolation, 1 = this wave serves listed (on-stairs) envs, 2 = index-order wave: listed envs are somebody else's
     uint16_t *lds_grid = reinterpret_cast<uint16_t *>(g_smem);
     const int lane = threadIdx.x;
     Prof pf; pf.start(S.prof);
@@ -1778,13 +1779,21 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     bool ui_dead = false, terminal = false;
     bool taken = false;  // terminal + auto-reset + spare ready: the spare becomes the live state at the end of the wave (take_spares)
     uint32_t n_bfs = 0, n_inline = 0, n_taken = 0;  // workload counters (S.stats)
-    const bool has_key = valid && e < S.n_keys;  // ThreadConductor::step zips keys with envs (thread_impls.rs:62-64)
-    if (valid) {
+    uint32_t key = 0;
+    if (valid_in) {  // one round of independent loads (a lane that turns out to be somebody else's -- stair_role 2 -- just drops them)
         old_flags = S.flags[e];
         steps = S.steps[e];
         gold_before = S.status[(size_t)e * 10 + 1];
+        if (e < S.n_keys) key = keys[e];  // (an env beyond the key prefix has no key: key = 0, never '>')
+    }
+    // An env is played by a stair wave iff its player stands on the stairs AND this key is '>' (the only way into a level generation); both
+    // kinds of wave decide from the same two words -- the key and the ON_STAIRS bit, which no k_step wave ever clears -- so exactly one of them
+    // takes the env.  A listed env with any other key costs its stair wave one round of loads.
+    const bool to_stair_wave = (old_flags & RG_FLAG_ON_STAIRS) && key == '>';
+    const bool valid = valid_in && (stair_role == 0 || (stair_role == 1) == to_stair_wave);
+    const bool has_key = valid && e < S.n_keys;  // ThreadConductor::step zips keys with envs (thread_impls.rs:62-64)
+    if (valid) {
         if (has_key && !(steps > c.max_steps)) {  // state_impls.rs:52-54
-            const uint32_t key = keys[e];
             act = decode_key(key, dir);
             if (act == ACT_INVALID) err = RG_FLAG_ERR_KEY;            // ErrorKind::InvalidInput: not mapped, not logged
             else {
@@ -1902,7 +1911,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             flags = (react & 0x7f00u);                       // message flags of this key only
             if (react & R_REDRAW) flags |= RG_FLAG_REDRAW | ((react & R_HIST_STALE) ? RG_FLAG_HIST_STALE : 0);
             else flags |= old_flags & (RG_FLAG_REDRAW | RG_FLAG_HIST_STALE);
-            flags |= old_flags & (RG_FLAG_HIST_LAG | RG_FLAG_HIST_DIRTY);
+            flags |= old_flags & (RG_FLAG_HIST_LAG | RG_FLAG_HIST_DIRTY | RG_FLAG_ON_STAIRS);  // (ON_STAIRS: refreshed by the next render pass if the player moved)
             if ((react & R_HIST_CHANGED) || descends) flags |= RG_FLAG_HIST_DIRTY;
             if (react & R_STATUS) write_status(S, c, E);
             if (ui_dead) flags |= RG_FLAG_DEAD;
@@ -1912,7 +1921,6 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         }
     }
     pf.mark(6);
-    pf.finish();
     if (S.stats) {
         // per-BLOCK rows, plain read-modify-write by the block's own lane 0 (launches of one handle are stream-ordered): no atomics.  (One
         // atomicAdd per wave and counter on a shared 64-byte line -- 7 000 same-line atomics per launch -- cost the kernel 20 us, measured.)
@@ -1941,7 +1949,9 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             write_status(S, c, E);
             S.dc_len[e] = 0; S.dc_head[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
             steps = 0;
-            flags = RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY;
+            // (ON_STAIRS is carried, never cleared here: the index-order wave that holds this env's lane decides from that bit whether the env is
+            // somebody else's, and it may read the flag word after the stair wave has already written it; the render pass recomputes the bit)
+            flags = RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY | (old_flags & RG_FLAG_ON_STAIRS);
             klog_new_episode(S, e);
         }
         if (E.err) { flags |= E.err; atomicOr(S.err_any, E.err); }
@@ -1954,83 +1964,40 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         S.reward[e] = (float)(gold_after - gold_before > 0 ? gold_after - gold_before : 0);
     }
     take_spares(S, SPd, c, lane, e, taken);
+    pf.mark(7);
+    pf.finish();
 }
 
 // ---------------------------------------------------------------------------------------------
-// Binning.  A wave costs the UNION of its lanes' paths: with envs laid out in index order nearly every 64-env wave contains somebody with
-// awake monsters (5 % of the envs in the steady state: prepass + BFS + moves, ~18 us) and every 40th a descent (a 35-40 us level generation that
-// the other 63 lanes wait for) -- the launch lasts as long as its slowest wave, ~2.4x the mean.  k_classify therefore sorts the envs of this
-// step by what their key is about to do, and k_step takes its lanes from the three lists:
-//   descents      one env per wave, first in the grid: the 75 us chain (own turn + generation) starts at t = 0 and nobody else waits for it
-//   monster envs  8 .. 64 per wave (few lanes => few BFS rounds per wave), next in the grid
-//   plain envs    64 per wave in (nearly) index order -- their waves never enter the monster code at all
-// The classification is a scheduling hint only: every wave runs the full turn code, so an env whose monsters wake during this very step is
-// still played correctly by a "plain" wave.
+// k_step: one key for every env.
+//
+// Stair isolation.  The one thing in a step that takes far longer than everything else is a DESCENT: the new level is generated inside the turn
+// (35-45 us by the whole wave, and the 63 other lanes of the wave wait for it) -- ~20 descents per 65 536-env step, and the launch lasts as
+// long as its slowest wave (80-100 us with the descent inside a 64-env wave, against 30-50 us for every other wave).  A descent needs the player
+// on the stairs, and whether he is there is known BEFORE the step: the render / observation pass keeps RG_FLAG_ON_STAIRS per env and
+// lists those envs (S.stair_list, ~240 of 65 536).  The blocks at the FRONT of the grid look the listed envs' keys up: an env that presses
+// '>' gets that wave for itself -- its turn + generation chain (55-70 us) starts at t = 0 and nobody waits for it -- and the index-order
+// wave holding its lane skips it; the other listed envs stay with their index-order waves.  (Sorting the envs of a step into
+// descent / awake-monster / plain waves with a classification kernel was tried first: neutral)
 // ---------------------------------------------------------------------------------------------
-#define BIN_G_DESC 128   // blocks reserved for the descent list (grid-stride beyond that)
-#define BIN_G_MON 1024   // blocks reserved for the monster list
-__device__ __forceinline__ int bin_epw_mon(int n_mon) { return n_mon <= 8 * BIN_G_MON ? 8 : (n_mon <= 16 * BIN_G_MON ? 16 : (n_mon <= 32 * BIN_G_MON ? 32 : 64)); }
-
-#define CLS_THREADS 1024
-__global__ void __launch_bounds__(CLS_THREADS) k_classify(RgState S, RgConfig c, const uint8_t *__restrict__ keys, int parity) {
-    __shared__ uint32_t s_cnt[3][CLS_THREADS / 64];  // per wave and class
-    __shared__ uint32_t s_base[3];
-    const int e = blockIdx.x * CLS_THREADS + threadIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t *cnt = S.bin_cnt + 4 * parity;
-    if (e == 0) { uint32_t *nx = S.bin_cnt + 4 * (parity ^ 1); nx[0] = nx[1] = nx[2] = 0; }  // the other set is idle during this step: ready for the next one
-    int cls = -1;  // 0 descent, 1 awake monsters, 2 plain
-    if (e < S.n) {
-        cls = 2;
-        const uint32_t fl = S.flags[e];
-        if (e < S.n_keys && !(S.steps[e] > c.max_steps) && !(fl & RG_FLAG_DEAD)) {
-            int dir;
-            const int act = decode_key(keys[e], dir);
-            if (act == ACT_DOWNSTAIR) {
-                const uint32_t p = S.p_pos[e];
-                if ((S.cell[(size_t)e * S.hw + POS_Y(p) * c.width + POS_X(p)] & C_SURF_MASK) == S_STAIR) cls = 0;
-            }
-            if (cls == 2 && act != ACT_INVALID && act != ACT_NOOP && ((S.mon_cnt[e] >> 8) & 0xff) != 0) cls = 1;  // NoOp costs no turn
-        }
-    }
-    // block-level compaction: three atomics per 1024 envs (same-line atomics are what a classification pass must not be made of); inside a
-    // block the lists keep the index order, which is what lets the plain waves load their lanes' state coalesced
-    uint64_t m[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { m[k] = __ballot(cls == k); if (lane == 0) s_cnt[k][wv] = (uint32_t)__popcll(m[k]); }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        uint32_t tot = 0;
-        for (int w = 0; w < CLS_THREADS / 64; w++) { const uint32_t v = s_cnt[threadIdx.x][w]; s_cnt[threadIdx.x][w] = tot; tot += v; }  // exclusive prefix
-        s_base[threadIdx.x] = tot ? atomicAdd(&cnt[threadIdx.x], tot) : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-        if (cls == k) S.bin_list[(size_t)k * S.n + s_base[k] + s_cnt[k][wv] + __popcll(m[k] & ((1ull << lane) - 1ull))] = e;
-}
+#define STAIR_BLOCKS 256   // blocks at the front of the grid that serve the stair list (grid-stride beyond that)
 
 template <int BW>
 __global__ void __launch_bounds__(WAVE) k_step(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset, int epw,
                                                int parity) {
     __builtin_amdgcn_s_setprio(3);  // issue-bound kernel: win VALU arbitration against the co-resident background k_regen waves
     const int lane = threadIdx.x;
-    // this block's work: items [first, first + per), [first + stride, ...) ... of one list (nullptr: the envs in index order); ONE call site
-    // of the turn code below, whatever the role
+    // this block's work: ONE call site of the turn code, whatever the role
     const int32_t *list = nullptr;
     int first = blockIdx.x * epw, stride = 0, per = epw, items = S.n;
     if (parity >= 0) {
-        const uint32_t *cnt = S.bin_cnt + 4 * parity;
-        const int n_desc = (int)cnt[0], n_mon = (int)cnt[1], n_plain = (int)cnt[2];
-        int b = blockIdx.x;
-        if (b < BIN_G_DESC) { list = S.bin_list; first = b; stride = BIN_G_DESC; per = 1; items = n_desc; }
-        else if ((b -= BIN_G_DESC) < BIN_G_MON) { per = bin_epw_mon(n_mon); list = S.bin_list + S.n; first = b * per; stride = BIN_G_MON * per; items = n_mon; }
-        else { b -= BIN_G_MON; list = S.bin_list + 2 * (size_t)S.n; first = b * epw; items = n_plain; }
+        if ((int)blockIdx.x < STAIR_BLOCKS) { list = S.stair_list + (size_t)parity * S.n; first = blockIdx.x; stride = STAIR_BLOCKS; per = 1; items = (int)S.stair_cnt[parity]; }
+        else first = (blockIdx.x - STAIR_BLOCKS) * epw;
     }
     for (int i0 = first; i0 < items; i0 += stride) {
         const bool v = lane < per && i0 + lane < items;
         const int e = v ? (list ? list[i0 + lane] : i0 + lane) : 0;
-        step_wave<BW>(S, SPd, c, keys, use_spares, mc_offset, e, v);
+        step_wave<BW>(S, SPd, c, keys, use_spares, mc_offset, e, v, parity >= 0 ? (list ? 1 : 2) : 0);
         if (stride == 0) break;
         __syncthreads();  // the next item reuses the wave's LDS
     }
@@ -2059,10 +2026,9 @@ void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const 
     int epw = WAVE;
     while (epw > 16 && (S->n + epw - 1) / epw < 1024) epw >>= 1;
     if (epw_env == 16 || epw_env == 32 || epw_env == 64) epw = epw_env;
-    // parity >= 0: binned (k_classify sorts the envs of this step into the descent / monster / plain lists of counter set `parity` first)
+    // parity >= 0: stair isolation with the list the last render / observation pass wrote into set `parity`
     const int nb = (S->n + epw - 1) / epw;
-    if (parity >= 0) hipLaunchKernelGGL(k_classify, dim3((S->n + CLS_THREADS - 1) / CLS_THREADS), dim3(CLS_THREADS), 0, st, *S, *c, keys, parity);
-    const dim3 grid(parity >= 0 ? BIN_G_DESC + BIN_G_MON + nb : nb), block(WAVE);
+    const dim3 grid(parity >= 0 ? STAIR_BLOCKS + nb : nb), block(WAVE);
     if (c->width <= 32) hipLaunchKernelGGL(k_step<0>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
     else if (c->width <= 64) hipLaunchKernelGGL(k_step<1>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
     else if (c->width <= 128) hipLaunchKernelGGL(k_step<2>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);

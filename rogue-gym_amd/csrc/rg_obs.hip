@@ -30,9 +30,15 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RgState S, RgConfig c
     __shared__ uint16_t s_cell_at[2 * RG_MAX_ROOMS];  // cell words under gold / monster overlays
     const int tid = threadIdx.x, W = c.width, H = c.height, HW = W * H, n = S.n;
     const int nrooms = c.room_num_x * c.room_num_y;
+    uint32_t *st_cnt = S.stair_cnt + S.stair_parity;
+    int32_t *st_list = S.stair_list + (size_t)S.stair_parity * n;
+    if (blockIdx.x == 0 && tid == 0) S.stair_cnt[S.stair_parity ^ 1] = 0;  // the other set is idle: ready for the pass after this one
     for (int e = blockIdx.x; e < n; e += gridDim.x) {
         const uint32_t fl = S.flags[e];
-        if (!(fl & RG_FLAG_REDRAW)) continue;
+        if (!(fl & RG_FLAG_REDRAW)) {  // the player did not move: still (not) on the stairs
+            if (tid == 0 && (fl & RG_FLAG_ON_STAIRS)) st_list[atomicAdd(st_cnt, 1u)] = e;
+            continue;
+        }
         const uint16_t *cell = S.cell + (size_t)e * HW;
         const bool upd_hist = !(fl & RG_FLAG_HIST_STALE);
         uint8_t *hist = S.hist + (size_t)e * HW;
@@ -76,8 +82,12 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RgState S, RgConfig c
             for (int i = tid; i < HW / 4; i += RENDER_THREADS) d4[i] = s4[i];
         } else
             for (int i = tid; i < HW; i += RENDER_THREADS) scr[i] = s_scr[i];
-        if (tid == 0)  // the history plane was written unless this Redraw was stale
-            S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | (upd_hist ? RG_FLAG_HIST_DIRTY : 0u))) | ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u);
+        if (tid == 0) {  // the history plane was written unless this Redraw was stale
+            const bool on = (cell[py * W + px] & C_SURF_MASK) == S_STAIR;  // RG_FLAG_ON_STAIRS: k_step gives these envs a wave of their own
+            if (on) st_list[atomicAdd(st_cnt, 1u)] = e;
+            S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_ON_STAIRS | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | (upd_hist ? RG_FLAG_HIST_DIRTY : 0u))) |
+                         ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u) | (on ? RG_FLAG_ON_STAIRS : 0u);
+        }
         __syncthreads();
     }
     (void)s_cell_at;
@@ -231,7 +241,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
             if (fl & RG_FLAG_REDRAW) {
                 if (lt < Q8) p.v0 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW)[lt];
                 if (lt < nrooms) { p.rect = S.room_rect[lt * n + e]; p.meta = S.room_meta[lt * n + e]; p.mon = S.mon_w0[lt * n + e]; p.gold = S.gold_pos[lt * n + e]; }
-                if (lt == tpe - 1) p.ppos = S.p_pos[e];
+                p.ppos = S.p_pos[e];  // every lane (one address: a broadcast): the lane that owns the player's cell tests it for the staircase
             } else if (lt < Q8) {
                 const uint2 m = reinterpret_cast<const uint2 *>(S.screen + (size_t)e * HW)[lt];
                 p.v0.x = m.x; p.v0.y = m.y;
@@ -239,6 +249,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
         }
         return p;
     };
+    if (blockIdx.x == 0 && tid == 0) S.stair_cnt[S.stair_parity ^ 1] = 0;  // the other set is idle: ready for the pass after this one
     const int base0 = blockIdx.x * epb;
     uint32_t fl_cur = load_flag(base0), fl_nxt = load_flag(base0 + stride);
     Pre nxt = prefetch(base0, fl_cur);
@@ -263,6 +274,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                 // stale Redraw
                 const bool upd_hist = !(fl & RG_FLAG_HIST_STALE) && (fl & RG_FLAG_HIST_DIRTY);
                 uint2 *hist8 = reinterpret_cast<uint2 *>(S.hist + (size_t)e * HW);
+                const int pidx = POS_Y(t_ppos) * W + POS_X(t_ppos);
                 for (int i = lt; i < Q8; i += tpe) {
                     uint4 v = i == lt ? v0 : cell4[i];
                     uint32_t q[4] = {v.x, v.y, v.z, v.w};
@@ -271,6 +283,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                     for (int t = 0; t < 8; t++) {
                         uint32_t cw = (q[t >> 1] >> ((t & 1) * 16)) & 0xffff;
                         int idx = i * 8 + t;
+                        if (idx == pidx) tb->pad[0] = (cw & C_SURF_MASK) == S_STAIR;  // exactly one lane owns the player's cell
                         bool inner = idx >= W && idx < HW - W;  // rows 1..H-2 only (rogue/mod.rs:278-290)
                         uint32_t gl = ' ';
                         if (inner && (cw & C_VISIBLE)) gl = glyph_of(cw);
@@ -368,9 +381,14 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                 }
             }
             if (KIND == 1 && bad) { atomicOr(&S.flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
-            if (redraw && lt == 0)  // a stale Redraw leaves the history mirror one level behind (k_step refreshes it before the next descent)
-                S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | ((fl & RG_FLAG_HIST_STALE) ? 0u : RG_FLAG_HIST_DIRTY))) |
-                             ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u) | (KIND == 1 && bad ? RG_FLAG_ERR_TILE : 0);
+            if (lt == 0) {
+                // RG_FLAG_ON_STAIRS: refreshed when the env was redrawn (the only time the player can have moved), listed for the k_step that follows
+                const bool on = redraw ? tb->pad[0] != 0 : (fl & RG_FLAG_ON_STAIRS) != 0;
+                if (on) S.stair_list[(size_t)S.stair_parity * n + atomicAdd(&S.stair_cnt[S.stair_parity], 1u)] = e;
+                if (redraw)  // a stale Redraw leaves the history mirror one level behind (k_step refreshes it before the next descent)
+                    S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_ON_STAIRS | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | ((fl & RG_FLAG_HIST_STALE) ? 0u : RG_FLAG_HIST_DIRTY))) |
+                                 ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u) | (KIND == 1 && bad ? RG_FLAG_ERR_TILE : 0) | (on ? RG_FLAG_ON_STAIRS : 0u);
+            }
         }
     }
 }

@@ -94,10 +94,11 @@ struct RgState {
     // workload counters (bench.py: resets/s, descents/s, BFS maps/s): [0] auto-resets [1] descents [2] dist maps built [3] inline level
     // generations [4] spare levels taken [5] Redraw reactions [6] keys processed; one atomicAdd per wave and counter
     unsigned long long *stats;
-    // per-step binning of the envs (k_classify -> k_step): [3][n] env indices of the descent / monster / plain lists, and two sets of
-    // {n_desc, n_mon, n_plain, -} counters used alternately (the idle set is zeroed by k_classify for the step after)
-    int32_t *bin_list;
-    uint32_t *bin_cnt;
+    // envs whose player stands on the stairs (RG_FLAG_ON_STAIRS), listed by every render / observation pass for the k_step that follows:
+    // [2][n] env indices and two counters used alternately (a pass fills set `stair_parity` and zeroes the other one for the pass after)
+    int32_t *stair_list;
+    uint32_t *stair_cnt;
+    int32_t stair_parity;
     // handle with per-env configs that differ in more than the seed: this RgState is one config GROUP, and env e of the group is env ext[e] of the
     // handle (observation tensors are written at the handle's index); NULL = the group is the whole handle
     const int32_t *ext;

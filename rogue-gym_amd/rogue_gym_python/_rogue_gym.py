@@ -309,7 +309,13 @@ class StateBatch:
         hd, L = self._hd, self._hd.L
         h, w = self.screen.shape[1:]
         c = (self.symbols if kind else 1) + bin(flag).count("1") + (1 if with_hist else 0)
-        img = np.empty((self.n, c, h, w), np.float32)
+        nbytes = self.n * c * h * w * 4
+        if nbytes <= _IMAGE_BATCH_LIMIT and not hd.pool.closed:  # pinned, pooled: a fresh 16 MB numpy array per step costs more in page faults than the copy
+            ptr = hd.pool.take(nbytes)
+            self._bufs.append((ptr, nbytes))
+            img = _view(ptr, (self.n, c, h, w), np.float32)
+        else:
+            img = np.empty((self.n, c, h, w), np.float32)
         if hd.h is not None and hd.epoch == self._epoch:
             hd.check(L.rg_obs_host(hd.h, int(kind), flag, int(with_hist), img.ctypes.data))  # the device still holds exactly these states
         elif hd.uniform_symbols:  # the envs have moved on: encode the snapshot itself

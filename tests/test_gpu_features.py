@@ -424,13 +424,13 @@ def test_heterogeneous_configs_per_env(goldens):
     venv.close()
 
 
-def test_binned_lane_mapping_is_bit_exact(goldens):
-    """The optional k_classify -> list-driven k_step mapping (ROGUE_GYM_HIP_BINS=1) plays every env exactly like the index-order mapping:
-    the lock-step parity tests again, in a process with the knob set."""
+def test_index_order_mapping_without_stair_waves_is_bit_exact(goldens):
+    """k_step gives the on-stairs envs waves of their own (default); ROGUE_GYM_HIP_NO_STAIR_WAVES=1 keeps every env in its index-order wave.
+    Both play every env identically: the lock-step parity tests again, in a process with the knob set."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, ROGUE_GYM_HIP_BINS="1")
+    env = dict(os.environ, ROGUE_GYM_HIP_NO_STAIR_WAVES="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-k",
                         "lockstep_random_policy or lockstep_run_keys or stair_seekers_with or frequent_descents or inline_generation"], cwd=root, env=env, capture_output=True, text=True, timeout=900)

@@ -60,7 +60,7 @@ if __name__ == "__main__":
 
 
 PHASES = {0: "load", 26: "window load", 1: "pre-gen/post-loop", 2: "gen_service", 28: "player action", 29: "turn_passed", 30: "mon prepass", 3: "dist lookup",
-          27: "fill+flush", 4: "bfs", 5: "monsters", 6: "tail"}
+          27: "fill+flush", 4: "bfs", 5: "monsters", 6: "tail", 7: "stores + spare take"}
 GEN_PHASES = {8: "g.clear", 9: "g.rooms", 10: "g.paint", 11: "g.passages", 12: "g.corridors", 13: "g.gold", 14: "g.stair", 15: "g.monsters", 16: "g.place+rest"}
 TICK_US = 1.0 / 2350.0  # s_memtime ticks at the shader clock (~2.35 GHz under this load; calibrated against the HIP-event kernel duration)
 
@@ -117,7 +117,7 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
             print("   %-18s avg/wave %7.2f us   max wave %7.2f us" % (nm, sums[pid] / max(n_waves, 1) / nl * TICK_US, maxs[pid] * TICK_US))
     if not do_reset:
         last = buf[:, 63].astype(np.float64) * TICK_US
-        for nm, lo, hi in (("desc blocks", 0, 128), ("mon blocks", 128, 1152), ("plain blocks", 1152, len(last))):
+        for nm, lo, hi in (("stair blocks", 0, 256), ("index-order blocks", 256, len(last))):
             seg = last[lo:hi]; seg = seg[seg > 0]
             if len(seg):
                 print("   %-12s (last launch) n=%d mean %.1f us p50 %.1f p90 %.1f max %.1f" % (nm, len(seg), seg.mean(), np.percentile(seg, 50), np.percentile(seg, 90), seg.max()))
