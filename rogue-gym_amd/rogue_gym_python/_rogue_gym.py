@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(os.path.dirname(_HERE), "librogue_gym_hip.so")
+_SO = os.environ.get("ROGUE_GYM_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "librogue_gym_hip.so")  # (override: A/B runs of two builds)
 
 RG_FLAG_TERMINAL = 0x1
 RG_FLAG_DEAD = 0x2
