@@ -115,9 +115,13 @@ class Harness:
                                   device=local_rank)
         dev = self.env.device
         gen = torch.Generator(device=dev).manual_seed(rank)  # action source is not part of parity
-        # pre-generated action tensor; the per-step "action fetch" is the row lookup below
-        actions = torch.randint(0, 11, (min(256, max(1, need_steps)), self.n), generator=gen, device=dev, dtype=torch.int64)
-        self.keys_all = self.env._action_keys[actions].contiguous()
+        # pre-generated action tensor (512 rows whatever --steps is: a table of only steps + warmup rows -- 25 for the driver's command -- turns the
+        # "uniform-random policy" into a 25-periodic one when it is cycled over a 1500-step pre-roll, a different and heavier workload; that, not
+        # clocks or spares, was the rest of the gap between the round-1 driver line and the 2000-step run); the per-step "action fetch" is the row lookup
+        rows = 512
+        actions = torch.randint(0, 11, (rows, self.n), generator=gen, device=dev, dtype=torch.uint8)
+        self.keys_all = self.env._action_keys[actions.long()].contiguous()
+        _ = need_steps
         self.t = 0
 
     def step(self):
@@ -183,7 +187,7 @@ def main():
     ap.add_argument("--preroll-steps", type=int, default=1500, help="untimed steps of the MEASURED batch before the warm-up: reach the steady-state episode mix "
                     "the metric is defined on (the first --steps of them are timed and reported as preroll.cold_start); 0 = off.  1.5 x max_steps: "
                     "not on a multiple of max_steps, where the survivors of the synchronised first episodes all reset at once")
-    ap.add_argument("--time-every", type=int, default=8, help="bracket every N-th kernel launch with HIP events (every launch when steps < 64)")
+    ap.add_argument("--time-every", type=int, default=8, help="bracket every N-th kernel launch with HIP events (every 2nd when steps < 64, every one when < 16)")
     ap.add_argument("--gather-steps", type=int, default=50, help="extra steps timed WITH the observation all-gather (N>1)")
     args = ap.parse_args()
 
@@ -257,7 +261,9 @@ def main():
                                   "note": "the first %d steps after creation, no warm-up at all" % kc}}
     for _ in range(W):
         hz.step()
-    every = 1 if K < 64 else args.time_every
+    # HIP-event pairs around a launch cost stream time (~3-4 us per record): every launch when there are very few, every 2nd for short runs
+    # (10 samples per kernel for the driver's 20 steps), every --time-every-th for long ones
+    every = 1 if K < 16 else (2 if K < 64 else args.time_every)
     hz.timing(every)  # HIP-event pairs on the launch stream around every `every`-th launch of each kernel
     env.counters(reset=True)
     barrier()
