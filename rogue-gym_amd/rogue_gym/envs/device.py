@@ -54,9 +54,17 @@ class HipVecRogueEnv:
             self._h.check(L.rg_status(h, C.byref(p)))
             self.status = torch.as_tensor(_DevArray(p.value, (self.num_envs, 10), "<i4"), device=self.device)
             self._h.check(L.rg_screen(h, C.byref(p)))
-            self.screen = torch.as_tensor(_DevArray(p.value, (self.num_envs, self.height, self.width), "|u1"), device=self.device)
+            self._screen = torch.as_tensor(_DevArray(p.value, (self.num_envs, self.height, self.width), "|u1"), device=self.device)
         self._scratch = {}
         self._encode()
+
+    @property
+    def screen(self):
+        """u8 [num_envs, H, W] glyph mirror (PlayerState.map of every env).  Reading it flushes the pending render (a batch with several
+        config groups assembles the groups' screens first); the tensor itself is the same device buffer every time."""
+        p = C.c_void_p()
+        self._h.check(self._h.L.rg_screen(self._h.h, C.byref(p)))
+        return self._screen
 
     def _encode(self):
         L, h = self._h.L, self._h.h
