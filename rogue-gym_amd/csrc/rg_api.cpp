@@ -138,40 +138,29 @@ extern "C" {
 
 const char *rg_last_error(const rg_t *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
-static int create_homog(const char *const *cfg_json, int n_env, uint64_t max_steps, int device, int auto_reset, rg_handle **out) {
+// what differs between the envs of one config group: the seed, or the range a fresh seed is drawn from
+struct EnvSeed { bool has_seed, has_range; uint64_t lo, hi; unsigned __int128 r0, r1; };
+
+static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env, uint64_t max_steps, int device, int auto_reset, rg_handle **out) {
     *out = nullptr;
     rg_handle *h = new rg_handle();
     std::random_device rd;
     std::mt19937_64 gen(((uint64_t)rd() << 32) ^ rd());
     h->seed_lo.resize(n_env); h->seed_hi.resize(n_env); h->reseed.resize(n_env);
-    const char *prev = nullptr;
-    RgParsed p;
+    h->parsed = parsed;
     for (int i = 0; i < n_env; i++) {
-        const char *js = cfg_json ? cfg_json[i] : nullptr;
-        bool same_text = i > 0 && ((js == nullptr && prev == nullptr) || (js && prev && strcmp(js, prev) == 0));
-        if (!same_text) {
-            std::string e = rg_parse_config(js, &p);
-            if (!e.empty()) { g_create_err = "Failed to parse config: " + e; delete h; return 1; }
-            if (i == 0) h->parsed = p;
-            else if (!rg_config_equal(p.cfg, h->parsed.cfg)) {
-                g_create_err = "configs of env 0 and env " + std::to_string(i) + " differ in more than the seed (unsupported by the batched stepper)";
-                delete h; return 1;
+        const EnvSeed &p = seeds[i];
+        if (p.has_seed) { h->seed_lo[i] = p.lo; h->seed_hi[i] = p.hi; h->reseed[i] = 0; }
+        else { h->seed_lo[i] = gen(); h->seed_hi[i] = gen(); h->reseed[i] = 1; }  // `seed: None`: every build draws its own seed on the device from this base (build_prologue)
+        if (p.has_range) {  // ... inside seed_range if one is given (kept, for dump_config, also when a seed overrides it: core/src/lib.rs:57-61)
+            if (!(p.r1 > p.r0)) {  // rng::gen_ranged_seed -> gen_range(start, end) panics when start >= end (core/src/rng.rs:42-45)
+                g_create_err = "Invalid Setting: seed_range must satisfy start < end"; delete h; return 1;
             }
-            prev = js;
-        }
-        if (p.has_seed) { h->seed_lo[i] = p.seed_lo; h->seed_hi[i] = p.seed_hi; h->reseed[i] = 0; }
-        else {  // `seed: None`: every build draws its own seed on the device from this base (build_prologue), inside seed_range if one is given
-            h->seed_lo[i] = gen(); h->seed_hi[i] = gen(); h->reseed[i] = 1;
-            if (p.has_seed_range) {
-                if (!(p.seed_range[1] > p.seed_range[0])) {  // rng::gen_ranged_seed -> gen_range(start, end) panics when start >= end (core/src/rng.rs:42-45)
-                    g_create_err = "Invalid Setting: seed_range must satisfy start < end"; delete h; return 1;
-                }
-                if (h->range_lo.empty()) { h->range_lo.assign(2 * (size_t)n_env, 0); h->range_span.assign(2 * (size_t)n_env, 0); }
-                const unsigned __int128 span = p.seed_range[1] - p.seed_range[0];
-                h->range_lo[i] = (uint64_t)p.seed_range[0]; h->range_lo[n_env + i] = (uint64_t)(p.seed_range[0] >> 64);
-                h->range_span[i] = (uint64_t)span; h->range_span[n_env + i] = (uint64_t)(span >> 64);
-                h->reseed[i] = 2;
-            }
+            if (h->range_lo.empty()) { h->range_lo.assign(2 * (size_t)n_env, 0); h->range_span.assign(2 * (size_t)n_env, 0); }
+            const unsigned __int128 span = p.r1 - p.r0;
+            h->range_lo[i] = (uint64_t)p.r0; h->range_lo[n_env + i] = (uint64_t)(p.r0 >> 64);
+            h->range_span[i] = (uint64_t)span; h->range_span[n_env + i] = (uint64_t)(span >> 64);
+            if (!p.has_seed) h->reseed[i] = 2;
         }
     }
     h->cfg = h->parsed.cfg;
@@ -292,8 +281,9 @@ static int assemble_screens(rg_handle *h) {
 int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int device, int auto_reset, rg_t **out) {
     if (!out || n_env <= 0) { g_create_err = "rg_create: invalid arguments"; return 1; }
     *out = nullptr;
-    // group the envs by parsed config (everything the device code reads; seeds and seed ranges stay per env)
-    std::vector<RgConfig> reps;
+    // parse every config ONCE and group the envs by parsed config (everything the device code reads; seeds and seed ranges stay per env)
+    std::vector<RgParsed> reps;
+    std::vector<EnvSeed> seeds(n_env);
     std::vector<int> g_of(n_env), l_of(n_env);
     std::vector<std::vector<int>> members;
     {
@@ -307,33 +297,34 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
                 std::string e = rg_parse_config(js, &p);
                 if (!e.empty()) { g_create_err = "Failed to parse config: " + e; return 1; }
                 g = -1;
-                for (size_t k = 0; k < reps.size(); k++) if (rg_config_equal(reps[k], p.cfg)) { g = (int)k; break; }
-                if (g < 0) { g = (int)reps.size(); reps.push_back(p.cfg); members.emplace_back(); }
+                for (size_t k = 0; k < reps.size(); k++) if (rg_config_equal(reps[k].cfg, p.cfg)) { g = (int)k; break; }
+                if (g < 0) { g = (int)reps.size(); reps.push_back(p); members.emplace_back(); }
                 prev = js; prev_g = g;
             }
+            seeds[i] = EnvSeed{p.has_seed, p.has_seed_range, p.seed_lo, p.seed_hi, p.seed_range[0], p.seed_range[1]};
             g_of[i] = g; l_of[i] = (int)members[g].size(); members[g].push_back(i);
         }
     }
-    if (reps.size() == 1) return create_homog(cfg_json, n_env, max_steps, device, auto_reset, out);
+    if (reps.size() == 1) return create_homog(reps[0], seeds.data(), n_env, max_steps, device, auto_reset, out);
     for (size_t k = 1; k < reps.size(); k++)
-        if (reps[k].width != reps[0].width || reps[k].height != reps[0].height) {
-            g_create_err = "configs of one batch must share width and height (env " + std::to_string(members[k][0]) + " is " + std::to_string(reps[k].width) + "x" +
-                           std::to_string(reps[k].height) + ", env 0 is " + std::to_string(reps[0].width) + "x" + std::to_string(reps[0].height) +
-                           "): the batch is exposed as [n_env][H][W] tensors";
+        if (reps[k].cfg.width != reps[0].cfg.width || reps[k].cfg.height != reps[0].cfg.height) {
+            g_create_err = "configs of one batch must share width and height (env " + std::to_string(members[k][0]) + " is " + std::to_string(reps[k].cfg.width) + "x" +
+                           std::to_string(reps[k].cfg.height) + ", env " + std::to_string(members[0][0]) + " is " + std::to_string(reps[0].cfg.width) + "x" +
+                           std::to_string(reps[0].cfg.height) + "): the batch is exposed as [n_env][H][W] tensors";
             return 1;
         }
     rg_handle *h = new rg_handle();
     h->device = device;
     h->g_of = g_of; h->l_of = l_of;
     for (size_t k = 0; k < reps.size(); k++) {
-        std::vector<const char *> js(members[k].size());
-        for (size_t j = 0; j < members[k].size(); j++) js[j] = cfg_json ? cfg_json[members[k][j]] : nullptr;
+        std::vector<EnvSeed> gs(members[k].size());
+        for (size_t j = 0; j < members[k].size(); j++) gs[j] = seeds[members[k][j]];
         rg_handle *sh = nullptr;
-        if (create_homog(js.data(), (int)js.size(), max_steps, device, auto_reset, &sh)) { destroy_handle(h); return 1; }
+        if (create_homog(reps[k], gs.data(), (int)gs.size(), max_steps, device, auto_reset, &sh)) { destroy_handle(h); return 1; }
         h->sub.push_back(sh);
         sh->ext.assign(members[k].begin(), members[k].end());
-        bool ok = dev_alloc(sh, &sh->d_ext, js.size()) && dev_alloc(sh, &sh->d_keys_sub, js.size()) &&
-                  hipMemcpy(sh->d_ext, sh->ext.data(), js.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+        bool ok = dev_alloc(sh, &sh->d_ext, gs.size()) && dev_alloc(sh, &sh->d_keys_sub, gs.size()) &&
+                  hipMemcpy(sh->d_ext, sh->ext.data(), gs.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
         if (!ok) { g_create_err = "device allocation failed"; destroy_handle(h); return 1; }
         sh->S.ext = sh->d_ext;
     }
@@ -841,7 +832,14 @@ int rg_timing_read(rg_t *h, double ms[4], uint64_t launches[4]) {
 int rg_dump_config(const rg_t *h, int env, char *buf, size_t cap) {
     if (env < 0 || env >= h->S.n) return 1;
     if (!h->sub.empty()) return rg_dump_config(h->sub[h->g_of[env]], h->l_of[env], buf, cap);
-    std::string s = rg_dump_config_json(h->parsed, h->seed_lo[env], h->seed_hi[env], !h->reseed[env]);
+    RgParsed p = h->parsed;  // the group's config with this env's own seed / seed range
+    const size_t n = (size_t)h->S.n;
+    p.has_seed_range = !h->range_span.empty() && (h->range_span[env] | h->range_span[n + env]) != 0;
+    if (p.has_seed_range) {
+        p.seed_range[0] = ((unsigned __int128)h->range_lo[n + env] << 64) | h->range_lo[env];
+        p.seed_range[1] = p.seed_range[0] + (((unsigned __int128)h->range_span[n + env] << 64) | h->range_span[env]);
+    }
+    std::string s = rg_dump_config_json(p, h->seed_lo[env], h->seed_hi[env], !h->reseed[env]);
     if (s.size() + 1 > cap) return 1;
     memcpy(buf, s.c_str(), s.size() + 1);
     return 0;

@@ -272,7 +272,7 @@ class StateBatch:
         st = self._items.get(i)
         if st is None:
             st = self._items[i] = PlayerState(self.screen[i], self.hist[i], self.status[i], int(self._hd.env_symbols[i]), int(self.flags[i]), self._hd.device,
-                                              batch=self if (self._hd.uniform_symbols) else None, index=i)
+                                              batch=self, index=i, batch_images=self._hd.uniform_symbols)
         return st
 
     def __iter__(self):
@@ -337,7 +337,7 @@ class PlayerState:
     """A memory efficient representation of Agent observation (python/src/lib.rs:27-206): a value
     object holding host copies of the mirror screen, history plane, status and flags."""
 
-    def __init__(self, screen, hist, status, symbols, flags, device=0, batch=None, index=0):
+    def __init__(self, screen, hist, status, symbols, flags, device=0, batch=None, index=0, batch_images=True):
         self._map = np.ascontiguousarray(screen, np.uint8)
         self._hist = np.ascontiguousarray(hist, np.uint8)
         self._status = np.ascontiguousarray(status, np.int32)
@@ -345,7 +345,8 @@ class PlayerState:
         self._flags = int(flags)
         self._terminal = bool(flags & RG_FLAG_TERMINAL)
         self._device = device
-        self._batch, self._index = batch, index  # keeps the batch (and its pinned buffers) alive while this view exists
+        self._batch, self._index = batch, index  # keeps the batch (and its pinned buffers, which these arrays are views of) alive while this view exists
+        self._batch_images = batch is not None and batch_images  # images of the whole batch by one launch (not when the batch mixes `symbols`)
 
     def __repr__(self):
         s = self._status  # Status::fmt (player.rs:433-449)
@@ -399,7 +400,7 @@ class PlayerState:
         h, w = self._map.shape
         c = (self._symbols if kind else 1) + bin(flag & 0x1FF).count("1") + (1 if with_hist else 0)
         b = self._batch
-        if b is not None and b.n * c * h * w * 4 <= _IMAGE_BATCH_LIMIT:
+        if self._batch_images and b.n * c * h * w * 4 <= _IMAGE_BATCH_LIMIT:
             return b.images(kind, flag, with_hist)[self._index].copy()  # one launch serves every state of the batch
         L = load_library()
         out = np.empty((c, h, w), np.float32)

@@ -115,6 +115,9 @@ def test_config_canonical_roundtrip(lib, goldens):
     m = _canon(lib, goldens["configs"]["mini"])
     assert m["dungeon"]["min_room_size"] == {"x": 4, "y": 4} and m["seed"] == 4
     assert _canon(lib, _canon(lib, goldens["configs"]["st"])) == st        # idempotent
+    rng = _canon(lib, {"seed_range": [3, 2**70]})                           # seed_range survives the dump (u128 bounds), with and without a seed
+    assert rng == {"seed_range": [3, 2**70], "hide_dungeon": True}
+    assert _canon(lib, {"seed": 7, "seed_range": [0, 40]}) == {"seed": 7, "seed_range": [0, 40], "hide_dungeon": True}
 
 
 def test_config_validation(lib):
