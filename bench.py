@@ -385,10 +385,10 @@ def main():
             out["roofline"]["copy_peak_error"] = str(e)
         if args.workload == "mini" and not args.no_extra:
             extra = {}
-            for name, ksteps, kwarm in (("default", 300, 50), ("nohide-symbol", 60, 10)):
+            for name, ksteps, kwarm, kpre in (("default", 300, 50, 500), ("nohide-symbol", 60, 10, 100)):
                 try:
                     x = Harness(torch, name, 0, 0, local_rank, ksteps + kwarm)
-                    for _ in range(kwarm):
+                    for _ in range(kpre + kwarm):  # (same reason as the main pre-roll: not the synchronised first steps of every env)
                         x.step()
                     x.timing(4)
                     x.env.counters(reset=True)
@@ -401,7 +401,7 @@ def main():
                     pk = x.read_timing()
                     cn = x.env.counters(reset=True)
                     x.env.check_errors()
-                    extra[name] = {"value": x.n * ksteps / xdt, "unit": "env-steps/s", "envs": x.n, "steps": ksteps, "warmup": kwarm, "ms_per_step": xdt / ksteps * 1e3,
+                    extra[name] = {"value": x.n * ksteps / xdt, "unit": "env-steps/s", "envs": x.n, "steps": ksteps, "warmup": kwarm, "preroll": kpre, "ms_per_step": xdt / ksteps * 1e3,
                                    "workload": "%s, %s-image obs [N,%d,%d,%d] f32" % (x.desc, x.obs_kind, x.env.channels, x.env.height, x.env.width),
                                    "algo_bytes_per_env_step": x.algo_bytes, "achieved_end_to_end_GBps": x.algo_bytes * x.n / (xdt / ksteps) / 1e9,
                                    "frac_end_to_end": x.algo_bytes * x.n / (xdt / ksteps) / 1e9 / HBM_PEAK_GBPS, "per_kernel": pk,

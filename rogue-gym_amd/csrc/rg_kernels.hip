@@ -1215,6 +1215,140 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {  // sum over the 64 l
     for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
     return v;
 }
+// 32 < W <= 96 with H * W <= 4096 (the reference's default 80 x 24 among them): the row is WN = 2 or 3 32-bit words, everything in registers.
+// The 64-bit-word form below spends two VALU ops on every logic op and three on every shift; here a shift across the word boundary is one
+// v_alignbit_b32 and a level step is ~26 ops per word.  Distances are < the number of walkable cells < 4096 = 3 low + 9 high bit-planes.
+template <int WN>
+__device__ __forceinline__ void bfs_rows_n32(const RgState &S, const RgConfig &c, bool active, int env, int tx, int ty, int slot, int row) {
+    const int W = c.width, H = c.height, HW = W * H;
+    const uint16_t *cell = S.cell + (size_t)env * HW;
+    const bool row_ok = active && row < H;
+    uint32_t wk[WN], wu[WN], wd[WN], vis[WN], fr[WN], inject[WN], p0[WN], p1[WN], p2[WN], ph[9][WN];
+#pragma unroll
+    for (int k = 0; k < WN; k++) {
+        wk[k] = vis[k] = fr[k] = inject[k] = p0[k] = p1[k] = p2[k] = 0u;
+#pragma unroll
+        for (int b = 0; b < 9; b++) ph[b][k] = 0u;
+    }
+    if (row_ok) {  // walkable mask of my row (Surface::can_walk, rogue/mod.rs:175-182)
+        const uint16_t *rowp = cell + row * W;
+        if ((W & 7) == 0) {
+            const uint4 *r4 = reinterpret_cast<const uint4 *>(rowp);
+#pragma unroll
+            for (int j = 0; j < WN * 4; j++) {  // (fully unrolled: compile-time word indices; the guard is the only run-time part)
+                if (j * 8 < W) {
+                    const uint4 v = r4[j];
+                    const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        bits |= (uint32_t)can_walk(q[t] & 0xffff) << (2 * t);
+                        bits |= (uint32_t)can_walk(q[t] >> 16) << (2 * t + 1);
+                    }
+                    wk[j >> 2] |= bits << ((j & 3) * 8);
+                }
+            }
+        } else {
+            for (int x = 0; x < W; x++) {
+                const uint32_t bb = (uint32_t)can_walk(rowp[x]) << (x & 31);
+#pragma unroll
+                for (int k = 0; k < WN; k++)
+                    if ((x >> 5) == k) wk[k] |= bb;
+            }
+        }
+    }
+    const bool up_ok = row > 0, dn_ok = row + 1 < H;
+#pragma unroll
+    for (int k = 0; k < WN; k++) {
+        wu[k] = up_ok ? wave_shr1(wk[k]) : 0u;   // walkable mask of row y-1
+        wd[k] = dn_ok ? wave_shl1(wk[k]) : 0u;   // and of row y+1
+        if (row_ok && row == ty && (tx >> 5) == k) inject[k] = 1u << (tx & 31);  // level 0: the target cell itself, walkable or not
+    }
+    uint32_t blk = 0;
+    for (;; blk++) {  // levels 8 * blk .. 8 * blk + 7
+        uint32_t acc[WN];
+#pragma unroll
+        for (int k = 0; k < WN; k++) acc[k] = 0u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t fu[WN], fd[WN], au[WN], ad[WN], nw[WN];
+#pragma unroll
+            for (int k = 0; k < WN; k++) {
+                fu[k] = up_ok ? wave_shr1(fr[k]) : 0u;
+                fd[k] = dn_ok ? wave_shl1(fr[k]) : 0u;
+                au[k] = fu[k] & wk[k]; ad[k] = fd[k] & wk[k];  // neighbour-row frontier whose vertical step lands on a walkable cell of my row
+            }
+#pragma unroll
+            for (int k = 0; k < WN; k++) {
+                // cell x-1 -> x (shift left, carry in from the word below) and x+1 -> x (shift right, carry in from the word above)
+                const uint32_t lo_fr = k > 0 ? fr[k - 1] : 0u, hi_fr = k + 1 < WN ? fr[k + 1] : 0u;
+                const uint32_t lo_au = k > 0 ? au[k - 1] : 0u, hi_au = k + 1 < WN ? au[k + 1] : 0u;
+                const uint32_t lo_ad = k > 0 ? ad[k - 1] : 0u, hi_ad = k + 1 < WN ? ad[k + 1] : 0u;
+                const uint32_t sl = __builtin_amdgcn_alignbit(fr[k], lo_fr, 31), sr = __builtin_amdgcn_alignbit(hi_fr, fr[k], 1);
+                const uint32_t aul = __builtin_amdgcn_alignbit(au[k], lo_au, 31), aur = __builtin_amdgcn_alignbit(hi_au, au[k], 1);
+                const uint32_t adl = __builtin_amdgcn_alignbit(ad[k], lo_ad, 31), adr = __builtin_amdgcn_alignbit(hi_ad, ad[k], 1);
+                // Left/Right | Down/Up | diagonals: source (x-+1, y-+1) needs walk(x, y-+1) and walk(x-+1, y)
+                const uint32_t tgt = sl | sr | fu[k] | fd[k] | ((aul | aur) & wu[k]) | ((adl | adr) & wd[k]);
+                nw[k] = (tgt & wk[k] & ~vis[k]) | inject[k];
+            }
+#pragma unroll
+            for (int k = 0; k < WN; k++) {
+                inject[k] = 0u;
+                vis[k] |= nw[k];
+                fr[k] = nw[k];
+                if (j & 1) p0[k] |= nw[k];
+                if (j & 2) p1[k] |= nw[k];
+                if (j & 4) p2[k] |= nw[k];
+                acc[k] |= nw[k];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 9; b++)
+            if ((blk >> b) & 1u) {  // wave-uniform condition
+#pragma unroll
+                for (int k = 0; k < WN; k++) ph[b][k] |= acc[k];
+            }
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < WN; k++) any = any || fr[k] != 0u;
+        if (!__any(any) || blk == 511u) break;
+    }
+    if (row_ok) {  // expand my row: cell x -> u16 distance, 0xFFFF where the cell was never reached
+        const int nhi = 32 - __clz((int)blk);  // high planes in use (wave-uniform)
+        uint16_t *out = S.dc_map + ((size_t)env * RG_DIST_SLOTS + slot) * HW + row * W;
+        const bool vec = (W & 7) == 0;
+#pragma unroll
+        for (int k = 0; k < WN; k++) {
+            const uint32_t unv = ~vis[k];
+#pragma unroll
+            for (int g8 = 0; g8 < 4; g8++) {  // 8 cells = one 16-byte store
+                const int x0 = k * 32 + g8 * 8;
+                if (x0 >= W) continue;
+                uint32_t d[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int x = g8 * 8 + 2 * q;
+                    uint32_t lo = ((p0[k] >> x) & 1u) | (((p1[k] >> x) & 1u) << 1) | (((p2[k] >> x) & 1u) << 2);
+                    uint32_t hi = ((p0[k] >> (x + 1)) & 1u) | (((p1[k] >> (x + 1)) & 1u) << 1) | (((p2[k] >> (x + 1)) & 1u) << 2);
+#pragma unroll
+                    for (int b = 0; b < 9; b++)
+                        if (b < nhi) {
+                            lo |= ((ph[b][k] >> x) & 1u) << (3 + b);
+                            hi |= ((ph[b][k] >> (x + 1)) & 1u) << (3 + b);
+                        }
+                    if ((unv >> x) & 1u) lo = 0xFFFFu;
+                    if ((unv >> (x + 1)) & 1u) hi = 0xFFFFu;
+                    d[q] = lo | (hi << 16);
+                }
+                if (vec) *reinterpret_cast<uint4 *>(out + x0) = make_uint4(d[0], d[1], d[2], d[3]);
+                else
+                    for (int t = 0; t < 8 && x0 + t < W; t++) out[x0 + t] = (uint16_t)(d[t >> 1] >> ((t & 1) * 16));
+            }
+        }
+    }
+    __syncthreads();  // the requesting lanes read their maps right after (monsters_move): the stores of the other lanes must have landed
+}
+
 // serve every lane of `need` (ballot mask): G requests per round.  BW = width class of the grid (0: W = 32, else 64-bit words per row): the
 // step kernel is instantiated per class, so a narrow grid does not pay the register footprint of the wide-row BFS (above 384 registers a
 // k_regen wave no longer fits beside a step wave on the SIMD).
@@ -1234,8 +1368,11 @@ __device__ __forceinline__ void bfs_service(const RgState &S, const RgConfig &c,
         const bool active = src >= 0;
         const int s = active ? src : 0;
         int env_s = __shfl(e, s), tx = __shfl(px, s), ty = __shfl(py, s), sl = __shfl(map_slot, s);
+        // width class BW: 0: W = 32 | 1, 2: W <= 64 / 96 and H * W <= 4096 (rows of 2 / 3 32-bit words) | 3, 4: wider or larger (2 / 3 64-bit words)
         if constexpr (BW == 0) bfs_rows_w32(S, c, active, env_s, tx, ty, sl, row);
-        else bfs_rows<BW, false>(S, c, lds, active, env_s, tx, ty, sl, row);
+        else if constexpr (BW == 1) bfs_rows_n32<2>(S, c, active, env_s, tx, ty, sl, row);
+        else if constexpr (BW == 2) bfs_rows_n32<3>(S, c, active, env_s, tx, ty, sl, row);
+        else bfs_rows<BW - 1, false>(S, c, lds, active, env_s, tx, ty, sl, row);
     }
 }
 
@@ -2015,7 +2152,8 @@ void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
 void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st) {
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw);  // the generator's staging grid + tables (inline descents, spare misses), shared with ...
-    const size_t bfs_hi = c->width <= 32 ? 0 : (size_t)10 * ((c->width + 63) / 64) * WAVE * 8;  // ... the BFS high distance planes
+    const bool n32 = c->width <= 96 && hw <= 4096;  // BFS rows as 32-bit words in registers (bfs_rows_n32): no LDS planes
+    const size_t bfs_hi = (c->width <= 32 || n32) ? 0 : (size_t)10 * ((c->width + 63) / 64) * WAVE * 8;  // ... the BFS high distance planes
     if (bfs_hi > smem) smem = bfs_hi;
     smem = (smem + 15) & ~(size_t)15;
     int mc_offset = (int)smem;
@@ -2030,9 +2168,10 @@ void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const 
     const int nb = (S->n + epw - 1) / epw;
     const dim3 grid(parity >= 0 ? STAIR_BLOCKS + nb : nb), block(WAVE);
     if (c->width <= 32) hipLaunchKernelGGL(k_step<0>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
-    else if (c->width <= 64) hipLaunchKernelGGL(k_step<1>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
-    else if (c->width <= 128) hipLaunchKernelGGL(k_step<2>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
-    else hipLaunchKernelGGL(k_step<3>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
+    else if (n32 && c->width <= 64) hipLaunchKernelGGL(k_step<1>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
+    else if (n32) hipLaunchKernelGGL(k_step<2>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
+    else if (c->width <= 128) hipLaunchKernelGGL(k_step<3>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
+    else hipLaunchKernelGGL(k_step<4>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
 }
 void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
