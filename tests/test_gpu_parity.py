@@ -449,3 +449,30 @@ def test_config5_10000_seeds_default_dungeon(goldens):
     torch.cuda.synchronize()
     assert torch.equal(out, venv.obs)
     venv.close()
+
+
+def test_full_size_descent_heavy(goldens):
+    """65 536 envs, half of all keys are '>': every step several hundred envs descend in waves of their own (k_step's stair waves) while the
+    index-order waves hold their lanes -- oracle parity on a 1 024-env stride sample every step guards the hand-over between the two kinds
+    of wave (the first version let an index-order wave that started late re-play an env its stair wave had already reset)."""
+    cfg = dict(goldens["configs"]["mini"], enemies={"enemies": [1, 10, 18]})
+    n = 65536
+    rng = np.random.RandomState(31)
+    table = np.frombuffer(b">>>>>>>>hjklyubn", np.uint8)
+    hip = HipBatch(cfg, list(range(n)), max_steps=60)
+    sample = list(range(0, n, 64))
+    oracles = make_oracles(cfg, sample, max_steps=60)
+    for t in range(90):
+        k = table[rng.randint(0, len(table), n)]
+        hip.step(k)
+        for j, o in enumerate(oracles):
+            o.step_autoreset(int(k[sample[j]]))
+        if t % 6 == 5:
+            screen, hist, status, flags = hip.fetch()
+            for j, o in enumerate(oracles):
+                i = sample[j]
+                assert np.array_equal(screen[i], o.screen()), "t=%d env %d" % (t, i)
+                assert [int(v) & 0xFFFFFFFF for v in status[i]] == [int(v) for v in o.status_arr()], "t=%d env %d status" % (t, i)
+    hip.sync()
+    levels = hip.fetch()[2][:, 0]
+    assert (levels > 3).mean() > 0.2  # the policy really descends
