@@ -459,9 +459,9 @@ def test_full_size_descent_heavy(goldens):
     n = 65536
     rng = np.random.RandomState(31)
     table = np.frombuffer(b">>>>>>>>hjklyubn", np.uint8)
-    hip = HipBatch(cfg, list(range(n)), max_steps=60)
+    hip = HipBatch(cfg, list(range(n)), max_steps=400)
     sample = list(range(0, n, 64))
-    oracles = make_oracles(cfg, sample, max_steps=60)
+    oracles = make_oracles(cfg, sample, max_steps=400)
     for t in range(90):
         k = table[rng.randint(0, len(table), n)]
         hip.step(k)
@@ -474,5 +474,7 @@ def test_full_size_descent_heavy(goldens):
                 assert np.array_equal(screen[i], o.screen()), "t=%d env %d" % (t, i)
                 assert [int(v) & 0xFFFFFFFF for v in status[i]] == [int(v) for v in o.status_arr()], "t=%d env %d status" % (t, i)
     hip.sync()
-    levels = hip.fetch()[2][:, 0]
-    assert (levels > 3).mean() > 0.2  # the policy really descends
+    import ctypes as C
+    cnt = (C.c_uint64 * 8)()
+    hip.h.check(hip.h.L.rg_counters(hip.h.h, cnt, 0))
+    assert cnt[1] > 3000, "only %d descents: the test does not exercise the stair waves" % cnt[1]
