@@ -478,3 +478,41 @@ def test_full_size_descent_heavy(goldens):
     cnt = (C.c_uint64 * 8)()
     hip.h.check(hip.h.L.rg_counters(hip.h.h, cnt, 0))
     assert cnt[1] > 3000, "only %d descents: the test does not exercise the stair waves" % cnt[1]
+
+
+def test_config1_plumbing_shape(goldens):
+    """BASELINE config 1 at its own shape: data/config-mini.json as it is (seed 4 in the file), 64 envs all on that seed, max_steps = 1000, actions =
+    LCG-generated indices into the 11-action table (seeded 0) -- 1 000 lock-step keys through the drop-in ParallelRogueEnv, every env equal to the
+    oracle (and to each other while they receive the same key)."""
+    from oracle.pyoracle import OracleEnv
+    from rogue_gym.envs import ParallelRogueEnv
+
+    cfg = goldens["configs"]["mini"]
+    assert cfg["seed"] == 4
+    n = 64
+    env = ParallelRogueEnv([cfg] * n, max_steps=1000)
+    oracles = [OracleEnv(cfg, max_steps=1000) for _ in range(4)]
+    lcg = 0
+    for t in range(1000):
+        acts = []
+        for i in range(n):
+            if i < 60:  # 60 envs share one action stream (they must stay identical), 4 get streams of their own
+                a = None
+            else:
+                lcg = (lcg * 1103515245 + 12345) & 0x7FFFFFFF
+                a = (lcg >> 16) % 11
+            acts.append(a)
+        lcg = (lcg * 1103515245 + 12345) & 0x7FFFFFFF
+        shared = (lcg >> 16) % 11
+        acts = [shared if a is None else a for a in acts]
+        states, rewards, dones, _ = env.step(acts)
+        keys = [ord(ParallelRogueEnv.ACTIONS[a]) for a in acts]
+        oracles[0].step_autoreset(keys[0])
+        for j in range(1, 4):
+            oracles[j].step_autoreset(keys[60 + j])
+        if t % 20 == 19 or dones[0]:
+            assert all(np.array_equal(states.screen[i], states.screen[0]) for i in range(1, 60))
+            assert states[0].dungeon == oracles[0].dungeon() and [int(v) for v in states.status[0].astype(np.uint32)] == [int(v) for v in oracles[0].status_arr()]
+            for j in range(1, 4):
+                assert states[60 + j].dungeon == oracles[j].dungeon(), "t=%d env %d" % (t, 60 + j)
+    env.close()
