@@ -34,7 +34,6 @@ typedef struct rg_handle rg_t;
 #define RG_FLAG_HIST_STALE 0x00000008u  /* internal: this Redraw keeps the old level's history */
 #define RG_FLAG_HIST_LAG   0x00000010u  /* internal: the history mirror still shows the level before the current one */
 #define RG_FLAG_HIST_DIRTY 0x00000020u  /* internal: the visited set changed since the history mirror was last written */
-#define RG_FLAG_ON_STAIRS  0x00000040u  /* internal: the player stands on the staircase (kept by the render / observation pass; k_step isolates these envs) */
 #define RG_FLAG_MSG_SHIFT  8            /* bits 8..14: MessageFlagInner (python/src/flags.rs:6-39) */
 #define RG_FLAG_MSG_MASK   0x00007f00u
 #define RG_FLAG_ERR_KEY    0x00010000u  /* ErrorKind::InvalidInput: key not in KeyMap::ai (input.rs:73-100) */

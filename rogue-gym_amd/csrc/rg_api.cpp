@@ -44,7 +44,7 @@ struct rg_handle {
     uint32_t *d_err = nullptr;
     uint8_t *d_keys = nullptr;
     bool render_pending = false;
-    bool stair_valid = false;    // a render / observation pass has listed the on-stairs envs since the last change of any player position
+    int stair_gen = 0;           // producers of the stair set launched so far (k_build, k_step, the debug descent; rg_state.h)
     float *obs_scratch = nullptr;  // rg_obs_host: device-side observation buffer, kept between calls
     size_t obs_scratch_cap = 0;
     std::vector<uint64_t> seed_lo, seed_hi;  // host copy of the seeds the next reset will use (reseed envs: the base of the per-build hash)
@@ -114,12 +114,8 @@ static void free_all(rg_handle *h) {
     h->allocs.clear();
 }
 
-// every render / observation pass lists the envs whose player stands on the stairs into the stair set it is given (alternating) for the k_step after it
-static void next_stair_set(rg_handle *h) { h->S.stair_parity ^= 1; h->stair_valid = true; }
-
 static int flush_render(rg_handle *h) {
     if (h->render_pending) {
-        next_stair_set(h);
         { TimedLaunch t(h, 1); rgk_render(&h->S, &h->cfg, h->stream); }
         HIPCHK(h, hipGetLastError());
         h->render_pending = false;
@@ -191,7 +187,7 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
               dev_alloc(h, &S.mon_w0, RG_MAX_ROOMS * n) && dev_alloc(h, &S.mon_hp, RG_MAX_ROOMS * n) && dev_alloc(h, &S.mon_exp, RG_MAX_ROOMS * n) &&
               dev_alloc(h, &S.mon_cnt, n) && dev_alloc(h, &S.gold_pos, RG_MAX_ROOMS * n) && dev_alloc(h, &S.gold_amt, RG_MAX_ROOMS * n) &&
               dev_alloc(h, &S.edge_a, RG_MAX_EDGES * n) && dev_alloc(h, &S.edge_b, RG_MAX_EDGES * n) &&
-              dev_alloc(h, &S.maze_stack, (size_t)maze_cap * n) && dev_alloc(h, &S.build_ctr, n) && dev_alloc(h, &S.stats, 8 * h->stat_rows) && dev_alloc(h, &S.stair_list, 2 * n) && dev_alloc(h, &S.stair_cnt, 4) &&
+              dev_alloc(h, &S.maze_stack, (size_t)maze_cap * n) && dev_alloc(h, &S.build_ctr, n) && dev_alloc(h, &S.stats, 8 * h->stat_rows) && dev_alloc(h, &S.stair_list, 2 * n) && dev_alloc(h, &S.stair_cnt, 4) && dev_alloc(h, &S.stair_mark, 2 * n) &&
               dev_alloc(h, &S.dc_map, h->cfg.n_enemies > 0 ? n * RG_DIST_SLOTS * hw : 16) && dev_alloc(h, &S.dc_key, RG_DIST_SLOTS * n) &&
               dev_alloc(h, &S.dc_head, n) && dev_alloc(h, &S.dc_len, n) && dev_alloc(h, &S.status, n * 10) &&
               dev_alloc(h, &h->d_err, 4) && dev_alloc(h, &h->d_keys, n);
@@ -212,7 +208,8 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
              dev_alloc(h, &P.rng, 12 * n) && dev_alloc(h, &P.room_rect, RG_MAX_ROOMS * n) && dev_alloc(h, &P.room_meta, RG_MAX_ROOMS * n) &&
              dev_alloc(h, &P.mon_w0, RG_MAX_ROOMS * n) && dev_alloc(h, &P.mon_hp, RG_MAX_ROOMS * n) && dev_alloc(h, &P.mon_exp, RG_MAX_ROOMS * n) &&
              dev_alloc(h, &P.mon_cnt, n) && dev_alloc(h, &P.gold_pos, RG_MAX_ROOMS * n) && dev_alloc(h, &P.gold_amt, RG_MAX_ROOMS * n) &&
-             dev_alloc(h, &P.edge_a, RG_MAX_EDGES * n) && dev_alloc(h, &P.edge_b, RG_MAX_EDGES * n) && dev_alloc(h, &P.maze_stack, (size_t)maze_cap * n);
+             dev_alloc(h, &P.edge_a, RG_MAX_EDGES * n) && dev_alloc(h, &P.edge_b, RG_MAX_EDGES * n) && dev_alloc(h, &P.maze_stack, (size_t)maze_cap * n) &&
+             dev_alloc(h, &P.on_stairs, n);
         P.prof = nullptr;
         int lo = 0, hi = 0;
         if (ok && (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, getenv("ROGUE_GYM_HIP_SIDE_LOWPRIO") ? lo : hi) != hipSuccess ||
@@ -225,6 +222,7 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
     // screen rows 0 and H-1 are never drawn: PlayerState::new fills the map with b' ' (python/src/lib.rs:41-50)
     if (hipMemset(S.screen, ' ', n * hw) != hipSuccess) { g_create_err = "hipMemset failed"; free_all(h); delete h; return 1; }
     if (upload_seeds(h, n)) { g_create_err = h->err; free_all(h); delete h; return 1; }
+    h->S.stair_gen = h->stair_gen++;  // k_build produces the stair set of the first k_step
     rgk_build(&h->S, &h->cfg, h->stream);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -413,6 +411,7 @@ int rg_reset(rg_t *h) {
         h->screens_stale = true;
         return assemble_small(h);
     }
+    h->S.stair_gen = h->stair_gen++;
     { TimedLaunch t(h, 3); rgk_build(&h->S, &h->cfg, h->stream); }  // (k_build and a k_regen in flight share only the atomically advanced build counters)
     HIPCHK(h, hipGetLastError());
     h->render_pending = true;
@@ -452,7 +451,8 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
     {   // stair isolation (rg_kernels.hip, k_step): on unless ROGUE_GYM_HIP_NO_STAIR_WAVES is set (the A/B knob of DESIGN.md's measurement)
         static const bool no_stair_waves = getenv("ROGUE_GYM_HIP_NO_STAIR_WAVES") != nullptr;
         TimedLaunch t(h, 0);
-        rgk_step(&h->S, h->d_SP, &h->cfg, dk, h->spares ? 1 : 0, (h->stair_valid && !no_stair_waves) ? h->S.stair_parity : -1, h->stream);
+        h->S.stair_gen = h->stair_gen++;  // reads the stair set its predecessor produced, produces the next one
+        rgk_step(&h->S, h->d_SP, &h->cfg, dk, h->spares ? 1 : 0, no_stair_waves ? -1 : 0, h->stream);
     }
     h->step_count++;
     HIPCHK(h, hipGetLastError());
@@ -520,15 +520,12 @@ static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, fl
     }
     {   // steady state: one fused pass refreshes the mirrors of Redraw envs and encodes every env
         TimedLaunch t(h, 2);
-        const int parity_before = h->S.stair_parity; const bool valid_before = h->stair_valid;
-        next_stair_set(h);
         if (rgk_obs(&h->S, &h->cfg, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->d_err, h->planes_sym, h->stream)) {
             HIPCHK(h, hipGetLastError());
             h->render_pending = false;
             return 0;
         }
         t.on = false;
-        h->S.stair_parity = parity_before; h->stair_valid = valid_before;  // geometry without the fused pass: nothing was launched
     }
     if (flush_render(h)) return 1;
     {
@@ -863,6 +860,7 @@ int rg_debug_descend(rg_t *h) {
         return assemble_small(h);
     }
     if (flush_render(h)) return 1;
+    h->S.stair_gen = h->stair_gen++;
     rgk_debug_descend(&h->S, &h->cfg, h->stream);
     HIPCHK(h, hipGetLastError());
     h->render_pending = true;

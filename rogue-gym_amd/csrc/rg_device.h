@@ -19,7 +19,7 @@ static __device__ __constant__ int8_t kDY[9] = {-1, 1, 0, 0, -1, -1, 1, 1, 0};
 // Surface::tile (rogue/mod.rs:149-163): '#' '.' '-' '|' '%' '+' '^' ' ' packed into one 64-bit immediate (a __constant__ table indexed per lane
 // would be a memory load per cell)
 // (v_perm_b32: byte `surface & 7` of the 8-byte table, one VALU op instead of a 64-bit shift)
-__device__ __forceinline__ uint32_t glyph_of(uint32_t surface) { return __builtin_amdgcn_perm(0x205E2B25u, 0x7C2D2E23u, (surface & 7u) | 0x0c0c0c00u); }
+__device__ __forceinline__ uint32_t glyph_of(uint32_t surface) { return (uint32_t)(0x205E2B257C2D2E23ull >> (8 * (surface & 7))) & 0xffu; }
 
 // monster statuses come from the config (RgConfig::mon, rarity-sorted): builtin presets (character/enemies.rs:474-761)
 // or custom ones; a monster's `type` is its index in that table

@@ -130,6 +130,7 @@ struct Env {
     uint16_t *stk_lds;  // generation: LDS maze stack of the lane's slot (GEN_STACK_LDS entries), else nullptr
     uint32_t *mc;       // k_step: this lane's column of the wave's LDS monster cache (word s at mc[s * WAVE]); write-through
     uint32_t err;       // RG_FLAG_ERR_INTERNAL if a capacity guard tripped (each guard carries its proof of unreachability)
+    uint32_t on_stairs; // set by place_player: the player was put on the staircase of the level just generated
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -699,6 +700,7 @@ __device__ __forceinline__ void place_player(const RgState &S, const RgConfig &c
     uint32_t pos = 0;
     floor_select(S, c, E, non_empty, 1, pos);
     E.px = POS_X(pos); E.py = POS_Y(pos);
+    E.on_stairs = (uni(E.lc[E.py * c.width + E.px]) & C_SURF_MASK) == S_STAIR;  // (select_cell only avoids characters: the stairs are a legal spot)
     player_in_init(S, c, E, E.px, E.py);
 }
 
@@ -762,13 +764,13 @@ __device__ __forceinline__ void env_from_lane(Env &U, const Env &E, int src) {
     U.hp = (int)lane_get((uint32_t)E.hp, src); U.hpmax = (int)lane_get((uint32_t)E.hpmax, src); U.plvl = (int)lane_get((uint32_t)E.plvl, src);
     U.exp = lane_get(E.exp, src); U.food = lane_get(E.food, src); U.quiet = lane_get(E.quiet, src); U.gold = lane_get(E.gold, src);
     U.dlevel = lane_get(E.dlevel, src); U.mon_alive = lane_get(E.mon_alive, src); U.mon_active = lane_get(E.mon_active, src);
-    U.err = 0;
+    U.err = 0; U.on_stairs = 0;
 }
 __device__ __forceinline__ void env_to_lane(Env &E, const Env &U) {  // the generated env's scalars back into its own lane
     E.rd = U.rd; E.ri = U.ri; E.re = U.re;
     E.px = U.px; E.py = U.py; E.hp = U.hp; E.hpmax = U.hpmax; E.plvl = U.plvl;
     E.exp = U.exp; E.food = U.food; E.quiet = U.quiet; E.gold = U.gold; E.dlevel = U.dlevel; E.mon_alive = U.mon_alive; E.mon_active = U.mon_active;
-    E.err |= U.err;
+    E.err |= U.err; E.on_stairs = U.on_stairs;
 }
 static_assert(sizeof(Rng) == 16, "Rng is 4 words");
 
@@ -859,6 +861,23 @@ __device__ __forceinline__ void store_env(const RgState &S, const Env &E) {
     S.mon_cnt[e] = E.mon_alive | (E.mon_active << 8);
 }
 
+// The stair set a producer launch writes for the k_step after it (rg_state.h): every env it owns gets its byte, marked envs are appended to the
+// list with one atomic per wave.
+__device__ __forceinline__ void stair_publish(const RgState &S, int lane, int e, bool mine, bool on) {
+    const int w = (S.stair_gen + 1) & 1;
+    if (mine) S.stair_mark[(size_t)w * S.n + e] = on ? 1 : 0;
+    const uint64_t m = __ballot(mine && on);
+    if (m) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&S.stair_cnt[(S.stair_gen + 1) % 3], (uint32_t)__popcll(m));
+        base = uni(base);
+        if (mine && on) S.stair_list[(size_t)w * S.n + base + __popcll(m & ((1ull << lane) - 1ull))] = e;
+    }
+}
+__device__ __forceinline__ void stair_recycle(const RgState &S) {  // one thread of the launch: the counter nobody reads or writes right now
+    S.stair_cnt[(S.stair_gen + 2) % 3] = 0;
+}
+
 // Action-history log (RunTime::saved_inputs: react_to_input pushes every mapped key before it is processed, core/src/lib.rs:288; a rebuilt
 // RunTime starts an empty log).  Two buffers per env: the running episode and the one before it, so the keys of an episode that ended in an
 // auto-reset can still be dumped (rg_dump_history).
@@ -891,7 +910,10 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     Env E;
     E.e = valid ? e : 0; E.n = S.n; E.cell = E.gcell = S.cell + (size_t)E.e * S.hw; E.err = 0;
     Prof pf; pf.start(S.prof);
+    E.on_stairs = 0;
     gen_service(S, c, E, lane, e, valid, true, reinterpret_cast<uint16_t *>(g_smem), pf);
+    if (blockIdx.x == 0 && lane == 0) stair_recycle(S);
+    stair_publish(S, lane, e, valid, E.on_stairs != 0);
     if (!valid) return;
     store_env(S, E);
     write_status(S, c, E);
@@ -915,7 +937,10 @@ __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
     E.err = 0;
     load_env(S, E, valid ? e : 0);
     Prof pf; pf.start(nullptr);
+    E.on_stairs = 0;
     gen_service(S, c, E, lane, e, valid, false, reinterpret_cast<uint16_t *>(g_smem), pf);
+    if (blockIdx.x == 0 && lane == 0) stair_recycle(S);
+    stair_publish(S, lane, e, valid, E.on_stairs != 0);
     if (!valid) return;
     store_env(S, E);
     write_status(S, c, E);
@@ -943,8 +968,9 @@ __global__ void __launch_bounds__(WAVE) k_regen(RgState SP, RgConfig c) {
     Env E;
     E.e = valid ? e : 0; E.n = SP.n; E.cell = E.gcell = SP.cell + (size_t)E.e * SP.hw; E.err = 0;
     Prof pf; pf.start(nullptr);
+    E.on_stairs = 0;
     gen_service(SP, c, E, lane, e, claim, true, reinterpret_cast<uint16_t *>(g_smem), pf);
-    if (claim) store_env(SP, E);
+    if (claim) { store_env(SP, E); SP.on_stairs[e] = (uint8_t)E.on_stairs; }
     if (claim && E.err) atomicOr(SP.err_any, E.err);  // (the flag word belongs to the concurrently running k_step)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1834,7 +1860,7 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
 // round-1 form -- scalars into registers, tables, then the grid, each waiting for the one before -- cost ~25 us of dependent round trips in
 // every wave with a terminal lane, a third of the waves of a step).  The spare's pointers come from a device-resident RgState: one kernel
 // argument instead of a second 60-pointer struct held in SGPRs by a kernel that is already spilling them.
-__device__ __forceinline__ void take_spares(const RgState &S, const RgState *__restrict__ SPd, const RgConfig &c, int lane, int e, bool taken) {
+__device__ __forceinline__ void take_spares(const RgState &S, const RgState *__restrict__ SPd, const RgConfig &c, int lane, int e, bool taken, bool &on_stairs) {
     const uint64_t tm = __ballot(taken);
     if (!tm) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // pairs with k_regen's release of sp_ready = 1
@@ -1875,6 +1901,7 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
         const uint16_t pp = SP.p_pos[e];
         const int32_t hp = SP.p_hp[e], hpm = SP.p_hpmax[e], lv = SP.p_lvl[e];
         const uint32_t ex = SP.p_exp[e], fd = SP.food[e], qu = SP.quiet[e], pg = SP.pack_gold[e], dl = SP.dlevel[e], mc = SP.mon_cnt[e];
+        on_stairs = SP.on_stairs[e] != 0;
 #pragma unroll
         for (int k = 0; k < 12; k++) S.rng[k * n + e] = r[k];
         S.p_pos[e] = pp; S.p_hp[e] = hp; S.p_hpmax[e] = hpm; S.p_lvl[e] = lv;
@@ -1908,7 +1935,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     const int lane = threadIdx.x;
     Prof pf; pf.start(S.prof);
     Env E;
-    E.err = 0;
+    E.err = 0; E.on_stairs = 0;
     uint32_t react = 0, err = 0, old_flags = 0, steps = 0, flags = 0;
     int act = ACT_NOOP, dir = 0;
     int gold_before = 0;
@@ -1917,16 +1944,19 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     bool taken = false;  // terminal + auto-reset + spare ready: the spare becomes the live state at the end of the wave (take_spares)
     uint32_t n_bfs = 0, n_inline = 0, n_taken = 0;  // workload counters (S.stats)
     uint32_t key = 0;
+    bool listed = false;  // the env is in the stair set this launch reads (its player stands on the stairs)
     if (valid_in) {  // one round of independent loads (a lane that turns out to be somebody else's -- stair_role 2 -- just drops them)
+        listed = S.stair_mark[(size_t)(S.stair_gen & 1) * S.n + e] != 0;
         old_flags = S.flags[e];
         steps = S.steps[e];
         gold_before = S.status[(size_t)e * 10 + 1];
         if (e < S.n_keys) key = keys[e];  // (an env beyond the key prefix has no key: key = 0, never '>')
     }
     // An env is played by a stair wave iff its player stands on the stairs AND this key is '>' (the only way into a level generation); both
-    // kinds of wave decide from the same two words -- the key and the ON_STAIRS bit, which no k_step wave ever clears -- so exactly one of them
-    // takes the env.  A listed env with any other key costs its stair wave one round of loads.
-    const bool to_stair_wave = (old_flags & RG_FLAG_ON_STAIRS) && key == '>';
+    // kinds of wave decide from the same two values -- the key and the env's byte of the stair set this launch READS, which nothing writes while
+    // the launch runs (the set for the next launch is a different buffer) -- so exactly one of them takes the env, whenever it starts.  A listed
+    // env with any other key costs its stair wave one round of loads.
+    const bool to_stair_wave = listed && key == '>';
     const bool valid = valid_in && (stair_role == 0 || (stair_role == 1) == to_stair_wave);
     const bool has_key = valid && e < S.n_keys;  // ThreadConductor::step zips keys with envs (thread_impls.rs:62-64)
     if (valid) {
@@ -2048,7 +2078,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             flags = (react & 0x7f00u);                       // message flags of this key only
             if (react & R_REDRAW) flags |= RG_FLAG_REDRAW | ((react & R_HIST_STALE) ? RG_FLAG_HIST_STALE : 0);
             else flags |= old_flags & (RG_FLAG_REDRAW | RG_FLAG_HIST_STALE);
-            flags |= old_flags & (RG_FLAG_HIST_LAG | RG_FLAG_HIST_DIRTY | RG_FLAG_ON_STAIRS);  // (ON_STAIRS: refreshed by the next render pass if the player moved)
+            flags |= old_flags & (RG_FLAG_HIST_LAG | RG_FLAG_HIST_DIRTY);
             if ((react & R_HIST_CHANGED) || descends) flags |= RG_FLAG_HIST_DIRTY;
             if (react & R_STATUS) write_status(S, c, E);
             if (ui_dead) flags |= RG_FLAG_DEAD;
@@ -2086,9 +2116,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             write_status(S, c, E);
             S.dc_len[e] = 0; S.dc_head[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
             steps = 0;
-            // (ON_STAIRS is carried, never cleared here: the index-order wave that holds this env's lane decides from that bit whether the env is
-            // somebody else's, and it may read the flag word after the stair wave has already written it; the render pass recomputes the bit)
-            flags = RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY | (old_flags & RG_FLAG_ON_STAIRS);
+            flags = RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY;
             klog_new_episode(S, e);
         }
         if (E.err) { flags |= E.err; atomicOr(S.err_any, E.err); }
@@ -2100,7 +2128,13 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         int gold_after = S.status[(size_t)e * 10 + 1];
         S.reward[e] = (float)(gold_after - gold_before > 0 ? gold_after - gold_before : 0);
     }
-    take_spares(S, SPd, c, lane, e, taken);
+    // the stair set for the NEXT k_step: where does this env's player stand now?  A level generated in this turn reported it (place_player), a taken
+    // spare carries it, otherwise it is the tile under the player in the window (centred on where the last move started; the player is within one cell)
+    bool on_next = listed;
+    if (live) on_next = ((descends || (terminal && c.auto_reset && !taken)) ? E.on_stairs != 0
+                                                                              : (win_get(w, WIN_K(E.px - w.ox, E.py - w.oy)) & C_SURF_MASK) == S_STAIR);
+    take_spares(S, SPd, c, lane, e, taken, on_next);
+    stair_publish(S, lane, e, valid, on_next);
     pf.mark(7);
     pf.finish();
 }
@@ -2111,8 +2145,8 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
 // Stair isolation.  The one thing in a step that takes far longer than everything else is a DESCENT: the new level is generated inside the turn
 // (35-45 us by the whole wave, and the 63 other lanes of the wave wait for it) -- ~20 descents per 65 536-env step, and the launch lasts as
 // long as its slowest wave (80-100 us with the descent inside a 64-env wave, against 30-50 us for every other wave).  A descent needs the player
-// on the stairs, and whether he is there is known BEFORE the step: the render / observation pass keeps RG_FLAG_ON_STAIRS per env and
-// lists those envs (S.stair_list, ~240 of 65 536).  The blocks at the FRONT of the grid look the listed envs' keys up: an env that presses
+// on the stairs, and whether he is there is known BEFORE the step: whoever moved the players last (the previous k_step, k_build, the debug descent)
+// left a byte per env and the list of the marked envs (S.stair_mark / stair_list, ~240 of 65 536; rg_state.h).  The blocks at the FRONT of the grid look the listed envs' keys up: an env that presses
 // '>' gets that wave for itself -- its turn + generation chain (55-70 us) starts at t = 0 and nobody waits for it -- and the index-order
 // wave holding its lane skips it; the other listed envs stay with their index-order waves.  (Sorting the envs of a step into
 // descent / awake-monster / plain waves with a classification kernel was tried first: neutral)
@@ -2127,9 +2161,11 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, const RgState *__restr
     // this block's work: ONE call site of the turn code, whatever the role
     const int32_t *list = nullptr;
     int first = blockIdx.x * epw, stride = 0, per = epw, items = S.n;
-    if (parity >= 0) {
-        if ((int)blockIdx.x < STAIR_BLOCKS) { list = S.stair_list + (size_t)parity * S.n; first = blockIdx.x; stride = STAIR_BLOCKS; per = 1; items = (int)S.stair_cnt[parity]; }
-        else first = (blockIdx.x - STAIR_BLOCKS) * epw;
+    if (blockIdx.x == 0 && lane == 0) stair_recycle(S);
+    if (parity >= 0) {  // stair waves on: the first STAIR_BLOCKS blocks serve the stair set this launch reads
+        if ((int)blockIdx.x < STAIR_BLOCKS) {
+            list = S.stair_list + (size_t)(S.stair_gen & 1) * S.n; first = blockIdx.x; stride = STAIR_BLOCKS; per = 1; items = (int)S.stair_cnt[S.stair_gen % 3];
+        } else first = (blockIdx.x - STAIR_BLOCKS) * epw;
     }
     for (int i0 = first; i0 < items; i0 += stride) {
         const bool v = lane < per && i0 + lane < items;

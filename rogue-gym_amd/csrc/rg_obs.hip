@@ -30,15 +30,9 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RgState S, RgConfig c
     __shared__ uint16_t s_cell_at[2 * RG_MAX_ROOMS];  // cell words under gold / monster overlays
     const int tid = threadIdx.x, W = c.width, H = c.height, HW = W * H, n = S.n;
     const int nrooms = c.room_num_x * c.room_num_y;
-    uint32_t *st_cnt = S.stair_cnt + S.stair_parity;
-    int32_t *st_list = S.stair_list + (size_t)S.stair_parity * n;
-    if (blockIdx.x == 0 && tid == 0) S.stair_cnt[S.stair_parity ^ 1] = 0;  // the other set is idle: ready for the pass after this one
     for (int e = blockIdx.x; e < n; e += gridDim.x) {
         const uint32_t fl = S.flags[e];
-        if (!(fl & RG_FLAG_REDRAW)) {  // the player did not move: still (not) on the stairs
-            if (tid == 0 && (fl & RG_FLAG_ON_STAIRS)) st_list[atomicAdd(st_cnt, 1u)] = e;
-            continue;
-        }
+        if (!(fl & RG_FLAG_REDRAW)) continue;
         const uint16_t *cell = S.cell + (size_t)e * HW;
         const bool upd_hist = !(fl & RG_FLAG_HIST_STALE);
         uint8_t *hist = S.hist + (size_t)e * HW;
@@ -82,12 +76,8 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RgState S, RgConfig c
             for (int i = tid; i < HW / 4; i += RENDER_THREADS) d4[i] = s4[i];
         } else
             for (int i = tid; i < HW; i += RENDER_THREADS) scr[i] = s_scr[i];
-        if (tid == 0) {  // the history plane was written unless this Redraw was stale
-            const bool on = (cell[py * W + px] & C_SURF_MASK) == S_STAIR;  // RG_FLAG_ON_STAIRS: k_step gives these envs a wave of their own
-            if (on) st_list[atomicAdd(st_cnt, 1u)] = e;
-            S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_ON_STAIRS | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | (upd_hist ? RG_FLAG_HIST_DIRTY : 0u))) |
-                         ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u) | (on ? RG_FLAG_ON_STAIRS : 0u);
-        }
+        if (tid == 0)  // the history plane was written unless this Redraw was stale
+            S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | (upd_hist ? RG_FLAG_HIST_DIRTY : 0u))) | ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u);
         __syncthreads();
     }
     (void)s_cell_at;
@@ -203,7 +193,9 @@ struct ObsTabs {  // per-env entity/room tables staged in LDS: every global load
 // LDS-only workgroup barrier: unlike __syncthreads() it does not drain vmcnt, so the prefetched global loads of the next env stay in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int KIND>
+// GROUPS: the batch is one config group of a handle with several (RgState::ext maps its envs to the handle's env order, and the one-hot depth is the
+// handle's): compiled separately so that the ordinary kernel carries none of it (its 72 registers = 7 waves per SIMD are what its bandwidth rests on)
+template <int KIND, bool GROUPS>
 __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint32_t sflag, int with_hist, float *__restrict__ out,
                                                     uint32_t *__restrict__ err_any, int tpe, int epb, int planes_sym) {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -221,7 +213,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
     }
     for (int g = tid; g < RG_MAX_ENEMY_KINDS + 6; g += blockDim.x) mtile[g] = c.mon[g].tile;
     const int le = tid / tpe, lt = tid - le * tpe;
-    const int base_planes = KIND ? planes_sym : 1;  // planes_sym >= symbols: the handle's one-hot depth (config groups of one handle may differ)
+    const int base_planes = KIND ? (GROUPS ? planes_sym : symbols) : 1;  // planes_sym >= symbols: the handle's one-hot depth (config groups of one handle may differ)
     const int nplanes = base_planes + __popc(sflag) + (with_hist ? 1 : 0);
     uint8_t *scr = envs + (size_t)le * OBS_ENV_BYTES(HW);
     ObsTabs *tb = reinterpret_cast<ObsTabs *>(scr + HW);
@@ -241,7 +233,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
             if (fl & RG_FLAG_REDRAW) {
                 if (lt < Q8) p.v0 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW)[lt];
                 if (lt < nrooms) { p.rect = S.room_rect[lt * n + e]; p.meta = S.room_meta[lt * n + e]; p.mon = S.mon_w0[lt * n + e]; p.gold = S.gold_pos[lt * n + e]; }
-                p.ppos = S.p_pos[e];  // every lane (one address: a broadcast): the lane that owns the player's cell tests it for the staircase
+                if (lt == tpe - 1) p.ppos = S.p_pos[e];
             } else if (lt < Q8) {
                 const uint2 m = reinterpret_cast<const uint2 *>(S.screen + (size_t)e * HW)[lt];
                 p.v0.x = m.x; p.v0.y = m.y;
@@ -249,7 +241,6 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
         }
         return p;
     };
-    if (blockIdx.x == 0 && tid == 0) S.stair_cnt[S.stair_parity ^ 1] = 0;  // the other set is idle: ready for the pass after this one
     const int base0 = blockIdx.x * epb;
     uint32_t fl_cur = load_flag(base0), fl_nxt = load_flag(base0 + stride);
     Pre nxt = prefetch(base0, fl_cur);
@@ -274,7 +265,6 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                 // stale Redraw
                 const bool upd_hist = !(fl & RG_FLAG_HIST_STALE) && (fl & RG_FLAG_HIST_DIRTY);
                 uint2 *hist8 = reinterpret_cast<uint2 *>(S.hist + (size_t)e * HW);
-                const int pidx = POS_Y(t_ppos) * W + POS_X(t_ppos);
                 for (int i = lt; i < Q8; i += tpe) {
                     uint4 v = i == lt ? v0 : cell4[i];
                     uint32_t q[4] = {v.x, v.y, v.z, v.w};
@@ -283,7 +273,6 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                     for (int t = 0; t < 8; t++) {
                         uint32_t cw = (q[t >> 1] >> ((t & 1) * 16)) & 0xffff;
                         int idx = i * 8 + t;
-                        if (idx == pidx) tb->pad[0] = (cw & C_SURF_MASK) == S_STAIR;  // exactly one lane owns the player's cell
                         bool inner = idx >= W && idx < HW - W;  // rows 1..H-2 only (rogue/mod.rs:278-290)
                         uint32_t gl = ' ';
                         if (inner && (cw & C_VISIBLE)) gl = glyph_of(cw);
@@ -342,7 +331,8 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
             uint32_t *m4 = reinterpret_cast<uint32_t *>(S.screen + (size_t)e * HW);
             const uint32_t *scr4 = reinterpret_cast<const uint32_t *>(scr);
             const uint32_t *hist4 = reinterpret_cast<const uint32_t *>(S.hist + (size_t)e * HW);
-            float4 *o = reinterpret_cast<float4 *>(out + (size_t)(S.ext ? S.ext[e] : e) * nplanes * HW);
+            const int xe = GROUPS ? __builtin_amdgcn_readfirstlane(S.ext[e]) : e;  // config-group handles write at the handle's env index (one env per block: uniform)
+            float4 *o = reinterpret_cast<float4 *>(out + (size_t)xe * nplanes * HW);
             const int q4 = HW >> 2;
             const uint32_t smax = (uint32_t)symbols - 1;  // construct_symbol_map fills channels 0..symbols-2 (symbol.rs:51-71)
             float stf[9];
@@ -366,7 +356,7 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                         store_obs(&o[(size_t)ch * q4 + q], v);
                     }
                     float4 z; z.x = z.y = z.z = z.w = 0.f;
-                    for (uint32_t ch = smax; ch < (uint32_t)planes_sym; ch++) store_obs(&o[(size_t)ch * q4 + q], z);  // the last channel is never set
+                    for (uint32_t ch = smax; ch < (uint32_t)base_planes; ch++) store_obs(&o[(size_t)ch * q4 + q], z);  // the last channel is never set
                 }
                 int p = base_planes;
                 for (int b = 0; b < nst; b++, p++) {
@@ -381,14 +371,9 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                 }
             }
             if (KIND == 1 && bad) { atomicOr(&S.flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
-            if (lt == 0) {
-                // RG_FLAG_ON_STAIRS: refreshed when the env was redrawn (the only time the player can have moved), listed for the k_step that follows
-                const bool on = redraw ? tb->pad[0] != 0 : (fl & RG_FLAG_ON_STAIRS) != 0;
-                if (on) S.stair_list[(size_t)S.stair_parity * n + atomicAdd(&S.stair_cnt[S.stair_parity], 1u)] = e;
-                if (redraw)  // a stale Redraw leaves the history mirror one level behind (k_step refreshes it before the next descent)
-                    S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_ON_STAIRS | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | ((fl & RG_FLAG_HIST_STALE) ? 0u : RG_FLAG_HIST_DIRTY))) |
-                                 ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u) | (KIND == 1 && bad ? RG_FLAG_ERR_TILE : 0) | (on ? RG_FLAG_ON_STAIRS : 0u);
-            }
+            if (redraw && lt == 0)  // a stale Redraw leaves the history mirror one level behind (k_step refreshes it before the next descent)
+                S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | ((fl & RG_FLAG_HIST_STALE) ? 0u : RG_FLAG_HIST_DIRTY))) |
+                             ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u) | (KIND == 1 && bad ? RG_FLAG_ERR_TILE : 0);
         }
     }
 }
@@ -480,8 +465,11 @@ int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, 
     int blocks = (S->n + epb - 1) / epb;
     // persistent grid: launching one tiny workgroup per env is dispatch-rate bound (65 536 one-wave blocks: 71 us; 16 384 looping blocks: 51 us)
     { const char *ev = getenv("RG_OBS_BLOCKS"); int cap = ev ? atoi(ev) : (bthreads <= 64 ? 16384 : 8192); if (blocks > cap) blocks = cap; }
-    if (!kind) hipLaunchKernelGGL(k_obs<0>, dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym);
-    else hipLaunchKernelGGL(k_obs<1>, dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym);
+    const bool groups = S->ext != nullptr;
+    if (!kind && !groups) hipLaunchKernelGGL((k_obs<0, false>), dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym);
+    else if (!kind) hipLaunchKernelGGL((k_obs<0, true>), dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym);
+    else if (!groups) hipLaunchKernelGGL((k_obs<1, false>), dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym);
+    else hipLaunchKernelGGL((k_obs<1, true>), dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym);
     return 1;
 }
 void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, size_t rs, size_t rst,

@@ -94,11 +94,15 @@ struct RgState {
     // workload counters (bench.py: resets/s, descents/s, BFS maps/s): [0] auto-resets [1] descents [2] dist maps built [3] inline level
     // generations [4] spare levels taken [5] Redraw reactions [6] keys processed; one atomicAdd per wave and counter
     unsigned long long *stats;
-    // envs whose player stands on the stairs (RG_FLAG_ON_STAIRS), listed by every render / observation pass for the k_step that follows:
-    // [2][n] env indices and two counters used alternately (a pass fills set `stair_parity` and zeroes the other one for the pass after)
-    int32_t *stair_list;
-    uint32_t *stair_cnt;
-    int32_t stair_parity;
+    // Envs whose player stands on the staircase, for k_step's stair waves.  Whoever changes player positions (k_build, k_step, the debug descent)
+    // PRODUCES the set for the k_step after it: a byte per env + the list of the marked envs, double-buffered, with three rotating counters
+    // (producer number g reads set g & 1 / counter g % 3, writes set (g + 1) & 1 / counter (g + 1) % 3, zeroes counter (g + 2) % 3) --
+    // so nothing a launch reads is ever written during that launch.
+    uint8_t *stair_mark;   // [2][n]
+    int32_t *stair_list;   // [2][n]
+    uint32_t *stair_cnt;   // [3]
+    int32_t stair_gen;     // producers launched so far (set by the host before every producer launch)
+    uint8_t *on_stairs;    // [n] spare view only: the pre-generated state's player stands on the stairs
     // handle with per-env configs that differ in more than the seed: this RgState is one config GROUP, and env e of the group is env ext[e] of the
     // handle (observation tensors are written at the handle's index); NULL = the group is the whole handle
     const int32_t *ext;
