@@ -1979,11 +1979,12 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     pf.mark(0);
     bool need_gen = false, descends = false;
     Win w;  // the 5x5 tiles around the player: one round of loads serves the whole player action
-    if (live) win_load(c, E.cell, w, E.px, E.py);
+    // (a stair wave's lanes press '>' on the staircase by construction: nothing of the old level is looked at again, so no window)
+    if (live && stair_role != 1) win_load(c, E.cell, w, E.px, E.py);
     else { w.inb = 0; w.dirty = 0; w.ox = w.oy = 0; }
     pf.mark(26);
     if (live && act == ACT_DOWNSTAIR) {
-        if ((w.v[WIN_K(0, 0)] & C_SURF_MASK) == S_STAIR) {
+        if (stair_role == 1 || (w.v[WIN_K(0, 0)] & C_SURF_MASK) == S_STAIR) {
             need_gen = descends = true;
             react |= R_REDRAW | R_STATUS | R_HIST_STALE;  // Redraw precedes StatusUpdated: history keeps the old level
         } else react |= MSG_NO_DOWNSTAIR;
