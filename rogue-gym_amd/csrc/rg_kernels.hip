@@ -613,8 +613,12 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
     // ---- dig_passges (passages.rs:16-67) ----
     int n_edges = 0;
     {
-        uint32_t conn[RG_MAX_ROOMS];
-        for (int i = 0; i < RG_MAX_ROOMS; i++) conn[i] = 0;
+        // the room graph's adjacency masks: room i's mask in LANE i of one VGPR (<= 32 rooms <= 64 lanes), read with v_readlane and updated with a
+        // lane-select -- a `uint32_t conn[32]` indexed at run time lived in scratch memory, a memory round trip per access inside this RNG-ordered chain
+        uint32_t conn_v = 0;
+        const int lane_id = (int)threadIdx.x;
+        auto conn_get = [&](int i) -> uint32_t { return lane_get(conn_v, i); };
+        auto conn_or = [&](int i, uint32_t bits) { conn_v = lane_id == i ? (conn_v | bits) : conn_v; };
         uint32_t selected = 0;
         int cur = (int)range64(E.rd, 0, (uint64_t)nrooms), n_sel = 1;
         selected |= 1u << cur;
@@ -623,7 +627,7 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
             int nxt = select_candidate(c, E, nrooms, cur, selected, dir);
             if (nxt >= 0) {
                 selected |= 1u << nxt; n_sel++;
-                conn[cur] |= 1u << nxt; conn[nxt] |= 1u << cur;
+                conn_or(cur, 1u << nxt); conn_or(nxt, 1u << cur);
                 connect_rooms(S, c, E, cur, nxt, dir, n_edges);
             } else {
                 cur = nth_bit(selected, (int)range64(E.rd, 0, (uint64_t)n_sel));
@@ -632,9 +636,9 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
         uint32_t try_num = range32(E.rd, 0, c.max_extra_edges);
         for (uint32_t t = 0; t < try_num; t++) {
             int room1 = (int)range64(E.rd, 0, (uint64_t)nrooms), dir = 0;
-            int room2 = select_candidate(c, E, nrooms, room1, conn[room1], dir);
+            int room2 = select_candidate(c, E, nrooms, room1, conn_get(room1), dir);
             if (room2 >= 0) {
-                conn[room1] |= 1u << room2; conn[room2] |= 1u << room1;
+                conn_or(room1, 1u << room2); conn_or(room2, 1u << room1);
                 connect_rooms(S, c, E, room1, room2, dir, n_edges);
             }
         }
