@@ -805,7 +805,12 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
         if (is_build) build_epilogue(L, c, U);
         place_player(L, c, U, non_empty);
         U.e = real_e; U.n = real_n;
-        if (lane == src) { env_to_lane(E, U); need = false; }
+        if (lane == src) {
+            env_to_lane(E, U); need = false;
+            // k_step's LDS monster cache of the requesting lane: filled straight from the generator's table (the alternative -- reloading the column
+            // from the global table that is written just below -- is a memory round trip in the descent chain, the longest chain of a step)
+            if (E.mc) for (int s = 0; s < nrooms; s++) E.mc[s * WAVE] = T->mon_w0[s];
+        }
         __syncthreads();
         // tables: one room slot per lane; grid: 16 bytes per lane
         if (lane < nrooms) {
@@ -912,7 +917,7 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     const int e = blockIdx.x * BUILD_EPB + lane;
     const bool valid = lane < BUILD_EPB && e < S.n;
     Env E;
-    E.e = valid ? e : 0; E.n = S.n; E.cell = E.gcell = S.cell + (size_t)E.e * S.hw; E.err = 0;
+    E.e = valid ? e : 0; E.n = S.n; E.cell = E.gcell = S.cell + (size_t)E.e * S.hw; E.err = 0; E.mc = nullptr;
     Prof pf; pf.start(S.prof);
     E.on_stairs = 0;
     gen_service(S, c, E, lane, e, valid, true, reinterpret_cast<uint16_t *>(g_smem), pf);
@@ -938,7 +943,7 @@ __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
     const int e = blockIdx.x * BUILD_EPB + lane;
     const bool valid = lane < BUILD_EPB && e < S.n;
     Env E;
-    E.err = 0;
+    E.err = 0; E.mc = nullptr;
     load_env(S, E, valid ? e : 0);
     Prof pf; pf.start(nullptr);
     E.on_stairs = 0;
@@ -970,7 +975,7 @@ __global__ void __launch_bounds__(WAVE) k_regen(RgState SP, RgConfig c) {
         claim = atomicCAS(&SP.sp_ready[e], 0u, 2u) == 0u;
     if (!__any(claim)) return;
     Env E;
-    E.e = valid ? e : 0; E.n = SP.n; E.cell = E.gcell = SP.cell + (size_t)E.e * SP.hw; E.err = 0;
+    E.e = valid ? e : 0; E.n = SP.n; E.cell = E.gcell = SP.cell + (size_t)E.e * SP.hw; E.err = 0; E.mc = nullptr;
     Prof pf; pf.start(nullptr);
     E.on_stairs = 0;
     gen_service(SP, c, E, lane, e, claim, true, reinterpret_cast<uint16_t *>(g_smem), pf);
@@ -2018,7 +2023,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         const bool regenerated = descends && pass == 0;
         if (need_gen) n_inline++;
         gen_service(S, c, E, lane, e, need_gen, pass == 1, lds_grid, pf);
-        if (regenerated) for (int s = 0; s < nrooms_k; s++) E.mc[s * WAVE] = S.mon_w0[s * S.n + e];  // descended: reload this lane's cache column (after a reset nothing reads it again)
+        (void)regenerated;  // (a descended lane's monster-cache column was refilled by gen_service from the generator's own table)
         pf.mark(2);
         need_gen = false;
         if (pass == 1) break;
