@@ -94,10 +94,10 @@ __device__ __forceinline__ int dir_dy(int d) { return (int)((dir_pack(kDYc) >> (
 
 // optional phase trace (development aid, tools/microbench.py prof): lane 0 of every wave appends (phase, elapsed shader-clock ticks)
 // records to the wave's own 64-word row of S.prof with plain stores -- no atomics, so the trace does not perturb what it measures.
-// Word 0 = number of records, word 63 = whole-wave ticks.
+// Word 0 = number of records, word 63 = whole-wave ticks, word 62 = start | end on the 100 MHz clock.
 struct Prof {
-    unsigned long long *p; unsigned long long t, t0; int k;
-    __device__ __forceinline__ void start(unsigned long long *pp) { p = pp ? pp + (size_t)blockIdx.x * 64 : nullptr; k = 0; if (p) t = t0 = __builtin_amdgcn_s_memtime(); }
+    unsigned long long *p; unsigned long long t, t0, r0; int k;
+    __device__ __forceinline__ void start(unsigned long long *pp) { p = pp ? pp + (size_t)blockIdx.x * 64 : nullptr; k = 0; if (p) { r0 = __builtin_amdgcn_s_memrealtime(); t = t0 = __builtin_amdgcn_s_memtime(); } }
     __device__ __forceinline__ void rec(int phase, unsigned long long v) {
         if (p && threadIdx.x == 0 && k < 61) p[1 + k++] = ((unsigned long long)phase << 48) | (v & 0xffffffffffffull);
     }
@@ -108,7 +108,8 @@ struct Prof {
         t = now;
     }
     __device__ __forceinline__ void finish() {
-        if (p && threadIdx.x == 0) { p[0] = (unsigned long long)k; p[63] = __builtin_amdgcn_s_memtime() - t0; }
+        // word 62: the wave's start and end on the chip-wide 100 MHz clock (low 32 bits each): where a launch's time goes outside its waves
+        if (p && threadIdx.x == 0) { p[0] = (unsigned long long)k; p[63] = __builtin_amdgcn_s_memtime() - t0; p[62] = (r0 << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull); }
     }
 };
 
@@ -802,8 +803,10 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
         L.maze_stack = S.maze_stack + (size_t)real_e * S.maze_cap;
         U.e = 0; U.n = 1;
         uint32_t non_empty = gen_level(L, c, U, pf);
+        pf.mark(17);
         if (is_build) build_epilogue(L, c, U);
         place_player(L, c, U, non_empty);
+        pf.mark(18);
         U.e = real_e; U.n = real_n;
         if (lane == src) {
             env_to_lane(E, U); need = false;
@@ -811,7 +814,9 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
             // from the global table that is written just below -- is a memory round trip in the descent chain, the longest chain of a step)
             if (E.mc) for (int s = 0; s < nrooms; s++) E.mc[s * WAVE] = T->mon_w0[s];
         }
+        pf.mark(19);
         __syncthreads();
+        pf.mark(21);
         // tables: one room slot per lane; grid: 16 bytes per lane
         if (lane < nrooms) {
             const size_t g = (size_t)lane * real_n + real_e;
@@ -832,6 +837,7 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
         if (pf.p) pf.rec(20, __builtin_amdgcn_s_memtime() - tg0);
         pf.mark(16);
         __syncthreads();
+        pf.mark(23);
     }
     (void)e;
 }
@@ -885,6 +891,7 @@ __device__ __forceinline__ void stair_publish(const RgState &S, int lane, int e,
 }
 __device__ __forceinline__ void stair_recycle(const RgState &S) {  // one thread of the launch: the counter nobody reads or writes right now
     S.stair_cnt[(S.stair_gen + 2) % 3] = 0;
+    S.stair_cnt[4 + (S.stair_gen + 2) % 3] = 0;  // ... and its take counter (k_step's stair blocks)
 }
 
 // Action-history log (RunTime::saved_inputs: react_to_input pushes every mapped key before it is processed, core/src/lib.rs:288; a rebuilt
@@ -1499,14 +1506,19 @@ __device__ __forceinline__ void player_attack(const RgState &S, const RgConfig &
 // are recorded as rectangles and applied by the wave (fill_service), mirrored into the window in the reference's order.
 // ---------------------------------------------------------------------------------------------
 struct Win {
-    uint32_t v[25];        // cell (ox + i, oy + j) at index (j + 2) * 5 + (i + 2); 0 outside the grid
+    lds_u16 *v;            // cell (ox + i, oy + j) = v[((j + 2) * 5 + (i + 2)) * WAVE] (this lane's column of the wave's [25][64] LDS block); 0 outside the grid
     uint32_t inb, dirty;   // bit k: cell k lies inside the grid / was modified since the load
     int ox, oy;
 };
+// The window lives in LDS, not in registers: 25 VGPRs held from the first load to the last line of the turn (the stair test of the tail reads it)
+// were a tenth of the kernel's register budget, and a run-time index into registers is a 25-deep select chain where LDS takes an address.
 #define WIN_K(i, j) (((j) + 2) * 5 + (i) + 2)
+#define WV(w, k) ((uint32_t)(w).v[(k) * WAVE])
+#define WSET(w, k, val) ((w).v[(k) * WAVE] = (uint16_t)(val))
 
 __device__ __forceinline__ void win_load(const RgConfig &c, const uint16_t *cell, Win &w, int ox, int oy) {
     w.ox = ox; w.oy = oy; w.inb = 0; w.dirty = 0;
+    uint32_t t[25];
 #pragma unroll
     for (int j = -2; j <= 2; j++)
 #pragma unroll
@@ -1514,9 +1526,11 @@ __device__ __forceinline__ void win_load(const RgConfig &c, const uint16_t *cell
             const int x = ox + i, y = oy + j;
             const bool in = in_bounds(c, x, y);
             const uint32_t val = cell[in ? y * c.width + x : oy * c.width + ox];  // unconditional load: all 25 are in flight together
-            w.v[WIN_K(i, j)] = in ? val : 0u;
+            t[WIN_K(i, j)] = in ? val : 0u;
             if (in) w.inb |= 1u << WIN_K(i, j);
         }
+#pragma unroll
+    for (int k = 0; k < 25; k++) WSET(w, k, t[k]);
 }
 __device__ __forceinline__ void win_flush(const RgConfig &c, uint16_t *cell, Win &w) {
     if (!w.dirty) return;
@@ -1524,18 +1538,12 @@ __device__ __forceinline__ void win_flush(const RgConfig &c, uint16_t *cell, Win
     for (int j = -2; j <= 2; j++)
 #pragma unroll
         for (int i = -2; i <= 2; i++)
-            if ((w.dirty >> WIN_K(i, j)) & 1u) cell[(w.oy + j) * c.width + w.ox + i] = (uint16_t)w.v[WIN_K(i, j)];
+            if ((w.dirty >> WIN_K(i, j)) & 1u) cell[(w.oy + j) * c.width + w.ox + i] = (uint16_t)WV(w, WIN_K(i, j));
     w.dirty = 0;
 }
-__device__ __forceinline__ uint32_t win_get(const Win &w, int k) {  // run-time index: a select chain, never scratch
-    uint32_t r = 0;
-#pragma unroll
-    for (int t = 0; t < 25; t++) r = (t == k) ? w.v[t] : r;
-    return r;
-}
+__device__ __forceinline__ uint32_t win_get(const Win &w, int k) { return WV(w, k); }  // run-time index
 __device__ __forceinline__ void win_set(Win &w, int k, uint32_t val) {
-#pragma unroll
-    for (int t = 0; t < 25; t++) w.v[t] = (t == k) ? val : w.v[t];
+    WSET(w, k, val);
     w.dirty |= 1u << k;
 }
 // apply `v = (v & ~clr) | set` to the window cells inside the half-open rectangle, and mark them for write-back (the wave's global
@@ -1547,7 +1555,7 @@ __device__ __forceinline__ void win_rect(Win &w, int x0, int y0, int x1, int y1,
         for (int i = -2; i <= 2; i++) {
             const int x = w.ox + i, y = w.oy + j;
             if (x >= x0 && x < x1 && y >= y0 && y < y1 && ((w.inb >> WIN_K(i, j)) & 1u)) {
-                w.v[WIN_K(i, j)] = (w.v[WIN_K(i, j)] & ~clr) | set;
+                WSET(w, WIN_K(i, j), (WV(w, WIN_K(i, j)) & ~clr) | set);
                 w.dirty |= 1u << WIN_K(i, j);
             }
         }
@@ -1577,7 +1585,7 @@ __device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c,
     int ms = mon_find(S, E, nrooms, POS(nx, ny));
     if (ms >= 0) { player_attack(S, c, E, ms, react); return true; }
     // ---- Floor::player_out at the old cell (field-of-view, floor.rs:201-312) ----
-    if (w.v[WIN_K(0, 0)] & C_DOOR) {  // Floor::leaves_room (floor.rs:249-261)
+    if (WV(w, WIN_K(0, 0)) & C_DOOR) {  // Floor::leaves_room (floor.rs:249-261)
         int rid = room_id_of(c, E.px, E.py);
         if (rid >= 0) {
             uint8_t meta = S.room_meta[rid * E.n + E.e];
@@ -1596,9 +1604,9 @@ __device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c,
     for (int j = -1; j <= 1; j++)
 #pragma unroll
         for (int i = -1; i <= 1; i++) {  // Cell::left on the 3x3 around the old cell
-            const uint32_t v = w.v[WIN_K(i, j)];
+            const uint32_t v = WV(w, WIN_K(i, j));
             if (((w.inb >> WIN_K(i, j)) & 1u) && (v & C_SURF_MASK) == S_FLOOR && (v & C_DARK) && (v & C_VISIBLE)) {
-                w.v[WIN_K(i, j)] = v & ~C_VISIBLE;
+                WSET(w, WIN_K(i, j), v & ~C_VISIBLE);
                 w.dirty |= 1u << WIN_K(i, j);
             }
         }
@@ -1629,10 +1637,10 @@ __device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c,
         for (int i = -2; i <= 2; i++) {  // Cell::approached (field.rs:20-26) on the 3x3 around the new cell
             const int ddx = i - dx, ddy = j - dy;
             const bool near = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && ((w.inb >> WIN_K(i, j)) & 1u);
-            const uint32_t v = w.v[WIN_K(i, j)];
+            const uint32_t v = WV(w, WIN_K(i, j));
             const bool diag = ddx != 0 && ddy != 0;
             if (near && !(diag && (v & C_SURF_MASK) == S_PASSAGE) && !(v & C_HIDDEN) && (v & (C_DRAWN | C_VISIBLE)) != (C_DRAWN | C_VISIBLE)) {
-                w.v[WIN_K(i, j)] = v | C_DRAWN | C_VISIBLE;
+                WSET(w, WIN_K(i, j), v | C_DRAWN | C_VISIBLE);
                 w.dirty |= 1u << WIN_K(i, j);
             }
         }
@@ -1682,7 +1690,7 @@ __device__ __forceinline__ void do_search(const RgConfig &c, Env &E, Win &w, uin
     for (int d = 0; d < 8; d++) {
         const int k = WIN_K(kDXc[d], kDYc[d]);
         if (!((w.inb >> k) & 1u)) continue;
-        uint32_t v = w.v[k];
+        uint32_t v = WV(w, k);
         const uint32_t v_in = v;
         if ((v & C_HIDDEN) && does_happen(E.rd, c.passage_unlock_rate_inv))
             v = (v & ~(C_LOCKED | C_HIDDEN | C_SURF_MASK)) | C_VISIBLE | S_PASSAGE;
@@ -1690,7 +1698,7 @@ __device__ __forceinline__ void do_search(const RgConfig &c, Env &E, Win &w, uin
             v = (v & ~(C_LOCKED | C_HIDDEN | C_SURF_MASK)) | C_VISIBLE | S_DOOR;
             react |= MSG_SECRET_DOOR;
         }
-        if (v != v_in) { w.v[k] = v; w.dirty |= 1u << k; }
+        if (v != v_in) { WSET(w, k, v); w.dirty |= 1u << k; }
     }
     react |= R_REDRAW;
 }
@@ -1954,12 +1962,20 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     uint32_t n_bfs = 0, n_inline = 0, n_taken = 0;  // workload counters (S.stats)
     uint32_t key = 0;
     bool listed = false;  // the env is in the stair set this launch reads (its player stands on the stairs)
-    if (valid_in) {  // one round of independent loads (a lane that turns out to be somebody else's -- stair_role 2 -- just drops them)
+    // LDS monster cache: column `lane` of [nrooms][64] words behind the generation / BFS staging area
+    const int nrooms_k = c.room_num_x * c.room_num_y;
+    E.mc = reinterpret_cast<uint32_t *>(g_smem + mc_offset) + lane;
+    if (valid_in) {
+        // ONE round of independent loads: the step's inputs, the env's scalars and its monster words together.  (Whether the lane plays at all is
+        // only known from the first few -- loading the env behind that decision was a second dependent round trip in every wave; a lane that turns
+        // out to be somebody else's (stair_role 2), dead or past max_steps just drops what it loaded.)
         listed = S.stair_mark[(size_t)(S.stair_gen & 1) * S.n + e] != 0;
         old_flags = S.flags[e];
         steps = S.steps[e];
         gold_before = S.status[(size_t)e * 10 + 1];
         if (e < S.n_keys) key = keys[e];  // (an env beyond the key prefix has no key: key = 0, never '>')
+        load_env(S, E, e);
+        for (int s = 0; s < nrooms_k; s++) E.mc[s * WAVE] = S.mon_w0[s * S.n + e];
     }
     // An env is played by a stair wave iff its player stands on the stairs AND this key is '>' (the only way into a level generation); both
     // kinds of wave decide from the same two values -- the key and the env's byte of the stair set this launch READS, which nothing writes while
@@ -1978,22 +1994,18 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
                 else live = true;
             }
         }
-        if (live) load_env(S, E, e);
     }
-    // LDS monster cache: column `lane` of [nrooms][64] words behind the generation / BFS staging area
-    const int nrooms_k = c.room_num_x * c.room_num_y;
-    E.mc = reinterpret_cast<uint32_t *>(g_smem + mc_offset) + lane;
-    if (live) for (int s = 0; s < nrooms_k; s++) E.mc[s * WAVE] = S.mon_w0[s * S.n + e];
     // Action::DownStair (actions.rs:27-36): the new level is produced by the generation service below
     pf.mark(0);
     bool need_gen = false, descends = false;
     Win w;  // the 5x5 tiles around the player: one round of loads serves the whole player action
+    w.v = (lds_u16 *)(g_smem + mc_offset + nrooms_k * WAVE * 4) + lane;
     // (a stair wave's lanes press '>' on the staircase by construction: nothing of the old level is looked at again, so no window)
     if (live && stair_role != 1) win_load(c, E.cell, w, E.px, E.py);
     else { w.inb = 0; w.dirty = 0; w.ox = w.oy = 0; }
     pf.mark(26);
     if (live && act == ACT_DOWNSTAIR) {
-        if (stair_role == 1 || (w.v[WIN_K(0, 0)] & C_SURF_MASK) == S_STAIR) {
+        if (stair_role == 1 || (WV(w, WIN_K(0, 0)) & C_SURF_MASK) == S_STAIR) {
             need_gen = descends = true;
             react |= R_REDRAW | R_STATUS | R_HIST_STALE;  // Redraw precedes StatusUpdated: history keeps the old level
         } else react |= MSG_NO_DOWNSTAIR;
@@ -2168,21 +2180,26 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, const RgState *__restr
                                                int parity) {
     __builtin_amdgcn_s_setprio(3);  // issue-bound kernel: win VALU arbitration against the co-resident background k_regen waves
     const int lane = threadIdx.x;
-    // this block's work: ONE call site of the turn code, whatever the role
-    const int32_t *list = nullptr;
-    int first = blockIdx.x * epw, stride = 0, per = epw, items = S.n;
     if (blockIdx.x == 0 && lane == 0) stair_recycle(S);
-    if (parity >= 0) {  // stair waves on: the first STAIR_BLOCKS blocks serve the stair set this launch reads
-        if ((int)blockIdx.x < STAIR_BLOCKS) {
-            list = S.stair_list + (size_t)(S.stair_gen & 1) * S.n; first = blockIdx.x; stride = STAIR_BLOCKS; per = 1; items = (int)S.stair_cnt[S.stair_gen % 3];
-        } else first = (blockIdx.x - STAIR_BLOCKS) * epw;
-    }
-    for (int i0 = first; i0 < items; i0 += stride) {
-        const bool v = lane < per && i0 + lane < items;
-        const int e = v ? (list ? list[i0 + lane] : i0 + lane) : 0;
-        step_wave<BW>(S, SPd, c, keys, use_spares, mc_offset, e, v, parity >= 0 ? (list ? 1 : 2) : 0);
-        if (stride == 0) break;
+    // this block's work: ONE call site of the turn code, whatever the role
+    const bool stair = parity >= 0 && (int)blockIdx.x < STAIR_BLOCKS;  // stair waves on: the first STAIR_BLOCKS blocks serve the stair set this launch reads
+    const int32_t *list = S.stair_list + (size_t)(S.stair_gen & 1) * S.n;
+    const int items = stair ? (int)S.stair_cnt[S.stair_gen % 3] : S.n;
+    const int first = stair ? (int)blockIdx.x : ((int)blockIdx.x - (parity >= 0 ? STAIR_BLOCKS : 0)) * epw;
+    // Stair block b looks at entry b of the list; entries beyond the first STAIR_BLOCKS are handed out one at a time through a counter, so that a
+    // block busy with a descent (60 us) never has a second one queued behind it while its neighbours sit idle.  An entry whose env does not press
+    // '>' stays with its index-order wave (step_wave's rule, applied here before anything else of the env is loaded: such a block is gone in ~2 us).
+    uint32_t *next = S.stair_cnt + 4 + S.stair_gen % 3;  // zeroed two producers ago (stair_recycle)
+    for (int i0 = first; i0 < items;) {
+        bool v; int e;
+        if (stair) { e = list[i0]; v = lane == 0 && e < S.n_keys && keys[e] == '>'; }
+        else { v = lane < epw && i0 + lane < items; e = v ? i0 + lane : 0; }
+        if (!stair || __any(v)) step_wave<BW>(S, SPd, c, keys, use_spares, mc_offset, e, v, parity >= 0 ? (stair ? 1 : 2) : 0);
+        if (!stair || items <= STAIR_BLOCKS) break;
         __syncthreads();  // the next item reuses the wave's LDS
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(next, 1u);
+        i0 = STAIR_BLOCKS + (int)uni(t);
     }
 }
 
@@ -2204,6 +2221,7 @@ void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const 
     smem = (smem + 15) & ~(size_t)15;
     int mc_offset = (int)smem;
     smem += (size_t)c->room_num_x * c->room_num_y * WAVE * 4;  // LDS monster cache
+    smem += 25 * WAVE * 2;                                     // ... and the lanes' 5x5 tile windows
     // envs per wave: the register footprint allows one step wave per SIMD (1024 on the chip); a batch below 64 x 1024 envs is spread over more,
     // emptier waves (less divergence per wave, no idle SIMDs).  More waves than SIMDs never pays: a wave's cost is the union of its lanes' paths.
     static const int epw_env = getenv("ROGUE_GYM_HIP_EPW") ? atoi(getenv("ROGUE_GYM_HIP_EPW")) : 0;

@@ -123,13 +123,34 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
                 print("   %-12s (last launch) n=%d mean %.1f us p50 %.1f p90 %.1f max %.1f" % (nm, len(seg), seg.mean(), np.percentile(seg, 50), np.percentile(seg, 90), seg.max()))
         hist = np.histogram(tot * TICK_US, bins=np.arange(0, 260, 10))[0] / nl
         print("   wave-duration histogram (10 us buckets, waves per launch): " + " ".join("%.0f" % v for v in hist))
+        # where the launch's time goes outside its waves: start / end of every wave of the last launch on the chip-wide 100 MHz clock
+        used = buf[:, 63] > 0
+        st = (buf[used, 62] >> np.uint64(32)).astype(np.int64); en = (buf[used, 62] & np.uint64(0xffffffff)).astype(np.int64)
+        en = en + ((en < st) * (1 << 32))
+        idx = np.nonzero(used)[0]
+        t0 = st.min()
+        s_us = (st - t0) / 100.0; e_us = (en - t0) / 100.0
+        print("   wave starts after the first wave's start (us): p50 %.1f p90 %.1f p99 %.1f max %.1f; last wave ends at %.1f us" %
+              (np.percentile(s_us, 50), np.percentile(s_us, 90), np.percentile(s_us, 99), s_us.max(), e_us.max()))
+        for nm, lo, hi in (("stair", 0, 256), ("index 0-767", 256, 1024), ("index 768+", 1024, 1 << 30)):
+            sel = (idx >= lo) & (idx < hi)
+            if sel.any():
+                print("      %-12s start p50 %.1f max %.1f | end p50 %.1f p99 %.1f max %.1f" % (nm, np.percentile(s_us[sel], 50), s_us[sel].max(), np.percentile(e_us[sel], 50), np.percentile(e_us[sel], 99), e_us[sel].max()))
+        d_us = e_us - s_us
+        for nm, lo, hi in (("big index", 256, 256 + 1024 - int(os.environ.get("ROGUE_GYM_HIP_TAIL", "64"))), ("small index", 256 + 1024 - int(os.environ.get("ROGUE_GYM_HIP_TAIL", "64")), 1 << 30)):
+            sel = (idx >= lo) & (idx < hi)
+            if sel.any():
+                print("      %-12s n=%d duration p50 %.1f p90 %.1f max %.1f | start p50 %.1f p90 %.1f max %.1f | end p90 %.1f max %.1f" % (nm, sel.sum(), np.percentile(d_us[sel], 50), np.percentile(d_us[sel], 90), d_us[sel].max(),
+                      np.percentile(s_us[sel], 50), np.percentile(s_us[sel], 90), s_us[sel].max(), np.percentile(e_us[sel], 90), e_us[sel].max()))
+        late = np.argsort(-e_us)[:5]
+        print("      last to end: " + ", ".join("block %d start %.1f end %.1f" % (idx[i], s_us[i], e_us[i]) for i in late))
         # which phase makes the slowest waves slow: phase sums over the slowest 1 % of waves of the last launch
         for nm, pid in (("gen (1 lane)", 20), ("gen (>1 lanes)", 22), ("bfs service", 24)):
             if pid in sums:
                 print("   %-16s calls/launch %.1f  avg %.1f us" % (nm, counts[pid] / nl, sums[pid] / counts[pid] * TICK_US))
         if 25 in sums:
             print("   dist maps/launch %.1f" % (sums[25] / nl))
-        order = np.argsort(-buf[:, 63].astype(np.float64))[:3]  # rows of the last launch
+        order = np.argsort(-buf[:, 63].astype(np.float64))[:int(os.environ.get('RG_SLOW_WAVES', '3'))]  # rows of the last launch
         for wv in order:  # the slowest waves of the last launch, record by record
             kk = int(buf[wv, 0])
             recs = ["%s=%.1f" % (PHASES.get(int(r >> np.uint64(48)), str(int(r >> np.uint64(48)))), float(r & np.uint64((1 << 48) - 1)) * TICK_US) for r in buf[wv, 1:1 + kk]]
