@@ -2176,8 +2176,8 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
 #define STAIR_BLOCKS 256   // blocks at the front of the grid that serve the stair list (grid-stride beyond that)
 
 template <int BW>
-__global__ void __launch_bounds__(WAVE) k_step(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset, int epw,
-                                               int parity) {
+__device__ __forceinline__ void step_block(const RgState &S, const RgState *__restrict__ SPd, const RgConfig &c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset, int epw,
+                                           int parity) {
     __builtin_amdgcn_s_setprio(3);  // issue-bound kernel: win VALU arbitration against the co-resident background k_regen waves
     const int lane = threadIdx.x;
     if (blockIdx.x == 0 && lane == 0) stair_recycle(S);
@@ -2201,6 +2201,20 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, const RgState *__restr
         if (lane == 0) t = atomicAdd(next, 1u);
         i0 = STAIR_BLOCKS + (int)uni(t);
     }
+}
+template <int BW>
+__global__ void __launch_bounds__(WAVE) k_step(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset, int epw,
+                                               int parity) {
+    step_block<BW>(S, SPd, c, keys, use_spares, mc_offset, epw, parity);
+}
+// The W <= 32 instance with the register allocation capped for TWO waves per SIMD (256 VGPRs).  With the 5x5 window in LDS it needs ~250: told to,
+// the allocator fits it without a spill (left alone it lands on either side of the line from build to build).  Every block of a 65 536-env launch
+// (1024 index-order + the stair blocks) is then resident from t = 0.  At one wave per SIMD the ~20 stair waves that really descend kept their SIMDs
+// for the whole launch, as many index-order blocks started only when the first waves ended (33-38 us) and finished last (84 us against 57-67 us
+// for every other wave).  The wider instances spill under the cap (15-136 VGPRs: a measured loss) and keep their natural allocation.
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_step_w32(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset, int epw, int parity) {
+    step_block<0>(S, SPd, c, keys, use_spares, mc_offset, epw, parity);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2231,7 +2245,7 @@ void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const 
     // parity >= 0: stair isolation with the list the last render / observation pass wrote into set `parity`
     const int nb = (S->n + epw - 1) / epw;
     const dim3 grid(parity >= 0 ? STAIR_BLOCKS + nb : nb), block(WAVE);
-    if (c->width <= 32) hipLaunchKernelGGL(k_step<0>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
+    if (c->width <= 32) hipLaunchKernelGGL(k_step_w32, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
     else if (n32 && c->width <= 64) hipLaunchKernelGGL(k_step<1>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
     else if (n32) hipLaunchKernelGGL(k_step<2>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
     else if (c->width <= 128) hipLaunchKernelGGL(k_step<3>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);

@@ -13,6 +13,8 @@ def load(d, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        if k.startswith("k_step"):
+            k = "k_step"  # (k_step_w32 = the W <= 32 instance, capped at two waves per SIMD)
         acc[k][0] += float(r["Counter_Value"])
         seen[k].add(r["Dispatch_Id"])
     return {k: (v[0], len(seen[k])) for k, v in acc.items()}

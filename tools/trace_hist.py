@@ -5,6 +5,7 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 d = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    k = "k_step" if k.startswith("k_step") else k
     d[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 for k in ("k_step", "k_obs<0>", "k_regen"):
     if k not in d:
