@@ -2175,37 +2175,36 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
 // ---------------------------------------------------------------------------------------------
 #define STAIR_BLOCKS 256   // blocks at the front of the grid that serve the stair list (grid-stride beyond that)
 
-template <int BW>
-__device__ __forceinline__ void step_block(const RgState &S, const RgState *__restrict__ SPd, const RgConfig &c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset, int epw,
-                                           int parity) {
-    __builtin_amdgcn_s_setprio(3);  // issue-bound kernel: win VALU arbitration against the co-resident background k_regen waves
-    const int lane = threadIdx.x;
-    if (blockIdx.x == 0 && lane == 0) stair_recycle(S);
-    // this block's work: ONE call site of the turn code, whatever the role
-    const bool stair = parity >= 0 && (int)blockIdx.x < STAIR_BLOCKS;  // stair waves on: the first STAIR_BLOCKS blocks serve the stair set this launch reads
-    const int32_t *list = S.stair_list + (size_t)(S.stair_gen & 1) * S.n;
-    const int items = stair ? (int)S.stair_cnt[S.stair_gen % 3] : S.n;
-    const int first = stair ? (int)blockIdx.x : ((int)blockIdx.x - (parity >= 0 ? STAIR_BLOCKS : 0)) * epw;
-    // Stair block b looks at entry b of the list; entries beyond the first STAIR_BLOCKS are handed out one at a time through a counter, so that a
-    // block busy with a descent (60 us) never has a second one queued behind it while its neighbours sit idle.  An entry whose env does not press
-    // '>' stays with its index-order wave (step_wave's rule, applied here before anything else of the env is loaded: such a block is gone in ~2 us).
-    uint32_t *next = S.stair_cnt + 4 + S.stair_gen % 3;  // zeroed two producers ago (stair_recycle)
-    for (int i0 = first; i0 < items;) {
-        bool v; int e;
-        if (stair) { e = list[i0]; v = lane == 0 && e < S.n_keys && keys[e] == '>'; }
-        else { v = lane < epw && i0 + lane < items; e = v ? i0 + lane : 0; }
-        if (!stair || __any(v)) step_wave<BW>(S, SPd, c, keys, use_spares, mc_offset, e, v, parity >= 0 ? (stair ? 1 : 2) : 0);
-        if (!stair || items <= STAIR_BLOCKS) break;
-        __syncthreads();  // the next item reuses the wave's LDS
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(next, 1u);
-        i0 = STAIR_BLOCKS + (int)uni(t);
+// (the body is spelled out twice -- below for the capped W <= 32 instance -- rather than shared through a device function: routing the template through
+// one more inlined call changed the allocation of the wider instances for the worse, 141 -> 153 us on the default 80x24 dungeon)
+#define RG_STEP_BLOCK_BODY(BWV) \
+    __builtin_amdgcn_s_setprio(3); \
+    const int lane = threadIdx.x; \
+    if (blockIdx.x == 0 && lane == 0) stair_recycle(S); \
+    const bool stair = parity >= 0 && (int)blockIdx.x < STAIR_BLOCKS; \
+    const int32_t *list = S.stair_list + (size_t)(S.stair_gen & 1) * S.n; \
+    const int items = stair ? (int)S.stair_cnt[S.stair_gen % 3] : S.n; \
+    const int first = stair ? (int)blockIdx.x : ((int)blockIdx.x - (parity >= 0 ? STAIR_BLOCKS : 0)) * epw; \
+    uint32_t *next = S.stair_cnt + 4 + S.stair_gen % 3; \
+    for (int i0 = first; i0 < items;) { \
+        bool v; int e; \
+        if (stair) { e = list[i0]; v = lane == 0 && e < S.n_keys && keys[e] == '>'; } \
+        else { v = lane < epw && i0 + lane < items; e = v ? i0 + lane : 0; } \
+        if (!stair || __any(v)) step_wave<BWV>(S, SPd, c, keys, use_spares, mc_offset, e, v, parity >= 0 ? (stair ? 1 : 2) : 0); \
+        if (!stair || items <= STAIR_BLOCKS) break; \
+        __syncthreads(); \
+        uint32_t t = 0; \
+        if (lane == 0) t = atomicAdd(next, 1u); \
+        i0 = STAIR_BLOCKS + (int)uni(t); \
     }
-}
 template <int BW>
 __global__ void __launch_bounds__(WAVE) k_step(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset, int epw,
                                                int parity) {
-    step_block<BW>(S, SPd, c, keys, use_spares, mc_offset, epw, parity);
+    // this block's work: ONE call site of the turn code, whatever the role.  Stair block b looks at entry b of the stair list; entries beyond the first
+    // STAIR_BLOCKS are handed out one at a time through a counter, so that a block busy with a descent (60 us) never has a second one queued behind
+    // it while its neighbours sit idle.  An entry whose env does not press '>' stays with its index-order wave (step_wave's rule, applied here before
+    // anything else of the env is loaded: such a block is gone in ~2 us).
+    RG_STEP_BLOCK_BODY(BW)
 }
 // The W <= 32 instance with the register allocation capped for TWO waves per SIMD (256 VGPRs).  With the 5x5 window in LDS it needs ~250: told to,
 // the allocator fits it without a spill (left alone it lands on either side of the line from build to build).  Every block of a 65 536-env launch
@@ -2214,8 +2213,9 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, const RgState *__restr
 // for every other wave).  The wider instances spill under the cap (15-136 VGPRs: a measured loss) and keep their natural allocation.
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_step_w32(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset, int epw, int parity) {
-    step_block<0>(S, SPd, c, keys, use_spares, mc_offset, epw, parity);
+    RG_STEP_BLOCK_BODY(0)
 }
+#undef RG_STEP_BLOCK_BODY
 
 // ---------------------------------------------------------------------------------------------
 // host-callable launchers (used by rg_api.cpp)
