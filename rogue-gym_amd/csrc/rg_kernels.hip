@@ -132,7 +132,15 @@ struct Env {
     uint32_t *mc;       // k_step: this lane's column of the wave's LDS monster cache (word s at mc[s * WAVE]); write-through
     uint32_t err;       // RG_FLAG_ERR_INTERNAL if a capacity guard tripped (each guard carries its proof of unreachability)
     uint32_t on_stairs; // set by place_player: the player was put on the staircase of the level just generated
+    // generation: the room table of the level being generated, room i's rect / meta in LANE i of one VGPR each (<= 32 rooms <= 64 lanes).  The
+    // generator reads them ~60 times in its RNG-ordered chain (doors, corridors, gold, monsters, placement); from the LDS table each read was a
+    // round trip (ds_read, wait, readfirstlane: 100+ cycles), from here it is one v_readlane.  Written to the LDS table once, at the end.
+    uint32_t g_rect, g_meta;
 };
+__device__ __forceinline__ uint32_t gen_rect(const Env &E, int i) { return lane_get(E.g_rect, i); }
+__device__ __forceinline__ uint32_t gen_meta(const Env &E, int i) { return lane_get(E.g_meta, i); }
+__device__ __forceinline__ void gen_set_rect(Env &E, int i, uint32_t v) { E.g_rect = (int)threadIdx.x == i ? v : E.g_rect; }
+__device__ __forceinline__ void gen_set_meta(Env &E, int i, uint32_t v) { E.g_meta = (int)threadIdx.x == i ? v : E.g_meta; }
 
 // ---------------------------------------------------------------------------------------------
 // monsters table helpers
@@ -194,12 +202,12 @@ __device__ __forceinline__ void player_in_init(const RgState &S, const RgConfig 
     int W = c.width;
     int rid = room_id_of(c, x, y);
     if (rid >= 0) {
-        uint32_t meta = uni(S.room_meta[rid * E.n + E.e]);
+        uint32_t meta = gen_meta(E, rid);
         if (!(meta & RM_VISITED)) {  // Floor::enters_room (floor.rs:231-247)
-            S.room_meta[rid * E.n + E.e] = (uint8_t)(meta | RM_VISITED);
+            gen_set_meta(E, rid, meta | RM_VISITED);
             if ((meta & RM_KIND_MASK) == RK_NORMAL && !(meta & RM_DARK)) {
                 int x0, y0, x1, y1;
-                unpack_rect(uni(S.room_rect[rid * E.n + E.e]), x0, y0, x1, y1);
+                unpack_rect(gen_rect(E, rid), x0, y0, x1, y1);
                 const int rw = x1 - x0, area = rw * (y1 - y0);
                 for (int t = threadIdx.x; t < area; t += WAVE) {  // one cell per lane
                     const int yy = small_div(t, rw), xx = t - yy * rw;
@@ -267,11 +275,11 @@ __device__ __forceinline__ int rect_count(const RgConfig &c, const Env &E, int x
 // handful of filled cells" is ever observed during level creation, so the set is
 // implicit: interior cells (Normal) or C_MAZE cells (Maze) in row-major order, minus `excl`.
 __device__ __forceinline__ bool room_select(const RgState &S, const RgConfig &c, Env &E, int rid, uint32_t excl /* pos or ~0u */, uint32_t &out) {
-    uint32_t meta = uni(S.room_meta[rid * E.n + E.e]);
+    uint32_t meta = gen_meta(E, rid);
     int kind = meta & RM_KIND_MASK;
     if (kind == RK_EMPTY) return false;
     int x0, y0, x1, y1;
-    unpack_rect(uni(S.room_rect[rid * E.n + E.e]), x0, y0, x1, y1);
+    unpack_rect(gen_rect(E, rid), x0, y0, x1, y1);
     if (kind == RK_NORMAL) {
         int iw = x1 - x0 - 2, ih = y1 - y0 - 2;
         int count = iw * ih;
@@ -320,10 +328,10 @@ __device__ __forceinline__ uint32_t gen_attr_corridor(const RgConfig &c, Env &E,
 }
 // select_start_or_end (passages.rs:143-179).  dir: 0 Up 1 Down 2 Left 3 Right
 __device__ __forceinline__ uint32_t select_door(const RgState &S, const RgConfig &c, Env &E, int rid, int dir) {
-    uint32_t meta = uni(S.room_meta[rid * E.n + E.e]);
+    uint32_t meta = gen_meta(E, rid);
     int kind = meta & RM_KIND_MASK;
     int x0, y0, x1, y1;
-    unpack_rect(uni(S.room_rect[rid * E.n + E.e]), x0, y0, x1, y1);
+    unpack_rect(gen_rect(E, rid), x0, y0, x1, y1);
     if (kind == RK_EMPTY) return POS(x0, y0);
     if (kind == RK_NORMAL) {  // edges(range, dir, inclusive): the wall without its corners; SliceRandom::choose = 64-bit draw
         if (dir < 2) {
@@ -369,8 +377,8 @@ __device__ __forceinline__ void connect_rooms(const RgState &S, const RgConfig &
     if (dir == 0 || dir == 2) { int t = r1; r1 = r2; r2 = t; dir ^= 1; }
     uint32_t s = select_door(S, c, E, r1, dir);
     uint32_t t = select_door(S, c, E, r2, dir ^ 1);
-    int k1 = (uni(S.room_meta[r1 * E.n + E.e]) & RM_KIND_MASK) == RK_NORMAL;
-    int k2 = (uni(S.room_meta[r2 * E.n + E.e]) & RM_KIND_MASK) == RK_NORMAL;
+    int k1 = (gen_meta(E, r1) & RM_KIND_MASK) == RK_NORMAL;
+    int k2 = (gen_meta(E, r2) & RM_KIND_MASK) == RK_NORMAL;
     int bend;
     if (dir == 1) bend = (int)range32(E.rd, (uint32_t)(POS_Y(s) + 1), (uint32_t)POS_Y(t));
     else bend = (int)range32(E.rd, (uint32_t)(POS_X(s) + 1), (uint32_t)POS_X(t));
@@ -578,17 +586,17 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
                 meta = RK_NORMAL | (dark ? RM_DARK : 0);
             }
         }
-        S.room_rect[i * n + e] = rect;
-        S.room_meta[i * n + e] = meta;
+        gen_set_rect(E, i, rect);
+        gen_set_meta(E, i, meta);
     }
     pf.mark(9);
     // ---- paint rooms in id order (floor.rs:61-71; Room::draw rooms.rs:58-82) ----
     for (int i = 0; i < nrooms; i++) {
-        uint32_t meta = uni(S.room_meta[i * n + e]);
+        uint32_t meta = gen_meta(E, i);
         int kind = meta & RM_KIND_MASK;
         if (kind == RK_EMPTY) continue;
         int x0, y0, x1, y1;
-        unpack_rect(uni(S.room_rect[i * n + e]), x0, y0, x1, y1);
+        unpack_rect(gen_rect(E, i), x0, y0, x1, y1);
         if (kind == RK_NORMAL) {
             const uint16_t fl = (uint16_t)(S_FLOOR | ((meta & RM_DARK) ? C_DARK : 0));
             const int rw = x1 - x0, rh = y1 - y0, area = rw * rh;
@@ -657,7 +665,7 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
         uint32_t num = range32(E.ri, 0, c.gold_base + c.gold_per_level * level) + c.gold_minimum;
         S.gold_pos[i * n + e] = pos | 0x10000u;
         S.gold_amt[i * n + e] = num;
-        S.room_meta[i * n + e] |= RM_HAS_GOLD;
+        gen_set_meta(E, i, gen_meta(E, i) | RM_HAS_GOLD);
         cell[POS_Y(pos) * W + POS_X(pos)] |= C_GOLD;
     }
     pf.mark(13);
@@ -677,7 +685,7 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
         for (int i = 0; i < nrooms; i++) {
             uint32_t pos;
             if (!room_select(S, c, E, i, ~0u, pos)) continue;
-            bool has_gold = uni(S.room_meta[i * n + e]) & RM_HAS_GOLD;
+            bool has_gold = gen_meta(E, i) & RM_HAS_GOLD;
             if (!parcent(E.re, has_gold ? c.appear_rate_gold : c.appear_rate_nogold)) continue;
             uint32_t len = (uint32_t)c.n_enemies;
             uint32_t idx = range32(E.re, mn, mx);
@@ -802,12 +810,14 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
         L.gold_pos = T->gold_pos; L.gold_amt = T->gold_amt; L.edge_a = T->edge_a; L.edge_b = T->edge_b;
         L.maze_stack = S.maze_stack + (size_t)real_e * S.maze_cap;
         U.e = 0; U.n = 1;
+        U.g_rect = U.g_meta = 0;
         uint32_t non_empty = gen_level(L, c, U, pf);
         pf.mark(17);
         if (is_build) build_epilogue(L, c, U);
         place_player(L, c, U, non_empty);
         pf.mark(18);
         U.e = real_e; U.n = real_n;
+        if (lane < nrooms) { T->room_rect[lane] = U.g_rect; T->room_meta[lane] = (uint8_t)U.g_meta; }  // the room table, for the copy-out below
         if (lane == src) {
             env_to_lane(E, U); need = false;
             // k_step's LDS monster cache of the requesting lane: filled straight from the generator's table (the alternative -- reloading the column
@@ -2241,7 +2251,7 @@ void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const 
     static const int epw_env = getenv("ROGUE_GYM_HIP_EPW") ? atoi(getenv("ROGUE_GYM_HIP_EPW")) : 0;
     int epw = WAVE;
     while (epw > 16 && (S->n + epw - 1) / epw < 1024) epw >>= 1;
-    if (epw_env == 16 || epw_env == 32 || epw_env == 64) epw = epw_env;
+    if (epw_env >= 8 && epw_env <= 64) epw = epw_env;
     // parity >= 0: stair isolation with the list the last render / observation pass wrote into set `parity`
     const int nb = (S->n + epw - 1) / epw;
     const dim3 grid(parity >= 0 ? STAIR_BLOCKS + nb : nb), block(WAVE);
