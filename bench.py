@@ -356,7 +356,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic,
                          "frac_end_to_end": e2e / HBM_PEAK_GBPS, "achieved_end_to_end": e2e,
-                         "event_sampling": "every %d-th launch of each kernel bracketed by a HIP-event pair on the launch stream" % every,
+                         "event_sampling": "every %d-th launch of each kernel carries a HIP-event pair stamped with the dispatch's own begin / end (hipExtLaunchKernelGGL on the launch stream)" % every,
                          "note": "achieved = %d algorithmic B/env-step x %d envs / avg %s duration (the contract's definition: it charges the whole step's "
                                  "bytes to the dominant kernel); frac_end_to_end = the same bytes / ms_per_step; per_kernel has every kernel's own algorithmic share. "
                                  "k_step is instruction-issue / latency / divergence-bound, k_obs is the HBM-side kernel." % (hz.algo_bytes, n, dom),

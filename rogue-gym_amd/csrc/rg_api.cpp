@@ -16,7 +16,7 @@
 
 extern "C" {
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st);
-void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st);
+void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 void rgk_probe_clock(unsigned long long *out, int spin, hipStream_t st);
 void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st);
 void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st);
@@ -26,7 +26,7 @@ void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *statu
 void rgk_pack(const RgState *S, int with_hist, uint8_t *out, hipStream_t st);
 void rgk_scatter_rows(const void *src, void *dst, const int32_t *ext, int n, int row_bytes, hipStream_t st);
 void rgk_gather_keys(const uint8_t *keys, const int32_t *ext, uint8_t *dst, int n, hipStream_t st);
-int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, int planes_sym, hipStream_t st);
+int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, int planes_sym, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 }
 
 struct rg_handle {
@@ -74,15 +74,21 @@ struct rg_handle {
 };
 
 #define RG_TIMING_MAX 4096
-struct TimedLaunch {  // brackets one kernel launch with an event pair when timing is on
-    rg_handle *h; int k; bool on;
-    TimedLaunch(rg_handle *h_, int k_) : h(h_), k(k_), on(false) {
-        // sampled: an event pair costs a few us of stream time, so only every `timing_stride`-th launch of a kernel is bracketed
+struct TimedLaunch {  // times one kernel launch with an event pair when timing is on
+    // Two forms.  bracket(): hipEventRecord before and after the launch -- the pair then also contains the marker packets' own processing and the
+    // gap to the neighbouring kernels (~5-10 us around an 80 us kernel).  ext(): the pair is handed to hipExtLaunchKernelGGL, which stamps it with the
+    // dispatch's own begin / end -- the same clock rocprofv3 --kernel-trace reports; used for the two kernels of the step.
+    rg_handle *h; int k; bool on, ext_;
+    TimedLaunch(rg_handle *h_, int k_, bool ext = false) : h(h_), k(k_), on(false), ext_(ext) {
+        // sampled: an event pair costs a few us of stream time, so only every `timing_stride`-th launch of a kernel is timed
         if (h->timing && (h->timing_seq[k]++ % h->timing_stride) == 0 && h->ev_used[k] + 2 <= h->ev[k].size()) {
-            on = true; (void)hipEventRecord(h->ev[k][h->ev_used[k]], h->stream);
+            on = true;
+            if (!ext_) (void)hipEventRecord(h->ev[k][h->ev_used[k]], h->stream);
         }
     }
-    void stop() { if (on) { (void)hipEventRecord(h->ev[k][h->ev_used[k] + 1], h->stream); h->ev_used[k] += 2; on = false; } }
+    hipEvent_t start_ev() const { return on && ext_ ? h->ev[k][h->ev_used[k]] : nullptr; }
+    hipEvent_t stop_ev() const { return on && ext_ ? h->ev[k][h->ev_used[k] + 1] : nullptr; }
+    void stop() { if (on) { if (!ext_) (void)hipEventRecord(h->ev[k][h->ev_used[k] + 1], h->stream); h->ev_used[k] += 2; on = false; } }
     ~TimedLaunch() { stop(); }
 };
 
@@ -448,19 +454,29 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
         dk = h->d_keys;
     }
     h->S.n_keys = n_keys;
+    // The consumed spares are refilled on the side stream (k_regen), purely stream-ordered (the host runs far ahead of the GPU, so polling an event here
+    // would be meaningless).  Behind every SECOND step: a k_regen launch is 1024 one-wave blocks dispatched, at the side stream's priority, at the very
+    // moment k_step ends -- when the observation pass wants the chip -- and it cost the main stream ~7 us per step (143.4 us per step with a launch behind
+    // every step, 135.3 behind every second one, 145 / 151 behind every third / fourth: those launches carry so many generations that their waves
+    // serialise).  A spare is wanted one episode after it was consumed, so the extra step of latency changes nothing (inline generations per step:
+    // 23.4 either way).  The side stream waits for the k_step's own completion signal: the event is handed to the launch (hipExtLaunchKernelGGL's stop
+    // event) instead of being recorded behind it, which would be one more packet between k_step and the observation pass (~1.3 us per step).
+    static const int regen_every = getenv("ROGUE_GYM_HIP_REGEN_EVERY") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_EVERY")) : 2;  // (A/B knob)
+    static const bool marker_event = getenv("ROGUE_GYM_HIP_STEP_MARKER") != nullptr;                                       // (A/B knob: the recorded-event form)
+    h->step_count++;
+    const bool regen = h->spares && (regen_every <= 1 || h->step_count % (uint64_t)regen_every == 0);
+    hipEvent_t done_ev = nullptr;
     {   // stair isolation (rg_kernels.hip, k_step): on unless ROGUE_GYM_HIP_NO_STAIR_WAVES is set (the A/B knob of DESIGN.md's measurement)
         static const bool no_stair_waves = getenv("ROGUE_GYM_HIP_NO_STAIR_WAVES") != nullptr;
-        TimedLaunch t(h, 0);
+        TimedLaunch t(h, 0, true);
         h->S.stair_gen = h->stair_gen++;  // reads the stair set its predecessor produced, produces the next one
-        rgk_step(&h->S, h->d_SP, &h->cfg, dk, h->spares ? 1 : 0, no_stair_waves ? -1 : 0, h->stream);
+        done_ev = t.stop_ev() ? t.stop_ev() : ((regen && !marker_event) ? h->ev_step : nullptr);
+        rgk_step(&h->S, h->d_SP, &h->cfg, dk, h->spares ? 1 : 0, no_stair_waves ? -1 : 0, h->stream, t.start_ev(), done_ev);
     }
-    h->step_count++;
     HIPCHK(h, hipGetLastError());
-    if (h->spares) {
-        // refill the consumed spares behind this step on the side stream.  Purely stream-ordered (the host runs far ahead of
-        // the GPU, so polling an event here would be meaningless); a launch that finds nothing to do costs ~10 us, concurrently.
-        HIPCHK(h, hipEventRecord(h->ev_step, h->stream));
-        HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_step, 0));
+    if (regen) {
+        if (!done_ev) { HIPCHK(h, hipEventRecord(h->ev_step, h->stream)); done_ev = h->ev_step; }
+        HIPCHK(h, hipStreamWaitEvent(h->side, done_ev, 0));
         rgk_regen(&h->SP, &h->cfg, h->side);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipEventRecord(h->ev_regen, h->side));
@@ -519,8 +535,8 @@ static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, fl
         return 0;
     }
     {   // steady state: one fused pass refreshes the mirrors of Redraw envs and encodes every env
-        TimedLaunch t(h, 2);
-        if (rgk_obs(&h->S, &h->cfg, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->d_err, h->planes_sym, h->stream)) {
+        TimedLaunch t(h, 2, true);
+        if (rgk_obs(&h->S, &h->cfg, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->d_err, h->planes_sym, h->stream, t.start_ev(), t.stop_ev())) {
             HIPCHK(h, hipGetLastError());
             h->render_pending = false;
             return 0;

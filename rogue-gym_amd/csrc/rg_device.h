@@ -1,6 +1,7 @@
 // rg_device.h -- device helpers shared by the step kernels (rg_kernels.hip) and the render / observation kernels (rg_obs.hip)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdlib>
 

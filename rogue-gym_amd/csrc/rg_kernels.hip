@@ -2236,7 +2236,7 @@ void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
     size_t smem = GEN_SLOT_BYTES(hw);  // one level at a time per wave: one staging grid + the generator's tables
     hipLaunchKernelGGL(k_build, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), smem, st, *S, *c);
 }
-void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st) {
+void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw);  // the generator's staging grid + tables (inline descents, spare misses), shared with ...
     const bool n32 = c->width <= 96 && hw <= 4096;  // BFS rows as 32-bit words in registers (bfs_rows_n32): no LDS planes
@@ -2255,11 +2255,15 @@ void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const 
     // parity >= 0: stair isolation with the list the last render / observation pass wrote into set `parity`
     const int nb = (S->n + epw - 1) / epw;
     const dim3 grid(parity >= 0 ? STAIR_BLOCKS + nb : nb), block(WAVE);
-    if (c->width <= 32) hipLaunchKernelGGL(k_step_w32, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
-    else if (n32 && c->width <= 64) hipLaunchKernelGGL(k_step<1>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
-    else if (n32) hipLaunchKernelGGL(k_step<2>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
-    else if (c->width <= 128) hipLaunchKernelGGL(k_step<3>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
-    else hipLaunchKernelGGL(k_step<4>, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity);
+    // (ev0 / ev1: optional events stamped with this dispatch's own begin and end -- rg_timing; ev1 alone: the completion event k_regen's stream waits for)
+#define RG_LAUNCH_STEP(K) do { if (ev0 || ev1) hipExtLaunchKernelGGL(K, grid, block, (uint32_t)smem, st, ev0, ev1, 0, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity); \
+                               else hipLaunchKernelGGL(K, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity); } while (0)
+    if (c->width <= 32) RG_LAUNCH_STEP(k_step_w32);
+    else if (n32 && c->width <= 64) RG_LAUNCH_STEP(k_step<1>);
+    else if (n32) RG_LAUNCH_STEP(k_step<2>);
+    else if (c->width <= 128) RG_LAUNCH_STEP(k_step<3>);
+    else RG_LAUNCH_STEP(k_step<4>);
+#undef RG_LAUNCH_STEP
 }
 void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;

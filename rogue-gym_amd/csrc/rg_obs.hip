@@ -454,7 +454,7 @@ void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st) {
     hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RENDER_THREADS), 0, st, *S, *c);
 }
 // fused mirror refresh + encode; returns 0 if the geometry is not supported (caller falls back to k_render + encode)
-int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, int planes_sym, hipStream_t st) {
+int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, int planes_sym, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     int hw = c->width * c->height;
     if (hw & 7) return 0;
     int q8 = hw / 8;
@@ -466,10 +466,13 @@ int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, 
     // persistent grid: launching one tiny workgroup per env is dispatch-rate bound (65 536 one-wave blocks: 71 us; 16 384 looping blocks: 51 us)
     { const char *ev = getenv("RG_OBS_BLOCKS"); int cap = ev ? atoi(ev) : (bthreads <= 64 ? 16384 : 8192); if (blocks > cap) blocks = cap; }
     const bool groups = S->ext != nullptr;
-    if (!kind && !groups) hipLaunchKernelGGL((k_obs<0, false>), dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym);
-    else if (!kind) hipLaunchKernelGGL((k_obs<0, true>), dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym);
-    else if (!groups) hipLaunchKernelGGL((k_obs<1, false>), dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym);
-    else hipLaunchKernelGGL((k_obs<1, true>), dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym);
+#define RG_LAUNCH_OBS(...) do { if (ev0) hipExtLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(bthreads), (uint32_t)smem, st, ev0, ev1, 0, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym); \
+                               else hipLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym); } while (0)
+    if (!kind && !groups) RG_LAUNCH_OBS(k_obs<0, false>);
+    else if (!kind) RG_LAUNCH_OBS(k_obs<0, true>);
+    else if (!groups) RG_LAUNCH_OBS(k_obs<1, false>);
+    else RG_LAUNCH_OBS(k_obs<1, true>);
+#undef RG_LAUNCH_OBS
     return 1;
 }
 void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, size_t rs, size_t rst,

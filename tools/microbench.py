@@ -61,7 +61,8 @@ if __name__ == "__main__":
 
 PHASES = {0: "load", 26: "window load", 1: "pre-gen/post-loop", 2: "gen_service", 28: "player action", 29: "turn_passed", 30: "mon prepass", 3: "dist lookup",
           27: "fill+flush", 4: "bfs", 5: "monsters", 6: "tail", 7: "stores + spare take"}
-GEN_PHASES = {8: "g.clear", 9: "g.rooms", 10: "g.paint", 11: "g.passages", 12: "g.corridors", 13: "g.gold", 14: "g.stair", 15: "g.monsters", 16: "g.place+rest"}
+GEN_PHASES = {8: "g.clear", 9: "g.rooms", 10: "g.paint", 11: "g.passages", 12: "g.corridors", 13: "g.gold", 14: "g.stair", 15: "g.monsters", 17: "g.reveal", 18: "g.place",
+              19: "g.hand-back", 21: "g.barrier", 16: "g.copy-out", 23: "g.barrier2", 20: "g.total"}
 TICK_US = 1.0 / 2350.0  # s_memtime ticks at the shader clock (~2.35 GHz under this load; calibrated against the HIP-event kernel duration)
 
 
@@ -136,12 +137,6 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
             sel = (idx >= lo) & (idx < hi)
             if sel.any():
                 print("      %-12s start p50 %.1f max %.1f | end p50 %.1f p99 %.1f max %.1f" % (nm, np.percentile(s_us[sel], 50), s_us[sel].max(), np.percentile(e_us[sel], 50), np.percentile(e_us[sel], 99), e_us[sel].max()))
-        d_us = e_us - s_us
-        for nm, lo, hi in (("big index", 256, 256 + 1024 - int(os.environ.get("ROGUE_GYM_HIP_TAIL", "64"))), ("small index", 256 + 1024 - int(os.environ.get("ROGUE_GYM_HIP_TAIL", "64")), 1 << 30)):
-            sel = (idx >= lo) & (idx < hi)
-            if sel.any():
-                print("      %-12s n=%d duration p50 %.1f p90 %.1f max %.1f | start p50 %.1f p90 %.1f max %.1f | end p90 %.1f max %.1f" % (nm, sel.sum(), np.percentile(d_us[sel], 50), np.percentile(d_us[sel], 90), d_us[sel].max(),
-                      np.percentile(s_us[sel], 50), np.percentile(s_us[sel], 90), s_us[sel].max(), np.percentile(e_us[sel], 90), e_us[sel].max()))
         late = np.argsort(-e_us)[:5]
         print("      last to end: " + ", ".join("block %d start %.1f end %.1f" % (idx[i], s_us[i], e_us[i]) for i in late))
         # which phase makes the slowest waves slow: phase sums over the slowest 1 % of waves of the last launch
@@ -153,7 +148,7 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
         order = np.argsort(-buf[:, 63].astype(np.float64))[:int(os.environ.get('RG_SLOW_WAVES', '3'))]  # rows of the last launch
         for wv in order:  # the slowest waves of the last launch, record by record
             kk = int(buf[wv, 0])
-            recs = ["%s=%.1f" % (PHASES.get(int(r >> np.uint64(48)), str(int(r >> np.uint64(48)))), float(r & np.uint64((1 << 48) - 1)) * TICK_US) for r in buf[wv, 1:1 + kk]]
+            recs = ["%s=%.1f" % (PHASES.get(int(r >> np.uint64(48)), GEN_PHASES.get(int(r >> np.uint64(48)), str(int(r >> np.uint64(48))))), float(r & np.uint64((1 << 48) - 1)) * TICK_US) for r in buf[wv, 1:1 + kk]]
             print("   slow wave %d: total %.1f us: %s" % (wv, float(buf[wv, 63]) * TICK_US, " ".join(recs)))
     h.close()
 
