@@ -37,7 +37,7 @@ struct rg_handle {
     bool spares = false;
     uint64_t step_count = 0;
     hipStream_t side = nullptr;  // stream of the background generator (high priority: a low-priority queue starves behind the back-to-back step kernels)
-    hipEvent_t ev_step = nullptr, ev_regen = nullptr;
+    hipEvent_t ev_step = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
@@ -219,7 +219,7 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
         P.prof = nullptr;
         int lo = 0, hi = 0;
         if (ok && (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, getenv("ROGUE_GYM_HIP_SIDE_LOWPRIO") ? lo : hi) != hipSuccess ||
-                   hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_regen, hipEventDisableTiming) != hipSuccess)) {
+                   hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming) != hipSuccess)) {
             h->err = "failed to create the background generation stream"; ok = false;
         }
     }
@@ -238,7 +238,6 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
         // first spares.  rg_create waits for them: left in the background, this one-off generation of EVERY env's spare (~2 ms at 65 536 envs)
         // competes with the first few hundred steps for issue slots (the driver's 20-step bench ran k_step at 141 us instead of ~100 us).
         rgk_regen(&h->SP, &h->cfg, h->side);
-        (void)hipEventRecord(h->ev_regen, h->side);
         e = hipGetLastError();
         if (e == hipSuccess && !getenv("ROGUE_GYM_HIP_ASYNC_FIRST_SPARES")) e = hipStreamSynchronize(h->side);  // (knob: the round-1 behaviour, for A/B evidence)
         if (e != hipSuccess) { g_create_err = std::string("k_regen: ") + hipGetErrorString(e); free_all(h); delete h; return 1; }
@@ -357,7 +356,6 @@ static void destroy_handle(rg_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->ev_step) (void)hipEventDestroy(h->ev_step);
-    if (h->ev_regen) (void)hipEventDestroy(h->ev_regen);
     for (int k = 0; k < 4; k++) for (auto &e : h->ev[k]) (void)hipEventDestroy(e);
     if (h->obs_scratch) (void)hipFree(h->obs_scratch);
     free_all(h);
@@ -460,7 +458,9 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
     // every step, 135.3 behind every second one, 145 / 151 behind every third / fourth: those launches carry so many generations that their waves
     // serialise).  A spare is wanted one episode after it was consumed, so the extra step of latency changes nothing (inline generations per step:
     // 23.4 either way).  The side stream waits for the k_step's own completion signal: the event is handed to the launch (hipExtLaunchKernelGGL's stop
-    // event) instead of being recorded behind it, which would be one more packet between k_step and the observation pass (~1.3 us per step).
+    // event) instead of being recorded behind it, which would be one more packet between k_step and the observation pass (~1.3 us per step).  (Measured and
+    // not kept: no dependency at all -- a free-running k_regen is 1 % faster on the mini workload and starves the spares of the default one; and an event
+    // recorded on the side stream behind every k_regen, which nothing waited for, cost the step another 4 us.)
     static const int regen_every = getenv("ROGUE_GYM_HIP_REGEN_EVERY") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_EVERY")) : 2;  // (A/B knob)
     static const bool marker_event = getenv("ROGUE_GYM_HIP_STEP_MARKER") != nullptr;                                       // (A/B knob: the recorded-event form)
     h->step_count++;
@@ -479,7 +479,6 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
         HIPCHK(h, hipStreamWaitEvent(h->side, done_ev, 0));
         rgk_regen(&h->SP, &h->cfg, h->side);
         HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipEventRecord(h->ev_regen, h->side));
     }
     h->render_pending = true;
     return 0;
