@@ -36,8 +36,9 @@ struct rg_handle {
     RgState SP;                  // spare view: core pointers address the pre-generated next level-1 state (k_regen)
     bool spares = false;
     uint64_t step_count = 0;
-    hipStream_t side = nullptr;  // stream of the background generator (high priority: a low-priority queue starves behind the back-to-back step kernels)
+    hipStream_t side = nullptr;  // stream of the background generator (LOW priority: the step kernel's blocks are placed first, k_regen takes what is left; rg_step_prefix)
     hipEvent_t ev_step = nullptr;
+    bool regen_pending = false;  // a k_regen launch is due and hangs behind the next observation pass (rg_step_prefix)
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
@@ -218,7 +219,7 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
              dev_alloc(h, &P.on_stairs, n);
         P.prof = nullptr;
         int lo = 0, hi = 0;
-        if (ok && (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, getenv("ROGUE_GYM_HIP_SIDE_LOWPRIO") ? lo : hi) != hipSuccess ||
+        if (ok && (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, getenv("ROGUE_GYM_HIP_SIDE_HIPRIO") ? hi : lo) != hipSuccess ||
                    hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming) != hipSuccess)) {
             h->err = "failed to create the background generation stream"; ok = false;
         }
@@ -453,18 +454,29 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
     }
     h->S.n_keys = n_keys;
     // The consumed spares are refilled on the side stream (k_regen), purely stream-ordered (the host runs far ahead of the GPU, so polling an event here
-    // would be meaningless).  Behind every SECOND step: a k_regen launch is 1024 one-wave blocks dispatched, at the side stream's priority, at the very
-    // moment k_step ends -- when the observation pass wants the chip -- and it cost the main stream ~7 us per step (143.4 us per step with a launch behind
-    // every step, 135.3 behind every second one, 145 / 151 behind every third / fourth: those launches carry so many generations that their waves
-    // serialise).  A spare is wanted one episode after it was consumed, so the extra step of latency changes nothing (inline generations per step:
-    // 23.4 either way).  The side stream waits for the k_step's own completion signal: the event is handed to the launch (hipExtLaunchKernelGGL's stop
-    // event) instead of being recorded behind it, which would be one more packet between k_step and the observation pass (~1.3 us per step).  (Measured and
-    // not kept: no dependency at all -- a free-running k_regen is 1 % faster on the mini workload and starves the spares of the default one; and an event
-    // recorded on the side stream behind every k_regen, which nothing waited for, cost the step another 4 us.)
+    // would be meaningless).  WHERE that work lands decides what it costs: ~335 level generations per 65 536-env step are ~10 000 wave-us, and beside the
+    // observation pass (a bandwidth kernel that lives on 7 waves per SIMD) or as a high-priority burst between the two kernels they cost the step
+    // 10-28 us; beside k_step -- latency-bound, a third of the chip's register file idle -- about 7.  So: a launch is due behind every SECOND step (a
+    // launch costs the main stream a few us whatever it finds; behind every third / fourth step its waves carry so many generations that they
+    // serialise and spares run out), it is hung behind the NEXT OBSERVATION PASS (the side stream waits for that kernel's own completion signal, handed
+    // to the launch as hipExtLaunchKernelGGL's stop event -- an event recorded behind it would be one more packet on the main stream), so it starts
+    // with the following k_step; the side stream has LOW priority, so the step kernel's blocks are placed first; and a k_regen wave looks at 8 envs, not
+    // 64 (rgk_regen), so nearly every wave generates at most one level and the launch is over in one generation time instead of 270 us.  Per step, same
+    // box: 143.4 us (every step, behind k_step, high priority, 64 envs per wave) -> 135.3 (every second) -> 125.8 (all four); k_obs 54 -> 46 us,
+    // k_step 77 -> 75 us, inline generations (spare not ready) 1.3 -> 0.3 per step.  A spare is wanted one episode after it was consumed, so the
+    // latency added here is free.  If no observation pass follows a step, the launch goes behind the next step instead.  (Measured and not kept: no stream
+    // dependency at all -- 1 % faster on the mini workload, starves the spares of the default one; an event recorded on the side stream behind every
+    // k_regen, which nothing waited for: +4 us per launch.)
     static const int regen_every = getenv("ROGUE_GYM_HIP_REGEN_EVERY") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_EVERY")) : 2;  // (A/B knob)
     static const bool marker_event = getenv("ROGUE_GYM_HIP_STEP_MARKER") != nullptr;                                       // (A/B knob: the recorded-event form)
     h->step_count++;
-    const bool regen = h->spares && (regen_every <= 1 || h->step_count % (uint64_t)regen_every == 0);
+    static const bool after_obs = getenv("ROGUE_GYM_HIP_REGEN_AFTER_STEP") == nullptr;  // (A/B knob: the launch behind k_step itself)
+    bool regen = h->spares && (regen_every <= 1 || h->step_count % (uint64_t)regen_every == 0);
+    if (after_obs && h->spares) {
+        const bool overdue = h->regen_pending;  // no observation pass since it became due: launch it behind this step after all
+        h->regen_pending = regen && !overdue;
+        regen = overdue;
+    }
     hipEvent_t done_ev = nullptr;
     {   // stair isolation (rg_kernels.hip, k_step): on unless ROGUE_GYM_HIP_NO_STAIR_WAVES is set (the A/B knob of DESIGN.md's measurement)
         static const bool no_stair_waves = getenv("ROGUE_GYM_HIP_NO_STAIR_WAVES") != nullptr;
@@ -535,8 +547,15 @@ static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, fl
     }
     {   // steady state: one fused pass refreshes the mirrors of Redraw envs and encodes every env
         TimedLaunch t(h, 2, true);
-        if (rgk_obs(&h->S, &h->cfg, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->d_err, h->planes_sym, h->stream, t.start_ev(), t.stop_ev())) {
+        hipEvent_t done_ev = t.stop_ev() ? t.stop_ev() : (h->regen_pending ? h->ev_step : nullptr);
+        if (rgk_obs(&h->S, &h->cfg, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->d_err, h->planes_sym, h->stream, t.start_ev(), done_ev)) {
             HIPCHK(h, hipGetLastError());
+            if (h->regen_pending) {  // the due k_regen starts when this pass ends, i.e. beside the next k_step
+                h->regen_pending = false;
+                HIPCHK(h, hipStreamWaitEvent(h->side, done_ev, 0));
+                rgk_regen(&h->SP, &h->cfg, h->side);
+                HIPCHK(h, hipGetLastError());
+            }
             h->render_pending = false;
             return 0;
         }

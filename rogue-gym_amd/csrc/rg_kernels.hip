@@ -983,10 +983,10 @@ __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
 // one generation per consumed spare, overlapped with the following steps; k_step's reset then is a copy.
 // SP is an RgState whose core pointers address the spare arrays.  Hand-off per env through sp_ready with
 // agent-scope release/acquire (the consumer kernel runs concurrently on another stream).
-__global__ void __launch_bounds__(WAVE) k_regen(RgState SP, RgConfig c) {
+__global__ void __launch_bounds__(WAVE) k_regen(RgState SP, RgConfig c, int epb) {
     const int lane = threadIdx.x;
-    const int e = blockIdx.x * WAVE + lane;
-    const bool valid = e < SP.n;
+    const int e = blockIdx.x * epb + lane;
+    const bool valid = lane < epb && e < SP.n;
     bool claim = false;
     if (valid && __hip_atomic_load(&SP.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
         claim = atomicCAS(&SP.sp_ready[e], 0u, 2u) == 0u;
@@ -2272,6 +2272,11 @@ void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st) {
 void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw);
-    hipLaunchKernelGGL(k_regen, dim3((SP->n + WAVE - 1) / WAVE), dim3(WAVE), smem, st, *SP, *c);
+    // envs per wave: a wave generates its claimed spares one after the other, so with 64 envs per wave the launch lasts as long as its unluckiest wave
+    // (4-6 claims: 270 us, the next launch queued behind it) and its waves sit beside two or three launches of the step kernels.  8 envs per wave: 0.08
+    // claims per wave, the launch is over in about one generation time, and the 8192 blocks that find nothing are gone at once.  (A/B knob.)
+    static const int epb_env = getenv("ROGUE_GYM_HIP_REGEN_EPB") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_EPB")) : 0;
+    const int epb = (epb_env >= 4 && epb_env <= WAVE) ? epb_env : 8;
+    hipLaunchKernelGGL(k_regen, dim3((SP->n + epb - 1) / epb), dim3(WAVE), smem, st, *SP, *c, epb);
 }
 }
