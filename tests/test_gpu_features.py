@@ -436,3 +436,22 @@ def test_index_order_mapping_without_stair_waves_is_bit_exact(goldens):
                         "lockstep_random_policy or lockstep_run_keys or stair_seekers_with or frequent_descents or inline_generation"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("knobs", [
+    {"ROGUE_GYM_HIP_REGEN_EVERY": "1", "ROGUE_GYM_HIP_REGEN_AFTER_STEP": "1", "ROGUE_GYM_HIP_SIDE_HIPRIO": "1", "ROGUE_GYM_HIP_REGEN_EPB": "64", "ROGUE_GYM_HIP_STEP_MARKER": "1"},
+    {"ROGUE_GYM_HIP_REGEN_EVERY": "4", "ROGUE_GYM_HIP_REGEN_EPB": "4", "ROGUE_GYM_HIP_EPW": "24"},
+], ids=["round-2-start scheduling", "sparse generator launches, 24 envs per step wave"])
+def test_results_do_not_depend_on_where_the_background_generator_runs(knobs):
+    """When and where the spare levels are regenerated (behind which kernel, how often, at which priority, how many envs per generator wave) and how many
+    envs a step wave holds decide only whether an auto-reset finds its spare or generates inline -- never what the env looks like afterwards: the
+    lock-step parity tests again, in processes with the scheduling knobs turned the other way."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, **knobs)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "lockstep_random_policy or frequent_descents or inline_generation or full_size_invariants"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in r.stdout
