@@ -1,0 +1,62 @@
+"""The register / scratch budget of the built kernels, read from the code objects inside librogue_gym_hip.so (no GPU needed: hipcc cross-compiles).
+
+Two of the stepper's performance properties are decided by the compiler's register allocation and are easy to lose without noticing: the W <= 32 step
+kernel must fit 256 registers (two waves per SIMD: every block of a 65 536-env launch resident from t = 0), and the observation
+kernel must stay at 72 (seven waves per SIMD: 27 more cost it 17 us).  No kernel may use scratch memory."""
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "rogue-gym_amd", "librogue_gym_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def kernel_metadata():
+    tools = [os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not os.path.exists(SO) or not all(os.path.exists(t) for t in tools):
+        pytest.skip("library or LLVM tools not available")
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.run([tools[0], "-O", "binary", "--only-section=.hip_fatbin", SO, fat], check=True)
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+        assert starts, "no offload bundle in the library"
+        for i, s in enumerate(starts):  # one bundle per translation unit
+            part = os.path.join(d, "b%d.bin" % i)
+            open(part, "wb").write(blob[s:(starts[i + 1] if i + 1 < len(starts) else len(blob))])
+            co = os.path.join(d, "b%d.co" % i)
+            subprocess.run([tools[1], "--unbundle", "--type=o", "--input=" + part, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            notes = subprocess.run([tools[2], "--notes", co], check=True, capture_output=True, text=True).stdout
+            for blk in notes.split("- .agpr_count:")[1:]:
+                blk = ".agpr_count:" + blk
+                f = {k: v for k, v in re.findall(r"\.(agpr_count|vgpr_count|sgpr_spill_count|vgpr_spill_count|private_segment_fixed_size|name):\s+(\S+)", blk)}
+                if "name" in f:
+                    out[f["name"]] = {k: int(v) for k, v in f.items() if k != "name"}
+    return out
+
+
+def test_register_and_scratch_budget_of_the_built_kernels():
+    md = kernel_metadata()
+    step32 = [k for k in md if "k_step_w32" in k]
+    assert step32, sorted(md)
+    for k in step32:
+        m = md[k]
+        assert m["vgpr_count"] <= 256 and m["agpr_count"] == 0, (k, m)   # (.vgpr_count is the unified total) two step waves per SIMD
+        assert m["vgpr_spill_count"] == 0, (k, m)
+    obs = [k for k in md if re.search(r"k_obsILi0ELb0E", k)]       # k_obs<gray, no config groups>: the kernel of the headline workload
+    assert obs, sorted(md)
+    for k in obs:
+        assert md[k]["vgpr_count"] <= 72 and md[k]["agpr_count"] == 0, (k, md[k])  # seven waves per SIMD
+    regen = [k for k in md if "k_regen" in k]
+    assert regen, sorted(md)
+    for k in regen:
+        assert md[k]["vgpr_count"] <= 128, (k, md[k])              # two generator waves beside a step wave on a SIMD (248 + 2 x 96 <= 512)
+    for k, m in md.items():
+        assert m["private_segment_fixed_size"] == 0, ("scratch memory in", k, m)
