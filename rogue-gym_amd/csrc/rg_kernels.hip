@@ -693,9 +693,19 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
             if (idx >= len) continue;
             uint32_t type = idx;
             int64_t mlevel = (int64_t)c.mon[type].level + lev_add, hp = 0;
-            for (int k = 0; k < 8; k++) hp += (int64_t)range64(E.re, 1, (uint64_t)mlevel + 1);
-            int64_t base = mlevel == 1 ? hp / 8 : hp / 6;
-            uint32_t exp_add = mlevel >= 10 ? (uint32_t)base * 20u : (uint32_t)base * 4u;
+            uint32_t exp_add;
+            if (mlevel >= 1 && mlevel < (1 << 24)) {  // every real table: the eight rolls sum to < 2^27, so 32-bit adds and a 32-bit divide (the i64 `/ 6` alone is ~40 instructions)
+                const uint32_t ml = (uint32_t)mlevel;
+                uint32_t h32 = 0;
+                for (int k = 0; k < 8; k++) h32 += (uint32_t)range64(E.re, 1, (uint64_t)ml + 1);
+                const uint32_t base = ml == 1 ? h32 / 8u : h32 / 6u;
+                exp_add = ml >= 10 ? base * 20u : base * 4u;
+                hp = h32;
+            } else {
+                for (int k = 0; k < 8; k++) hp += (int64_t)range64(E.re, 1, (uint64_t)mlevel + 1);
+                int64_t base = mlevel == 1 ? hp / 8 : hp / 6;
+                exp_add = mlevel >= 10 ? (uint32_t)base * 20u : (uint32_t)base * 4u;
+            }
             S.mon_w0[i * n + e] = pos | (type << 16) | ((uint32_t)MF_ALIVE << 24);
             S.mon_hp[i * n + e] = (int32_t)hp;
             S.mon_exp[i * n + e] = c.mon[type].exp + lev_add * 10u + exp_add;
