@@ -136,6 +136,7 @@ struct Env {
     // generator reads them ~60 times in its RNG-ordered chain (doors, corridors, gold, monsters, placement); from the LDS table each read was a
     // round trip (ds_read, wait, readfirstlane: 100+ cycles), from here it is one v_readlane.  Written to the LDS table once, at the end.
     uint32_t g_rect, g_meta;
+    uint32_t g_ea, g_eb;  // ... and the corridor records (edge k in lane k, <= RG_MAX_EDGES = 64), replayed for the deferred gen_attr draws
 };
 __device__ __forceinline__ uint32_t gen_rect(const Env &E, int i) { return lane_get(E.g_rect, i); }
 __device__ __forceinline__ uint32_t gen_meta(const Env &E, int i) { return lane_get(E.g_meta, i); }
@@ -383,8 +384,9 @@ __device__ __forceinline__ void connect_rooms(const RgState &S, const RgConfig &
     if (dir == 1) bend = (int)range32(E.rd, (uint32_t)(POS_Y(s) + 1), (uint32_t)POS_Y(t));
     else bend = (int)range32(E.rd, (uint32_t)(POS_X(s) + 1), (uint32_t)POS_X(t));
     if (n_edges < RG_MAX_EDGES) {  // always: RG_MAX_EDGES >= the number of grid-adjacent room pairs (rg_state.h)
-        S.edge_a[n_edges * E.n + E.e] = s | (t << 16);
-        S.edge_b[n_edges * E.n + E.e] = (uint32_t)bend | ((uint32_t)(dir == 1) << 8) | ((uint32_t)k1 << 9) | ((uint32_t)k2 << 10);
+        const uint32_t ea = s | (t << 16), eb = (uint32_t)bend | ((uint32_t)(dir == 1) << 8) | ((uint32_t)k1 << 9) | ((uint32_t)k2 << 10);
+        E.g_ea = (int)threadIdx.x == n_edges ? ea : E.g_ea;
+        E.g_eb = (int)threadIdx.x == n_edges ? eb : E.g_eb;
         n_edges++;
     } else E.err |= RG_FLAG_ERR_INTERNAL;
 }
@@ -653,7 +655,7 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
         }
     }
     pf.mark(11);
-    for (int k = 0; k < n_edges; k++) paint_corridor(c, E, uni(S.edge_a[k * n + e]), uni(S.edge_b[k * n + e]), level);
+    for (int k = 0; k < n_edges; k++) paint_corridor(c, E, lane_get(E.g_ea, k), lane_get(E.g_eb, k), level);
 
     const uint32_t non_empty = (nrooms >= 32 ? 0xffffffffu : ((1u << nrooms) - 1u)) & ~empty_mask;
     pf.mark(12);
@@ -820,7 +822,7 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
         L.gold_pos = T->gold_pos; L.gold_amt = T->gold_amt; L.edge_a = T->edge_a; L.edge_b = T->edge_b;
         L.maze_stack = S.maze_stack + (size_t)real_e * S.maze_cap;
         U.e = 0; U.n = 1;
-        U.g_rect = U.g_meta = 0;
+        U.g_rect = U.g_meta = U.g_ea = U.g_eb = 0;
         uint32_t non_empty = gen_level(L, c, U, pf);
         pf.mark(17);
         if (is_build) build_epilogue(L, c, U);
