@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- env-steps/s of the batched HIP Rogue-Gym stepper (BASELINE.json's metric).
 
-  python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts its own N ranks, one per GPU, RCCL)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (ranks from the launcher's environment)
 
 A "step" is one lock-step pass of the hot path over every env of this rank: action fetch ->
 k_step (player turn, monster AI, combat, FoV, descents, auto-reset) -> k_obs (mirror refresh fused with the
@@ -101,7 +101,7 @@ def cpu_baseline(cfg, desc, budget_s=10.0):
 class Harness:
     """One workload on this rank: env batch + pre-generated action tensor."""
 
-    def __init__(self, torch, workload, n, rank, local_rank, need_steps):
+    def __init__(self, torch, workload, n, rank, local_rank):
         from rogue_gym.envs import DungeonType, HipVecRogueEnv, ImageSetting, StatusFlag
 
         cfg_name, n_default, obs_kind, self.algo_bytes, (self.step_bytes, self.obs_bytes), self.desc = WORKLOADS[workload]
@@ -121,7 +121,6 @@ class Harness:
         rows = 512
         actions = torch.randint(0, 11, (rows, self.n), generator=gen, device=dev, dtype=torch.uint8)
         self.keys_all = self.env._action_keys[actions.long()].contiguous()
-        _ = need_steps
         self.t = 0
 
     def step(self):
@@ -173,6 +172,33 @@ def copy_peak(torch, dev):
     return 2.0 * n * reps / (ms * 1e-3) / 1e9
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (the reference's executor owns its workers too,
+    python/src/thread_impls.rs:14-34) -- one process per GPU, rendezvous on 127.0.0.1, RCCL.  Rank 0 inherits stdout and prints the one
+    JSON line; the exit code is the worst of the ranks'."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    finally:
+        for p in procs:  # one rank died: do not leave the others blocked in a collective
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +217,10 @@ def main():
                     "the background generator runs beside every second k_step, an even stride would sample one kind only")
     ap.add_argument("--gather-steps", type=int, default=50, help="extra steps timed WITH the observation all-gather (N>1)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -203,6 +233,9 @@ def main():
     one_device = os.environ.get("ROGUE_GYM_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local_rank = 0
+    elif torch.cuda.device_count() < min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+        sys.exit("bench.py: %d ranks on this node but only %d GPU(s) visible (one rank per GPU; ROGUE_GYM_BENCH_ONE_DEVICE=1 is the 1-GPU development mode)"
+                 % (world, torch.cuda.device_count()))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -225,7 +258,7 @@ def main():
     # ---- disclosed clock-warm phase on a scratch batch (never the measured one) ----
     clock_warm = None
     if args.clock_warm_s > 0:
-        scratch = Harness(torch, "mini", 16384, rank, local_rank, 64)
+        scratch = Harness(torch, "mini", 16384, rank, local_rank)
         mhz0 = scratch.sclk()
         t0, warm_steps = time.perf_counter(), 0
         while time.perf_counter() - t0 < args.clock_warm_s:
@@ -239,7 +272,7 @@ def main():
         scratch.close()
         del scratch
 
-    hz = Harness(torch, args.workload, args.envs_per_gpu, rank, local_rank, K + W)
+    hz = Harness(torch, args.workload, args.envs_per_gpu, rank, local_rank)
     n, env = hz.n, hz.env
     preroll = None
     if args.preroll_steps > 0:
@@ -302,22 +335,60 @@ def main():
         repeats = {"ms_per_step": runs, "median_ms_per_step": med, "median_value": n * world / (med * 1e-3),
                    "note": "run 0 is the timed region `value` is computed from; runs 1-4 repeat it without HIP-event bracketing"}
 
-    # optional: the north-star's observation all-gather (ONE collective of the packed compact records, expanded by HIP kernels on the consumer)
+    # optional: the north-star's observation all-gather (ONE collective of the packed compact records, expanded by HIP kernels on the consumer).
+    # Two legs: through torch.distributed (all_gather_into_tensor, backend nccl = RCCL) and through the C-ABI's own communicator
+    # (rg_comm_init / rg_allgather_compact: pack into the rank's slice + ncclAllGather in place on the handle's stream).  Neither can take the
+    # headline down: each leg runs under a watchdog (a collective that never completes cannot be caught as an exception), and a failure is
+    # reported inside "allgather" instead of being raised.
     gather = None
     if world > 1 and args.gather_steps > 0:
-        for _ in range(5):
-            hz.step(); env.all_gather_obs(compact=True)
-        barrier()
-        g0 = time.perf_counter()
-        for _ in range(args.gather_steps):
-            hz.step(); env.all_gather_obs(compact=True)
-        barrier()
-        gdt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=dev)
-        dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
+        import threading
+
         rec = env._h.L.rg_compact_record_bytes(env._h.h, 0)
-        gather = {"value": n * world * args.gather_steps / float(gdt.item()), "unit": "env-steps/s",
-                  "payload": "one all-gather per step of %d-byte records (u8 screen [%d,%d] + i32 status [10]) = %.1f MB per rank, expanded to f32 [N,%d,%d,%d] "
-                             "on every rank by rg_expand_compact" % (rec, env.height, env.width, rec * n / 1e6, env.channels, env.height, env.width)}
+        payload = ("one all-gather per step of %d-byte records (u8 screen [%d,%d] + i32 status [10]) = %.1f MB per rank, expanded to f32 [N,%d,%d,%d] "
+                   "on every rank by rg_expand_compact" % (rec, env.height, env.width, rec * n / 1e6, env.channels, env.height, env.width))
+        gather = {"unit": "env-steps/s", "payload": payload}
+
+        def leg(name):
+            for _ in range(5):
+                hz.step(); env.all_gather_obs(compact=True)
+            barrier()
+            g0 = time.perf_counter()
+            for _ in range(args.gather_steps):
+                hz.step(); env.all_gather_obs(compact=True)
+            barrier()
+            gdt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=dev)
+            dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
+            gather[name] = n * world * args.gather_steps / float(gdt.item())
+
+        def guarded(name, fn, limit_s=120.0):
+            done = threading.Event()
+
+            def bail():  # the leg hangs: rank 0 still owes the driver its one JSON line
+                if not done.is_set():
+                    gather[name + "_error"] = "no completion within %.0f s" % limit_s
+                    if rank == 0 and emit_line is not None:
+                        emit_line()
+                    os._exit(0)
+
+            t = threading.Timer(limit_s, bail)
+            t.daemon = True
+            t.start()
+            try:
+                fn()
+            except Exception as e:  # noqa: BLE001
+                gather[name + "_error"] = "%s: %s" % (type(e).__name__, e)
+            done.set()
+            t.cancel()
+
+        gather_legs = [("value", lambda: leg("value"))]   # torch.distributed
+        if not one_device:  # two ranks cannot share one GPU under RCCL: the C-ABI communicator needs one device per rank
+            def cabi():
+                env.init_comm()
+                leg("value_cabi")
+            gather_legs.append(("value_cabi", cabi))
+    else:
+        gather_legs = []
 
     out = None
     if rank == 0:
@@ -325,15 +396,15 @@ def main():
         dom_s = per_kernel[dom]["avg_us"] * 1e-6 if per_kernel else dt_max / K
         achieved = hz.algo_bytes * n / dom_s / 1e9
         e2e = hz.algo_bytes * n / (dt_max / K) / 1e9
-        traffic, traffic_all = None, None
+        traffic, traffic_all, traffic_src = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from rocprofv3 --pmc passes (see profiles/README.md)
         if os.path.exists(pmc) and args.workload == "mini" and n == 65536:  # the PMC passes ran on 65 536 envs per launch
             with open(pmc) as f:
                 pj = json.load(f)
             traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
+            traffic_src = pj.get("_measured", "profiles/pmc_traffic.json (rocprofv3 --pmc passes; build not stamped)")
             traffic_all = {k: {"hbm_bytes_per_launch": v.get("hbm_bytes_per_launch"), "hbm_bytes_per_env_step": (v.get("hbm_bytes_per_launch") or 0) / 65536.0}
                            for k, v in pj.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
-        rate = K * world / dt_max  # batch steps per second over the whole job... per-rank counters are rank 0's: scale by world
         out = {
             "metric": "env-steps/sec (whole node) at 65 536 envs, 32x16 mini-dungeon" if args.workload == "mini" and n == 65536
                       else "env-steps/sec (whole node), workload %s, %d envs per GPU" % (args.workload, n),
@@ -343,6 +414,9 @@ def main():
             "steps": K,
             "warmup": W,
             "ms_per_step": dt_max / K * 1e3,
+            "value_is": "steady-state episode mix: EXACTLY `steps` timed steps after a disclosed pre-roll of the measured batch (`preroll`) + `warmup` steps",
+            "value_cold_start": preroll["cold_start"]["value"] if preroll else None,   # the first `steps` steps after creation, no warm-up at all
+            "value_median_of_repeats": repeats["median_value"] if repeats else None,   # 5 runs of `steps` steps; runs 1-4 without HIP-event pairs
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -355,7 +429,7 @@ def main():
             "preroll": preroll,
             "sclk_mhz_after_timed_region": sclk_after,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "frac_end_to_end": e2e / HBM_PEAK_GBPS, "achieved_end_to_end": e2e,
                          "event_sampling": "every %d-th launch of each kernel carries a HIP-event pair stamped with the dispatch's own begin / end (hipExtLaunchKernelGGL on the launch stream)" % every,
                          "note": "achieved = %d algorithmic B/env-step x %d envs / avg %s duration (the contract's definition: it charges the whole step's "
@@ -366,11 +440,17 @@ def main():
                                **{k + "_per_s": v * world / dt_max for k, v in counts.items()},
                                "per_batch_step": {k: v / K for k, v in counts.items()}},
         }
-        _ = rate
         if repeats:
             out["repeats"] = repeats
-        if gather:
-            out["allgather"] = gather
+        if gather is not None:
+            out["allgather"] = gather  # filled in by the legs below
+
+    emit_line = None
+    if rank == 0:
+        def emit_line():
+            print(json.dumps(out), flush=True)
+    for name, fn in gather_legs:
+        guarded(name, fn)
     hz.close()
     del hz, env
 
@@ -388,7 +468,7 @@ def main():
             extra = {}
             for name, ksteps, kwarm, kpre in (("default", 300, 50, 500), ("nohide-symbol", 60, 10, 100)):
                 try:
-                    x = Harness(torch, name, 0, 0, local_rank, ksteps + kwarm)
+                    x = Harness(torch, name, 0, 0, local_rank)
                     for _ in range(kpre + kwarm):  # (same reason as the main pre-roll: not the synchronised first steps of every env)
                         x.step()
                     x.timing(4)
@@ -415,7 +495,7 @@ def main():
         if not args.no_cpu_baseline and WORKLOADS[args.workload][2] == "gray":
             out["cpu_baseline"] = cpu_baseline(golden_config(WORKLOADS[args.workload][0]), WORKLOADS[args.workload][5])
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit_line()
     if world > 1:
         dist.destroy_process_group()
 

@@ -136,6 +136,16 @@ void rg_host_free(void *p);
  * bytes.  H*W must be divisible by 4. */
 int rg_compact_record_bytes(const rg_t *h, int with_hist);
 int rg_pack_compact(rg_t *h, int with_hist, uint8_t *out_dev);
+/* The collective itself ("exactly one per step: ncclAllGather (RCCL over xGMI) of the obs slice, in place into rank-ordered
+ * slices"), for hosts that do not bring their own (the reference has none: its workers are threads, python/src/thread_impls.rs:14-34).
+ * rg_comm_unique_id: ncclGetUniqueId on one rank, handed to the others by the caller (any channel; 128 bytes).  rg_comm_init: ncclCommInitRank
+ * for the handle's device; every rank's handle must hold the same n_env.  rg_allgather_compact: packs this rank's records into slice `rank` of
+ * out_dev = u8 [world * n_env][record] and all-gathers in place on the handle's stream (asynchronous like every launch; expand with
+ * rg_expand_compact).  librccl is bound at run time: only these four calls need it. */
+int rg_comm_unique_id(uint8_t id[128]);
+int rg_comm_init(rg_t *h, const uint8_t id[128], int rank, int world);
+int rg_comm_destroy(rg_t *h);
+int rg_allgather_compact(rg_t *h, int with_hist, uint8_t *out_dev);
 int rg_expand_compact(rg_t *h, const uint8_t *packed_dev, int n, int packed_has_hist, int kind, uint32_t status_flag, int with_hist, float *out_dev);
 
 /* Action-history log (RunTime::saved_inputs, core/src/lib.rs:288; GameState::dump_history, python/src/lib.rs:245-250).  Off by default;
@@ -172,6 +182,18 @@ int rg_dump_config(const rg_t *h, int env, char *buf, size_t cap);
  * re-serialisation (GameConfig::to_json with the reference's skip-if-default rules) into buf.  Needs no device.
  * Returns non-zero and sets rg_last_error(NULL) on a parse / validation error. */
 int rg_config_canonical(const char *cfg_json, char *buf, size_t cap);
+
+/* Stateless: what the stepper resolved from the item tables and the player's pack of one GameConfig (Player::init_items, player.rs:136-153;
+ * InitItem::initialize, item/mod.rs:181-221) -- JSON {"weapon": {"times", "max", "hit_plus", "dam_plus"} (the wielded dice, fight.rs:21-33),
+ * "armor_def" (Player::arm), "init_gold", "can_pickup", "init_draws": [[lo, hi] ...] (the item-stream draws of the build, weapon.rs:159),
+ * "symbols", "n_enemies"}.  Needs no device; errors as rg_config_canonical. */
+int rg_config_resolved(const char *cfg_json, char *buf, size_t cap);
+
+/* The config surface, key by key: a JSON array of {"path", "status": "honoured" | "inert", "why"} for every key the reference's serde structs
+ * know (core/src/lib.rs:42-86, rogue/mod.rs:23-66, item/{mod,gold,weapon,armor}.rs, player.rs:17-32, enemies.rs:18-121).  "inert" = serde reads
+ * it and the engine never does; such keys are accepted, type-checked and written back by rg_dump_config.  Needs no device.  *needed = bytes incl.
+ * NUL (buf may be NULL to query). */
+int rg_config_schema(char *buf, size_t cap, size_t *needed);
 
 /* Parity/debug: synchronous copy of env i's internal state to the host. */
 typedef struct rg_debug_state {

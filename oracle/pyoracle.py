@@ -19,6 +19,31 @@ class OrcMonStat(C.Structure):
                 ("exp", C.c_uint32), ("level", C.c_int32), ("rarity", C.c_int32), ("tile", C.c_int32)]
 
 
+NAME_CAP, MAX_STATS, MAX_INIT_ITEMS = 32, 16, 16
+
+
+class OrcWeaponStat(C.Structure):
+    _fields_ = [("name", C.c_char * NAME_CAP), ("wield_times", C.c_uint64), ("wield_max", C.c_int64), ("init_lo", C.c_uint32), ("init_hi", C.c_uint32),
+                ("attr", C.c_uint32)]
+
+
+class OrcArmorStat(C.Structure):
+    _fields_ = [("name", C.c_char * NAME_CAP), ("def_", C.c_int32)]
+
+
+class OrcItem(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("how_many", C.c_uint32), ("attr", C.c_uint32), ("name", C.c_char * NAME_CAP), ("wield_times", C.c_uint64),
+                ("wield_max", C.c_int64), ("hit_plus", C.c_int64), ("dam_plus", C.c_int64), ("def_", C.c_int32), ("def_plus", C.c_int32)]
+
+
+class OrcInitItem(C.Structure):
+    _fields_ = [("tag", C.c_int32), ("name", C.c_char * NAME_CAP), ("num_plus", C.c_uint32), ("hit_plus", C.c_int32), ("dam_plus", C.c_int32),
+                ("def_plus", C.c_int32), ("item", OrcItem)]
+
+
+ITEM_KINDS = ["Armor", "Food", "Gold", "Potion", "Ring", "Scroll", "Wand", "Weapon"]  # ItemKind order (item/mod.rs:32-41)
+
+
 class OrcConfig(C.Structure):
     _fields_ = [
         ("width", C.c_int32), ("height", C.c_int32),
@@ -40,6 +65,9 @@ class OrcConfig(C.Structure):
         ("enemy_builtin", C.c_int32 * 32),
         ("enemy_custom", OrcMonStat * 32),
         ("choose_width", C.c_int32),
+        ("n_weapons", C.c_int32), ("n_armors", C.c_int32), ("n_init_items", C.c_int32),
+        ("weapons", OrcWeaponStat * MAX_STATS), ("armors", OrcArmorStat * MAX_STATS), ("init_items", OrcInitItem * MAX_INIT_ITEMS),
+        ("max_items", C.c_uint64),
     ]
 
 
@@ -149,7 +177,77 @@ def config_from_dict(d, seed=None, choose_width=64):
     if "appear_rate_nogold" in en:
         c.appear_rate_nogold = en["appear_rate_nogold"]
     c.choose_width = choose_width
+    _items_from_dict(c, d)
     return c
+
+
+def _name(s):
+    b = s.encode()
+    if len(b) >= NAME_CAP:
+        raise ValueError("oracle: item name longer than %d bytes" % (NAME_CAP - 1))
+    return b
+
+
+def _items_from_dict(c, d):
+    """item.weapon / item.armor presets and player.{init_items,max_items} (weapon.rs:12-81, armor.rs:10-86, player.rs:26-29) into the
+    oracle's tables.  orc_config_default filled in the builtin tables and the default pack; builtin presets are copied from there."""
+    item = d.get("item")
+    if item is not None:
+        for k in ("armor", "gold", "weapon"):  # item::Config has no serde defaults (item/mod.rs:24-29)
+            if k not in item:
+                raise ValueError("missing field `%s`" % k)
+        if "weapons" in item["weapon"]:
+            builtin = [OrcWeaponStat.from_buffer_copy(w) for w in c.weapons[:9]]
+            ws = item["weapon"]["weapons"]
+            if len(ws) > MAX_STATS:
+                raise ValueError("oracle: at most %d weapon presets" % MAX_STATS)
+            c.n_weapons = len(ws)
+            for i, w in enumerate(ws):
+                if isinstance(w, int):
+                    c.weapons[i] = builtin[w]
+                else:
+                    c.weapons[i] = OrcWeaponStat(_name(w["name"]), w["at_weild"]["times"], w["at_weild"]["max"], w["init_num"]["start"],
+                                                 w["init_num"]["end"], w["attr"])
+        if "armors" in item["armor"]:
+            builtin = [OrcArmorStat.from_buffer_copy(a) for a in c.armors[:8]]
+            ar = item["armor"]["armors"]
+            if len(ar) > MAX_STATS:
+                raise ValueError("oracle: at most %d armor presets" % MAX_STATS)
+            c.n_armors = len(ar)
+            for i, a in enumerate(ar):
+                c.armors[i] = builtin[a] if isinstance(a, int) else OrcArmorStat(_name(a["name"]), a["def"])
+    pl = d.get("player", {})
+    if "max_items" in pl:
+        c.max_items = pl["max_items"]
+    if "init_items" in pl:
+        items = pl["init_items"]
+        if len(items) > MAX_INIT_ITEMS:
+            raise ValueError("oracle: at most %d init_items" % MAX_INIT_ITEMS)
+        c.n_init_items = len(items)
+        for i, it in enumerate(items):
+            (tag, b), = it.items()
+            o = OrcInitItem()
+            if tag == "Weapon":
+                o.tag, o.name, o.num_plus, o.hit_plus, o.dam_plus = 2, _name(b["name"]), b["num_plus"], b["hit_plus"], b["dam_plus"]
+            elif tag == "Armor":
+                o.tag, o.name, o.def_plus = 1, _name(b["name"]), b["def_plus"]
+            elif tag == "Noinit":
+                o.tag = 0
+                kind = b["kind"]
+                o.item.how_many, o.item.attr = b["how_many"], b["attr"]
+                if isinstance(kind, str):
+                    o.item.kind = ITEM_KINDS.index(kind)
+                else:
+                    (kt, kb), = kind.items()
+                    o.item.kind = ITEM_KINDS.index(kt)
+                    if kt == "Weapon":
+                        o.item.name, o.item.wield_times, o.item.wield_max = _name(kb["name"]), kb["at_weild"]["times"], kb["at_weild"]["max"]
+                        o.item.hit_plus, o.item.dam_plus = kb["hit_plus"], kb["dam_plus"]
+                    elif kt == "Armor":
+                        o.item.name, o.item.def_, o.item.def_plus = _name(kb["name"]), kb["def"], kb["def_plus"]
+            else:
+                raise ValueError("unknown InitItem variant " + tag)
+            c.init_items[i] = o
 
 
 STATUS_KEYS = ["dungeon_level", "gold", "hp_current", "hp_max", "str_current", "str_max", "defense", "player_level", "exp", "hunger"]
@@ -238,7 +336,7 @@ class OracleEnv:
     def scalars(self):
         a = np.zeros(16, np.int64)
         self._L.orc_scalars(self._e, a.ctypes.data)
-        keys = ["px", "py", "level", "hp", "hp_max", "exp", "plevel", "food_left", "quiet", "gold", "n_monsters"]
+        keys = ["px", "py", "level", "hp", "hp_max", "exp", "plevel", "food_left", "quiet", "gold", "n_monsters", "n_pack", "weapon_slot", "armor_slot"]
         return dict(zip(keys, (int(v) for v in a)))
 
     def monsters(self):

@@ -188,7 +188,11 @@ struct orc_env {
     /* player (player.rs:280-306) */
     int px, py;
     int64_t hp, hp_max, plevel;
-    uint32_t exp, food_left, quiet, pack_gold;
+    uint32_t exp, food_left, quiet;
+    /* ItemBox (itembox.rs:8-12): slot ch holds pack[ch]; slots fill from 0 upwards and nothing reachable ever removes an item, so the
+     * BTreeMap<usize, ItemToken> is the array prefix.  weapon / armor: the equipped tokens (player.rs:95-96), as pack slots. */
+    orc_item pack[ORC_MAX_INIT_ITEMS + 1]; int n_pack;
+    int weapon, armor;
     int dead; /* ui == Grave */
     /* GameStateImpl + PlayerState mirror (state_impls.rs, python/src/lib.rs:29-38) */
     uint64_t steps;
@@ -217,6 +221,29 @@ void orc_config_default(orc_config *c) {
     c->n_enemies = 26;
     for (int i = 0; i < 26; i++) c->enemy_builtin[i] = i;
     c->choose_width = 64;
+    /* weapon::Config::default / armor::Config::default: every builtin preset in order (weapon.rs:66-68, armor.rs:34-36) */
+    static const struct { const char *name; int t, m; uint32_t lo, hi, attr; } BW[9] = { /* BUILTIN_WEAPONS (weapon.rs:198-298) */
+        {"mace", 2, 4, 1, 2, 0}, {"long-sword", 3, 4, 1, 2, 0}, {"bow", 1, 1, 1, 2, 0}, {"arrow", 1, 1, 8, 17, 6}, {"dagger", 1, 6, 2, 7, 2},
+        {"two-handed-sword", 4, 4, 1, 2, 0}, {"dart", 1, 1, 8, 17, 6}, {"shuriken", 1, 2, 8, 17, 6}, {"spear", 2, 3, 8, 17, 4}};
+    static const struct { const char *name; int def; } BA[8] = { /* BUILTIN_ARMORS (armor.rs:170-219) */
+        {"leather armor", 2}, {"ring mail", 3}, {"studded leather armor", 3}, {"scale mail", 4}, {"chain mail", 5}, {"splint mail", 6},
+        {"banded mail", 6}, {"plate mail", 7}};
+    c->n_weapons = 9; c->n_armors = 8;
+    for (int i = 0; i < 9; i++) {
+        orc_weapon_stat *w = &c->weapons[i];
+        strncpy(w->name, BW[i].name, ORC_NAME_CAP - 1); w->wield_times = (uint64_t)BW[i].t; w->wield_max = BW[i].m;
+        w->init_lo = BW[i].lo; w->init_hi = BW[i].hi; w->attr = BW[i].attr;
+    }
+    for (int i = 0; i < 8; i++) { strncpy(c->armors[i].name, BA[i].name, ORC_NAME_CAP - 1); c->armors[i].def = BA[i].def; }
+    /* default_init_items (player.rs:68-75): 0 gold, a food ration, ring mail +1 (armor.rs:68-73), mace +1,+1, bow +1,+0, arrows +25 (weapon.rs:179-188) */
+    c->max_items = 27;
+    c->n_init_items = 6;
+    c->init_items[0].tag = ORC_INIT_NOINIT; c->init_items[0].item.kind = ORC_KIND_GOLD; c->init_items[0].item.how_many = 0; c->init_items[0].item.attr = ORC_ATTR_IS_MANY;
+    c->init_items[1].tag = ORC_INIT_NOINIT; c->init_items[1].item.kind = ORC_KIND_FOOD; c->init_items[1].item.how_many = 1; c->init_items[1].item.attr = ORC_ATTR_IS_MANY;
+    c->init_items[2].tag = ORC_INIT_ARMOR; strcpy(c->init_items[2].name, "ring mail"); c->init_items[2].def_plus = 1;
+    c->init_items[3].tag = ORC_INIT_WEAPON; strcpy(c->init_items[3].name, "mace"); c->init_items[3].hit_plus = 1; c->init_items[3].dam_plus = 1;
+    c->init_items[4].tag = ORC_INIT_WEAPON; strcpy(c->init_items[4].name, "bow"); c->init_items[4].hit_plus = 1;
+    c->init_items[5].tag = ORC_INIT_WEAPON; strcpy(c->init_items[5].name, "arrow"); c->init_items[5].num_plus = 25;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -833,9 +860,8 @@ static uint32_t attack_rate(int64_t level, int armor, int64_t revision) { /* fig
 }
 #define PLAYER_STR 16    /* StatusInner::from_config: Strength(16) (player.rs:288) */
 #define ENEMY_STR 10     /* Enemy::STRENGTH (enemies.rs:161) */
-#define ARMOR_DEF 4      /* ring mail def 3 + def_plus 1 (armor.rs:68-73,172-177) */
-#define WEAPON_HIT 1     /* mace +1,+1 2d4 (weapon.rs:179-188,200-203) */
-#define WEAPON_DAM 1
+/* Player::arm (player.rs:125-132): def + def_plus of the equipped armor (Armor::def, armor.rs:100-102), Defense(0) without one */
+static int player_arm(const orc_env *e) { return e->armor < 0 ? 0 : e->pack[e->armor].def + e->pack[e->armor].def_plus; }
 
 /* Player::heal (player.rs:221-240) */
 static int player_heal(orc_env *e) {
@@ -892,7 +918,7 @@ static int move_active_enemies(orc_env *e, rlist_t *res) {
     int did_hit = 0;
     for (int i = 0; i < n_att; i++) {
         const mon_t *m = &attackers[i]; const mstat_t *st = &e->stats[m->type];
-        uint32_t rate = attack_rate(m->level, ARMOR_DEF, hit_prob_plus(ENEMY_STR));
+        uint32_t rate = attack_rate(m->level, player_arm(e), hit_prob_plus(ENEMY_STR));
         int64_t dam_plus = damage_plus(ENEMY_STR) + damage_plus(PLAYER_STR), sum = 0; int hit = 0;
         for (int k = 0; k < st->n_attack; k++) {
             if (!parcent(&e->rng_e, rate)) continue;
@@ -927,12 +953,15 @@ static void player_attack(orc_env *e, int x, int y, rlist_t *res) {
     activate_at(e, x, y);
     int is_active = 0;
     mon_t *m = (mon_t *)mon_at(e, x, y, &is_active);
-    int64_t str_p = hit_prob_plus(PLAYER_STR) + (m->running ? 0 : 4) + WEAPON_HIT;
+    /* no thrown weapon: hit_plus / dam_plus / at_weild of Player::weapon, else 0 / 0 / 1d4 (fight.rs:20-33) */
+    const orc_item *wp = e->weapon < 0 ? NULL : &e->pack[e->weapon];
+    int64_t str_p = hit_prob_plus(PLAYER_STR) + (m->running ? 0 : 4) + (wp ? wp->hit_plus : 0);
     uint32_t rate = attack_rate(e->plevel, m->defense, str_p);
-    if (parcent(&e->rng_e, rate)) {
+    if (parcent(&e->rng_e, rate)) { /* roll over the one die (fight.rs:52-72) */
+        uint64_t times = wp ? wp->wield_times : 1; int64_t mx = wp ? wp->wield_max : 4;
         int64_t dmg = 0;
-        for (int t = 0; t < 2; t++) dmg += (int64_t)range64(&e->rng_e, 1, 5); /* mace 2d4 */
-        dmg += WEAPON_DAM + damage_plus(PLAYER_STR);
+        for (uint64_t t = 0; t < times; t++) dmg += (int64_t)range64(&e->rng_e, 1, (uint64_t)mx + 1); /* Damage::random (character/mod.rs:229-234) */
+        dmg += (wp ? wp->dam_plus : 0) + damage_plus(PLAYER_STR);
         rpush(res, RE_NOTIFY, MSG_HIT_TO);
         if (m->hp <= dmg) { /* Enemy::get_damage (enemies.rs:205-213) */
             uint32_t exp = m->exp;
@@ -953,8 +982,15 @@ static int move_player(orc_env *e, int d, rlist_t *res) {
     e->px = nx; e->py = ny;
     rpush(res, RE_REDRAW, 0);
     int id = IDX(e, nx, ny);
-    if (e->fl.gold[id] >= 0) { /* ItemBox::entry -> Merge into the pack's gold (itembox.rs:30-40) */
-        e->pack_gold += (uint32_t)e->fl.gold[id];
+    if (e->fl.gold[id] >= 0) { /* actions::get_item (actions.rs:206-231) -> ItemBox::entry (itembox.rs:30-40) */
+        /* dungeon gold is `many` (item/mod.rs:409): merge into the first pack item of the same kind (check_merge, itembox.rs:52-58) ... */
+        int slot = -1;
+        for (int k = 0; k < e->n_pack && slot < 0; k++) if (e->pack[k].kind == ORC_KIND_GOLD) slot = k;
+        if (slot >= 0) { e->pack[slot].how_many += (uint32_t)e->fl.gold[id]; e->pack[slot].attr |= ORC_ATTR_IS_MANY; } /* MergeEntry::exec (itembox.rs:74-79) */
+        else if ((uint64_t)e->n_pack < e->cfg.max_items && e->n_pack < ORC_MAX_INIT_ITEMS + 1) { /* ... else the lowest free slot (InsertEntry) ... */
+            orc_item *g = &e->pack[e->n_pack++];
+            memset(g, 0, sizeof *g); g->kind = ORC_KIND_GOLD; g->how_many = (uint32_t)e->fl.gold[id]; g->attr = ORC_ATTR_IS_MANY;
+        } else return 0; /* ... else `entry` is None: get_item returns Ok(None), nothing is picked up or removed */
         remove_obj(&e->fl, nx, ny, 0);
         e->fl.gold[id] = -1;
         rpush(res, RE_NOTIFY, 0 /* GotItem */);
@@ -1056,7 +1092,9 @@ static void draw_screen(const orc_env *e, uint8_t *map) {
 /* RunTime::player_status + Player::fill_status (core/src/lib.rs:345-356, player.rs:107-118) */
 static void player_status(const orc_env *e, uint32_t st[10]) {
     uint32_t hunger = e->cfg.hunger_time / 10;
-    st[0] = e->level; st[1] = e->pack_gold; st[2] = (uint32_t)e->hp; st[3] = (uint32_t)e->hp_max;
+    uint32_t gold = 0; /* the first Gold token of the pack, or 0 (core/src/lib.rs:348-353) */
+    for (int k = 0; k < e->n_pack; k++) if (e->pack[k].kind == ORC_KIND_GOLD) { gold = e->pack[k].how_many; break; }
+    st[0] = e->level; st[1] = gold; st[2] = (uint32_t)e->hp; st[3] = (uint32_t)e->hp_max;
     st[4] = PLAYER_STR; st[5] = PLAYER_STR; st[6] = 0 /* defense never filled */; st[7] = (uint32_t)e->plevel; st[8] = e->exp;
     st[9] = e->food_left <= hunger ? 2 : e->food_left <= hunger * 2 ? 1 : 0;
 }
@@ -1082,7 +1120,47 @@ static void runtime_free(orc_env *e) {
     e->n_placed = e->n_active = 0;
 }
 /* GameConfig::build (core/src/lib.rs:193-228) */
-static void runtime_build(orc_env *e) {
+/* ItemHandler::init_player_items (item/mod.rs:411-422) over InitItem::initialize (item/mod.rs:181-221), then the two equip_from_box calls of
+ * Player::init_items (player.rs:140-152).  Returns 1 where the reference returns an InvalidSetting error. */
+static int player_init_items(orc_env *e) {
+    const orc_config *c = &e->cfg;
+    e->n_pack = 0; e->weapon = e->armor = -1;
+    for (int i = 0; i < c->n_init_items; i++) {
+        const orc_init_item *it = &c->init_items[i];
+        orc_item item;
+        memset(&item, 0, sizeof item);
+        if (it->tag == ORC_INIT_NOINIT) item = it->item;
+        else if (it->tag == ORC_INIT_WEAPON) { /* Handler::gen_item_by: the first status of that name (handler.rs:54-62) */
+            const orc_weapon_stat *st = NULL;
+            for (int k = 0; k < c->n_weapons && !st; k++) if (!strcmp(c->weapons[k].name, it->name)) st = &c->weapons[k];
+            if (!st) return 1; /* "Specified item {} is not registerd to WeaponHandler" */
+            uint32_t num = range32(&e->rng_i, st->init_lo, st->init_hi); /* WeaponStatus::build (weapon.rs:148-170): the one draw, on the item stream */
+            item.kind = ORC_KIND_WEAPON; strcpy(item.name, st->name); item.wield_times = st->wield_times; item.wield_max = st->wield_max;
+            item.hit_plus = 0 + it->hit_plus; item.dam_plus = 0 + it->dam_plus; item.attr = st->attr; item.how_many = num + it->num_plus;
+        } else { /* ArmorStatus::build draws nothing (armor.rs:141-169) */
+            const orc_armor_stat *st = NULL;
+            for (int k = 0; k < c->n_armors && !st; k++) if (!strcmp(c->armors[k].name, it->name)) st = &c->armors[k];
+            if (!st) return 1;
+            item.kind = ORC_KIND_ARMOR; strcpy(item.name, st->name); item.def = st->def; item.def_plus = 0 + it->def_plus; item.how_many = 1;
+        }
+        if ((uint64_t)e->n_pack >= c->max_items) return 1; /* ItemBox::add finds no empty char: "[init_player_items] Failed to add item" */
+        e->pack[e->n_pack++] = item;
+    }
+    /* get_initial_weapon / get_initial_armor: the name of the FIRST InitItem of that variant (player.rs:198-213); equip_from_box: the first
+     * pack item of that kind and name (player.rs:214-220, ItemBox::find_by iterates in slot order) */
+    for (int i = 0; i < c->n_init_items; i++) if (c->init_items[i].tag == ORC_INIT_WEAPON) {
+        for (int k = 0; k < e->n_pack && e->weapon < 0; k++)
+            if (e->pack[k].kind == ORC_KIND_WEAPON && !strcmp(e->pack[k].name, c->init_items[i].name)) { e->weapon = k; e->pack[k].attr |= ORC_ATTR_EQUIPPED; }
+        break;
+    }
+    for (int i = 0; i < c->n_init_items; i++) if (c->init_items[i].tag == ORC_INIT_ARMOR) {
+        for (int k = 0; k < e->n_pack && e->armor < 0; k++)
+            if (e->pack[k].kind == ORC_KIND_ARMOR && !strcmp(e->pack[k].name, c->init_items[i].name)) { e->armor = k; e->pack[k].attr |= ORC_ATTR_EQUIPPED; }
+        break;
+    }
+    return 0;
+}
+static int runtime_build(orc_env *e) {
     const orc_config *c = &e->cfg;
     runtime_free(e);
     rng_seed(&e->rng_i, c->seed_lo, c->seed_hi);  /* ItemHandler::new (item/mod.rs:390) */
@@ -1107,12 +1185,12 @@ static void runtime_build(orc_env *e) {
     }
     e->level = 0;
     new_level_(e, 1);
-    /* Player::init_items: three weapon-count draws on the item rng (weapon.rs:159: mace 1..2, bow 1..2,
-     * arrow 8..17); armor draws nothing (armor.rs:157-159) */
-    (void)range32(&e->rng_i, 1, 2); (void)range32(&e->rng_i, 1, 2); (void)range32(&e->rng_i, 8, 17);
+    /* Player::build (player.rs:78-91) + Player::init_items (player.rs:136-153) */
     e->hp = e->hp_max = c->init_hp; e->plevel = 1; e->exp = 0;
-    e->food_left = c->hunger_time; e->quiet = 0; e->pack_gold = 0; e->dead = 0;
+    e->food_left = c->hunger_time; e->quiet = 0; e->dead = 0;
+    if (player_init_items(e)) return 1;
     actions_new_level(e, 1);
+    return 0;
 }
 static void mirror_reset(orc_env *e) { /* PlayerState::reset (python/src/lib.rs:52-58) */
     player_status(e, e->status);
@@ -1138,7 +1216,7 @@ orc_env *orc_new(const orc_config *cfg, uint64_t max_steps) {
     int n = e->W * e->H;
     e->screen = malloc(n); memset(e->screen, ' ', n);
     e->hist = calloc(n, 1);
-    runtime_build(e);
+    if (runtime_build(e)) { orc_free(e); return NULL; } /* GameConfig::build failed in Player::init_items (core/src/lib.rs:209) */
     mirror_reset(e);
     e->steps = 0;
     return e;
@@ -1146,7 +1224,7 @@ orc_env *orc_new(const orc_config *cfg, uint64_t max_steps) {
 void orc_free(orc_env *e) { if (!e) return; runtime_free(e); free(e->past_visited); free(e->screen); free(e->hist); free(e); }
 void orc_set_seed(orc_env *e, uint64_t lo, uint64_t hi) { e->cfg.seed_lo = lo; e->cfg.seed_hi = hi; }
 int orc_reset(orc_env *e) {
-    runtime_build(e);
+    if (runtime_build(e)) return 1; /* cannot happen: the same config built in orc_new */
     mirror_reset(e);
     e->steps = 0;
     return 0;
@@ -1198,7 +1276,9 @@ void orc_grid(const orc_env *e, uint8_t *surface, uint8_t *attr, uint8_t *doors,
 void orc_scalars(const orc_env *e, int64_t out[16]) {
     memset(out, 0, 16 * sizeof(int64_t));
     out[0] = e->px; out[1] = e->py; out[2] = e->level; out[3] = e->hp; out[4] = e->hp_max; out[5] = e->exp;
-    out[6] = e->plevel; out[7] = e->food_left; out[8] = e->quiet; out[9] = e->pack_gold; out[10] = e->n_placed + e->n_active;
+    out[6] = e->plevel; out[7] = e->food_left; out[8] = e->quiet; out[10] = e->n_placed + e->n_active;
+    uint32_t st[10]; player_status(e, st); out[9] = st[1];
+    out[11] = e->n_pack; out[12] = e->weapon; out[13] = e->armor;
 }
 int orc_monsters(const orc_env *e, orc_monster *out, int cap) {
     mon_t all[2 * MAX_MON]; int act[2 * MAX_MON]; int n = 0;

@@ -31,6 +31,30 @@ typedef struct orc_monstat {
     int32_t level, rarity, tile;
 } orc_monstat;
 
+/* item tables and the player's initial pack (item/weapon.rs:129-140, item/armor.rs:133-139, item/mod.rs:166-229).  Only the fields something
+ * reachable from the RL action set reads are carried (throw dice, worth, launcher, appear rates: not). */
+#define ORC_NAME_CAP 32
+#define ORC_MAX_STATS 16
+#define ORC_MAX_INIT_ITEMS 16
+typedef struct orc_weapon_stat { char name[ORC_NAME_CAP]; uint64_t wield_times; int64_t wield_max; uint32_t init_lo, init_hi; uint32_t attr; } orc_weapon_stat;
+typedef struct orc_armor_stat { char name[ORC_NAME_CAP]; int32_t def; } orc_armor_stat;
+enum { ORC_KIND_ARMOR = 0, ORC_KIND_FOOD, ORC_KIND_GOLD, ORC_KIND_POTION, ORC_KIND_RING, ORC_KIND_SCROLL, ORC_KIND_WAND, ORC_KIND_WEAPON }; /* ItemKind, item/mod.rs:32-41 */
+#define ORC_ATTR_IS_MANY 4u      /* ItemAttr::IS_MANY (item/mod.rs:131) */
+#define ORC_ATTR_EQUIPPED 8u     /* ItemAttr::IS_EQUIPPED (item/mod.rs:132) */
+typedef struct orc_item { /* Item (item/mod.rs:224-229) with the Weapon / Armor payload flattened */
+    int32_t kind; uint32_t how_many, attr;
+    char name[ORC_NAME_CAP];
+    uint64_t wield_times; int64_t wield_max, hit_plus, dam_plus; /* Weapon (weapon.rs:83-92) */
+    int32_t def, def_plus;                                        /* Armor (armor.rs:88-94) */
+} orc_item;
+enum { ORC_INIT_NOINIT = 0, ORC_INIT_ARMOR, ORC_INIT_WEAPON };    /* InitItem (item/mod.rs:166-178) */
+typedef struct orc_init_item {
+    int32_t tag;
+    char name[ORC_NAME_CAP];
+    uint32_t num_plus; int32_t hit_plus, dam_plus, def_plus;
+    orc_item item; /* Noinit */
+} orc_init_item;
+
 /* Flat config (the test harness parses the JSON; the oracle stays JSON-free).
  * Field defaults: core/src/lib.rs:134-140, dungeon/rogue/mod.rs:23-134,
  * character/enemies.rs:56-85, character/player.rs:37-66, item/gold.rs:27-52. */
@@ -50,13 +74,20 @@ typedef struct orc_config {
     int32_t enemy_builtin[32];  /* indices into BUILTIN_ENEMIES (enemies.rs:474-761), or -1: use enemy_custom[i] */
     orc_monstat enemy_custom[32];
     int32_t choose_width;       /* 64 (what reproduces the goldens) or 32; SliceRandom::choose */
+    /* item::Config tables + player.{init_items,max_items} (weapon.rs:34-47, armor.rs:46-60, player.rs:26-29) */
+    int32_t n_weapons, n_armors, n_init_items;
+    orc_weapon_stat weapons[ORC_MAX_STATS];
+    orc_armor_stat armors[ORC_MAX_STATS];
+    orc_init_item init_items[ORC_MAX_INIT_ITEMS];
+    uint64_t max_items;
 } orc_config;
 
 void orc_config_default(orc_config *c);
 
 typedef struct orc_env orc_env;
 
-/* GameStateImpl::new (python/src/state_impls.rs:20-38). Returns NULL on invalid size. */
+/* GameStateImpl::new (python/src/state_impls.rs:20-38). Returns NULL on invalid size, or when Player::init_items fails (an InitItem names an
+ * item that is not in the table; the pack is full: item/mod.rs:216-220,415-419). */
 orc_env *orc_new(const orc_config *cfg, uint64_t max_steps);
 void orc_free(orc_env *e);
 /* GameState.set_seed / Instruction::Seed: takes effect at the next reset. */
@@ -87,7 +118,7 @@ typedef struct orc_monster {
 /* surface: 0 Passage 1 Floor 2 WallX 3 WallY 4 Stair 5 Door 6 Trap 7 None (rogue/mod.rs:137-147)
  * attr: CellAttr bits (dungeon/field.rs:107-124) */
 void orc_grid(const orc_env *e, uint8_t *surface, uint8_t *attr, uint8_t *doors, int32_t *gold);
-/* out: px,py,level,hp,hp_max,exp,plevel,food_left,quiet,gold,n_monsters */
+/* out: px,py,level,hp,hp_max,exp,plevel,food_left,quiet,gold,n_monsters,pack items,equipped weapon slot (-1 none),equipped armor slot (-1 none) */
 void orc_scalars(const orc_env *e, int64_t out[16]);
 int orc_monsters(const orc_env *e, orc_monster *out, int cap); /* sorted by (x,y) */
 /* rng state: 3 streams (dungeon,item,enemy) x {x,y,z,w}; counts = u32 outputs consumed */

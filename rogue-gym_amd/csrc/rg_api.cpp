@@ -2,6 +2,8 @@
 // Owns the HBM state, parses configs, sequences the kernels on one HIP stream.  There is no CPU
 // fallback: without a HIP device every entry point that needs one fails loudly.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -65,6 +67,8 @@ struct rg_handle {
     size_t stat_rows = 0;        // workload counters: one row of 8 per k_step block (summed by rg_counters)
     RgState *d_SP = nullptr;     // device-resident copy of SP: k_step reads the spare's pointers from it on the rare take path (one kernel argument
                                  // instead of a second 60-pointer struct in SGPRs)
+    ncclComm_t comm = nullptr;   // rg_comm_init: the RCCL communicator of the one collective of the sharded path (rg_allgather_compact)
+    int comm_rank = 0, comm_world = 1;
     std::string err;
     // per-kernel HIP-event timing (rg_timing_*)
     bool timing = false;
@@ -156,8 +160,10 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
         if (p.has_seed) { h->seed_lo[i] = p.lo; h->seed_hi[i] = p.hi; h->reseed[i] = 0; }
         else { h->seed_lo[i] = gen(); h->seed_hi[i] = gen(); h->reseed[i] = 1; }  // `seed: None`: every build draws its own seed on the device from this base (build_prologue)
         if (p.has_range) {  // ... inside seed_range if one is given (kept, for dump_config, also when a seed overrides it: core/src/lib.rs:57-61)
-            if (!(p.r1 > p.r0)) {  // rng::gen_ranged_seed -> gen_range(start, end) panics when start >= end (core/src/rng.rs:42-45)
-                g_create_err = "Invalid Setting: seed_range must satisfy start < end"; delete h; return 1;
+            if (!(p.r1 > p.r0)) {  // rng::gen_ranged_seed -> gen_range(start, end) panics when start >= end (core/src/rng.rs:42-45) ...
+                // ... but the range is consulted only without a seed (core/src/lib.rs:157-165): {seed: 7, seed_range: [5, 5]} builds there
+                if (!p.has_seed) { g_create_err = "Invalid Setting: seed_range must satisfy start < end"; delete h; return 1; }
+                continue;  // kept for dump_config (RgParsed), never used
             }
             if (h->range_lo.empty()) { h->range_lo.assign(2 * (size_t)n_env, 0); h->range_span.assign(2 * (size_t)n_env, 0); }
             const unsigned __int128 span = p.r1 - p.r0;
@@ -205,6 +211,13 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
              hipMemcpy(S.range_lo, h->range_lo.data(), 2 * n * 8, hipMemcpyHostToDevice) == hipSuccess &&
              hipMemcpy(S.range_span, h->range_span.data(), 2 * n * 8, hipMemcpyHostToDevice) == hipSuccess;
         if (!ok && h->err.empty()) h->err = "hipMemcpy failed";
+    }
+    if (ok && !h->parsed.init_draws.empty()) {  // Player::init_items' item-stream draws (rg_items.cpp): (lo, hi) pairs, read by build_epilogue
+        uint32_t *d = nullptr;
+        ok = dev_alloc(h, &d, h->parsed.init_draws.size()) &&
+             hipMemcpy(d, h->parsed.init_draws.data(), h->parsed.init_draws.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+        if (!ok && h->err.empty()) h->err = "hipMemcpy failed";
+        S.init_draws = d;
     }
     h->SP = S;
     h->spares = auto_reset != 0 && getenv("ROGUE_GYM_HIP_NO_SPARES") == nullptr;
@@ -301,7 +314,7 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
                 std::string e = rg_parse_config(js, &p);
                 if (!e.empty()) { g_create_err = "Failed to parse config: " + e; return 1; }
                 g = -1;
-                for (size_t k = 0; k < reps.size(); k++) if (rg_config_equal(reps[k].cfg, p.cfg)) { g = (int)k; break; }
+                for (size_t k = 0; k < reps.size(); k++) if (rg_config_equal(reps[k], p)) { g = (int)k; break; }
                 if (g < 0) { g = (int)reps.size(); reps.push_back(p); members.emplace_back(); }
                 prev = js; prev_g = g;
             }
@@ -355,6 +368,7 @@ static void destroy_handle(rg_handle *h) {
     for (rg_handle *sh : h->sub) destroy_handle(sh);
     h->sub.clear();
     (void)hipStreamSynchronize(h->stream);
+    if (h->comm) (void)rg_comm_destroy(h);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->ev_step) (void)hipEventDestroy(h->ev_step);
     for (int k = 0; k < 4; k++) for (auto &e : h->ev[k]) (void)hipEventDestroy(e);
@@ -671,6 +685,88 @@ int rg_pack_compact(rg_t *h, int with_hist, uint8_t *out_dev) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The one collective of the sharded path behind the C-ABI: RCCL over xGMI.  librccl is bound at run time (dlopen on first use):
+// a single-GPU user of this library needs no RCCL, and inside a PyTorch process the soname resolves to the copy torch already loaded, so
+// there is one RCCL per process.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+Rccl *rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) { r.err = std::string("librccl not found: ") + dlerror(); return; }
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+        if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString) r.err = "librccl lacks an expected symbol";
+    });
+    return &r;
+}
+}  // namespace
+
+int rg_comm_unique_id(uint8_t id[128]) {
+    Rccl *r = rccl();
+    if (!r->err.empty()) { g_create_err = r->err; return 1; }
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId");
+    ncclUniqueId u;
+    ncclResult_t e = r->GetUniqueId(&u);
+    if (e != ncclSuccess) { g_create_err = std::string("ncclGetUniqueId: ") + r->GetErrorString(e); return 1; }
+    memcpy(id, &u, 128);
+    return 0;
+}
+
+int rg_comm_init(rg_t *h, const uint8_t id[128], int rank, int world) {
+    Rccl *r = rccl();
+    if (!r->err.empty()) { h->err = r->err; return 1; }
+    if (world < 1 || rank < 0 || rank >= world) { h->err = "rg_comm_init: invalid rank / world"; return 1; }
+    if (h->comm) { h->err = "rg_comm_init: the handle already has a communicator"; return 1; }
+    HIPCHK(h, hipSetDevice(h->device));
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    ncclResult_t e = r->CommInitRank(&h->comm, world, u, rank);
+    if (e != ncclSuccess) { h->comm = nullptr; h->err = std::string("ncclCommInitRank: ") + r->GetErrorString(e); return 1; }
+    h->comm_rank = rank; h->comm_world = world;
+    return 0;
+}
+
+int rg_comm_destroy(rg_t *h) {
+    if (!h->comm) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    ncclResult_t e = rccl()->CommDestroy(h->comm);
+    h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0;
+    if (e != ncclSuccess) { h->err = std::string("ncclCommDestroy: ") + rccl()->GetErrorString(e); return 1; }
+    return 0;
+}
+
+int rg_allgather_compact(rg_t *h, int with_hist, uint8_t *out_dev) {
+    if (!h->comm) { h->err = "rg_allgather_compact: no communicator (rg_comm_init first)"; return 1; }
+    const size_t bytes = (size_t)h->S.n * (size_t)rg_compact_record_bytes(h, with_hist);
+    // pack straight into this rank's slice of the gathered batch, then gather IN PLACE (sendbuff == recvbuff + rank * count) on the handle's stream:
+    // no staging copy, and the collective is ordered behind the step like any other launch of the handle
+    uint8_t *mine = out_dev + (size_t)h->comm_rank * bytes;
+    if (rg_pack_compact(h, with_hist, mine)) return 1;
+    ncclResult_t e = rccl()->AllGather(mine, out_dev, bytes, ncclUint8, h->comm, h->stream);
+    if (e != ncclSuccess) { h->err = std::string("ncclAllGather: ") + rccl()->GetErrorString(e); return 1; }
+    return 0;
+}
+
 int rg_expand_compact(rg_t *h, const uint8_t *packed_dev, int n, int packed_has_hist, int kind, uint32_t status_flag, int with_hist, float *out_dev) {
     HIPCHK(h, hipSetDevice(h->device));
     if (h->S.hw & 3) { h->err = "rg_expand_compact needs H*W divisible by 4"; return 1; }
@@ -872,6 +968,30 @@ int rg_dump_config(const rg_t *h, int env, char *buf, size_t cap) {
     }
     std::string s = rg_dump_config_json(p, h->seed_lo[env], h->seed_hi[env], !h->reseed[env]);
     if (s.size() + 1 > cap) return 1;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return 0;
+}
+
+int rg_config_schema(char *buf, size_t cap, size_t *needed) {
+    std::string s = rg_config_schema_json();
+    if (needed) *needed = s.size() + 1;
+    if (!buf || s.size() + 1 > cap) return buf ? 1 : 0;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return 0;
+}
+
+int rg_config_resolved(const char *cfg_json, char *buf, size_t cap) {
+    RgParsed p;
+    std::string e = rg_parse_config(cfg_json, &p);
+    if (!e.empty()) { g_create_err = "Failed to parse config: " + e; return 1; }
+    const RgConfig &c = p.cfg;
+    std::string s = "{\"weapon\": {\"times\": " + std::to_string(c.wpn_times) + ", \"max\": " + std::to_string(c.wpn_max) + ", \"hit_plus\": " +
+                    std::to_string(c.wpn_hit_plus) + ", \"dam_plus\": " + std::to_string(c.wpn_dam_plus) + "}, \"armor_def\": " + std::to_string(c.armor_def) +
+                    ", \"init_gold\": " + std::to_string(c.init_gold) + ", \"can_pickup\": " + (c.can_pickup ? "true" : "false") + ", \"init_draws\": [";
+    for (size_t i = 0; i + 1 < p.init_draws.size(); i += 2)
+        s += std::string(i ? ", " : "") + "[" + std::to_string(p.init_draws[i]) + ", " + std::to_string(p.init_draws[i + 1]) + "]";
+    s += "], \"symbols\": " + std::to_string(c.symbols) + ", \"n_enemies\": " + std::to_string(c.n_enemies) + "}";
+    if (s.size() + 1 > cap) { g_create_err = "rg_config_resolved: buffer too small"; return 1; }
     memcpy(buf, s.c_str(), s.size() + 1);
     return 0;
 }

@@ -1,7 +1,9 @@
 // rg_config.cpp -- minimal JSON reader for GameConfig (core/src/lib.rs:42-86 and the per-module
 // Config structs: rogue/mod.rs:23-134, enemies.rs:18-85, player.rs:17-66, item/gold.rs:6-52).
-// Like serde without deny_unknown_fields, unknown keys are ignored; wrong types are errors.
+// Like serde without deny_unknown_fields, keys the reference's structs do not know are ignored; wrong types are errors.  Every key the
+// structs DO know is either honoured or provably inert in the engine (rg_config_schema_json lists which and why); none is dropped silently.
 #include "rg_config.h"
+#include "rg_json.h"
 
 #include <cctype>
 #include <cstring>
@@ -9,94 +11,10 @@
 #include <memory>
 #include <vector>
 
+using rgjson::JVal;
+using rgjson::Parser;
+
 namespace {
-
-struct JVal {
-    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
-    bool b = false;
-    bool neg = false, is_int = true;
-    unsigned __int128 mag = 0; // integer magnitude
-    double d = 0;
-    std::string s;
-    std::vector<JVal> arr;
-    std::vector<std::pair<std::string, JVal>> obj;
-    const JVal *get(const char *k) const {
-        for (auto &kv : obj) if (kv.first == k) return &kv.second;
-        return nullptr;
-    }
-};
-
-struct Parser {
-    const char *p, *end;
-    std::string err;
-    void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; }
-    bool fail(const std::string &m) { if (err.empty()) err = m; return false; }
-    bool parse(JVal &v) {
-        ws();
-        if (p >= end) return fail("EOF while parsing a value");
-        char c = *p;
-        if (c == '{') {
-            v.kind = JVal::Obj; p++; ws();
-            if (p < end && *p == '}') { p++; return true; }
-            for (;;) {
-                ws();
-                JVal k;
-                if (p >= end || *p != '"') return fail("key must be a string");
-                if (!parse(k)) return false;
-                ws();
-                if (p >= end || *p != ':') return fail("expected `:`");
-                p++;
-                JVal x;
-                if (!parse(x)) return false;
-                v.obj.emplace_back(k.s, std::move(x));
-                ws();
-                if (p < end && *p == ',') { p++; ws(); if (p < end && *p == '}') return fail("trailing comma"); continue; }
-                if (p < end && *p == '}') { p++; return true; }
-                return fail("expected `,` or `}`");
-            }
-        }
-        if (c == '[') {
-            v.kind = JVal::Arr; p++; ws();
-            if (p < end && *p == ']') { p++; return true; }
-            for (;;) {
-                JVal x;
-                if (!parse(x)) return false;
-                v.arr.push_back(std::move(x));
-                ws();
-                if (p < end && *p == ',') { p++; ws(); if (p < end && *p == ']') return fail("trailing comma"); continue; }
-                if (p < end && *p == ']') { p++; return true; }
-                return fail("expected `,` or `]`");
-            }
-        }
-        if (c == '"') {
-            v.kind = JVal::Str; p++;
-            while (p < end && *p != '"') {
-                if (*p == '\\' && p + 1 < end) { p++; char e = *p++; v.s += (e == 'n' ? '\n' : e == 't' ? '\t' : e); }
-                else v.s += *p++;
-            }
-            if (p >= end) return fail("EOF while parsing a string");
-            p++;
-            return true;
-        }
-        if (!strncmp(p, "true", 4) && end - p >= 4) { v.kind = JVal::Bool; v.b = true; p += 4; return true; }
-        if (!strncmp(p, "false", 5) && end - p >= 5) { v.kind = JVal::Bool; v.b = false; p += 5; return true; }
-        if (!strncmp(p, "null", 4) && end - p >= 4) { v.kind = JVal::Null; p += 4; return true; }
-        if (c == '-' || isdigit((unsigned char)c)) {
-            v.kind = JVal::Num;
-            const char *s = p;
-            if (c == '-') { v.neg = true; p++; }
-            if (p >= end || !isdigit((unsigned char)*p)) return fail("invalid number");
-            while (p < end && isdigit((unsigned char)*p)) { v.mag = v.mag * 10 + (unsigned)(*p - '0'); p++; }
-            if (p < end && (*p == '.' || *p == 'e' || *p == 'E')) {
-                v.is_int = false;
-                while (p < end && (isdigit((unsigned char)*p) || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) p++;
-                v.d = strtod(std::string(s, p).c_str(), nullptr);
-            }
-            return true;
-        }
-        return fail(std::string("expected value, found `") + c + "`");
-    }
-};
 
 struct Ctx { std::string err; };
 
@@ -172,6 +90,31 @@ void set_defaults(RgParsed *p) {
     for (int i = 0; i < 26; i++) fill_builtin(p, i, i);
     memcpy(c.level_exps, DEFAULT_EXPS, sizeof DEFAULT_EXPS);
     c.n_level_exps = 21;
+    p->init_str = 16; p->heal_threshold = 20; p->enable_trap = true; p->exps_given = false; p->keymap_json.clear();
+    (void)rg_resolve_items(nullptr, nullptr, p);  // the default pack: mace 2d4 +1,+1, ring mail 3 + 1, draws 1..2, 1..2, 8..17, gold 0
+}
+
+// KeyMap::default (input.rs:23-66) in its serialised form (input.rs:141-198; data/config-default.json holds the same 28 entries): `keymap`
+// is carried only so that dump_config can skip it when default and write it back otherwise
+bool keymap_is_default(const JVal &km) {
+    static const struct { const char *key, *code; } D[28] = {
+        {"l", "{\"Act\": {\"Move\": \"Right\"}}"}, {"k", "{\"Act\": {\"Move\": \"Up\"}}"}, {"j", "{\"Act\": {\"Move\": \"Down\"}}"},
+        {"h", "{\"Act\": {\"Move\": \"Left\"}}"}, {"u", "{\"Act\": {\"Move\": \"RightUp\"}}"},
+        {"y", "{\"Both\": {\"act\": {\"Move\": \"LeftUp\"}, \"sys\": \"Yes\"}}"}, {"n", "{\"Both\": {\"act\": {\"Move\": \"RightDown\"}, \"sys\": \"No\"}}"},
+        {"b", "{\"Act\": {\"Move\": \"LeftDown\"}}"}, {"L", "{\"Act\": {\"MoveUntil\": \"Right\"}}"}, {"K", "{\"Act\": {\"MoveUntil\": \"Up\"}}"},
+        {"J", "{\"Act\": {\"MoveUntil\": \"Down\"}}"}, {"H", "{\"Act\": {\"MoveUntil\": \"Left\"}}"}, {"U", "{\"Act\": {\"MoveUntil\": \"RightUp\"}}"},
+        {"Y", "{\"Act\": {\"MoveUntil\": \"LeftUp\"}}"}, {"N", "{\"Act\": {\"MoveUntil\": \"RightDown\"}}"}, {"B", "{\"Act\": {\"MoveUntil\": \"LeftDown\"}}"},
+        {"s", "{\"Act\": \"Search\"}"}, {".", "{\"Act\": \"NoOp\"}"}, {">", "{\"Act\": \"DownStair\"}"},
+        {"Up", "{\"Act\": {\"Move\": \"Up\"}}"}, {"Down", "{\"Act\": {\"Move\": \"Down\"}}"}, {"Left", "{\"Act\": {\"Move\": \"Left\"}}"},
+        {"Right", "{\"Act\": {\"Move\": \"Right\"}}"}, {"Esc", "{\"Sys\": \"Cancel\"}"}, {"S", "{\"Sys\": \"Save\"}"}, {"Q", "{\"Sys\": \"Quit\"}"},
+        {"i", "{\"Sys\": \"Inventory\"}"}, {" ", "{\"Sys\": \"Continue\"}"},
+    };
+    if (km.obj.size() != 28) return false;
+    for (auto &d : D) {
+        const JVal *v = km.get(d.key);
+        if (!v || rgjson::to_string(*v) != d.code) return false;
+    }
+    return true;
 }
 
 std::string finish(RgParsed *p) {
@@ -245,6 +188,10 @@ std::string rg_parse_config(const char *json, RgParsed *out) {
             GET_I32(m, "x", g.min_room_x);
             GET_I32(m, "y", g.min_room_y);
         }
+        if (const JVal *t = d->get("enable_trap")) {  // read by serde, used by nothing: the engine has no trap code (rogue/mod.rs:33-35)
+            if (t->kind != JVal::Bool) return "invalid type for `enable_trap`, expected a boolean";
+            out->enable_trap = t->b;
+        }
         GET_U32(d, "max_empty_rooms", g.max_empty_rooms);
         GET_U32(d, "amulet_level", g.amulet_level);
         GET_U32(d, "maze_rate_inv", g.maze_rate_inv);
@@ -264,13 +211,22 @@ std::string rg_parse_config(const char *json, RgParsed *out) {
             GET_U32(gd, "per_level", g.gold_per_level);
             GET_U32(gd, "minimum", g.gold_minimum);
         }
-        // armor / weapon tables only matter for item drops, which the engine never generates
+        // item.armor / item.weapon: the tables the player's init_items are looked up in (rg_resolve_items below)
     }
-    if (const JVal *pl = root.get("player")) {
+    const JVal *pl = root.get("player");
+    if (pl) {
         if (pl->kind != JVal::Obj) return "invalid type for `player`";
         GET_U32(pl, "hunger_time", g.hunger_time);
         GET_I32(pl, "init_hp", g.init_hp);
+        {   // init_str / heal_threshold: deserialised, then never read (StatusInner::from_config uses Strength(16), player.rs:284; Player::heal
+            // uses the literal 20, player.rs:226): accepted, type-checked, carried for dump_config
+            int64_t t = out->init_str;
+            if (!get_int(c, pl, "init_str", -0x7fffffffffffffffLL - 1, 0x7fffffffffffffffLL, &t)) return c.err;
+            out->init_str = t;
+            GET_U32(pl, "heal_threshold", out->heal_threshold);
+        }
         if (const JVal *ex = pl->get("exps")) {
+            out->exps_given = true;
             if (ex->kind != JVal::Arr || ex->arr.empty() || ex->arr.size() > 21) return "invalid `exps` (1..=21 entries supported)";
             g.n_level_exps = (int)ex->arr.size();
             for (size_t i = 0; i < ex->arr.size(); i++) {
@@ -325,18 +281,20 @@ std::string rg_parse_config(const char *json, RgParsed *out) {
         GET_U32(en, "appear_rate_gold", g.appear_rate_gold);
         GET_U32(en, "appear_rate_nogold", g.appear_rate_nogold);
     }
+    if (const JVal *km = root.get("keymap")) {  // GameStateImpl::new replaces RunTime::keymap with KeyMap::ai (python/src/state_impls.rs:27,40): inert at this boundary
+        if (km->kind != JVal::Obj) return "invalid type for `keymap`, expected a map";
+        if (!keymap_is_default(*km)) out->keymap_json = rgjson::to_string(*km);  // to_json skips a default keymap (core/src/lib.rs:71-73)
+    }
+    {   // item.weapon / item.armor / player.init_items / player.max_items (rg_items.cpp)
+        std::string e = rg_resolve_items(root.get("item"), pl, out);
+        if (!e.empty()) return e;
+    }
     return finish(out);
 }
 
-bool rg_config_equal(const RgConfig &a, const RgConfig &b) { return memcmp(&a, &b, sizeof(RgConfig)) == 0; }
+bool rg_config_equal(const RgParsed &a, const RgParsed &b) { return memcmp(&a.cfg, &b.cfg, sizeof(RgConfig)) == 0 && a.init_draws == b.init_draws; }
 
-static std::string u128_str(uint64_t lo, uint64_t hi) {
-    unsigned __int128 v = ((unsigned __int128)hi << 64) | lo;
-    if (v == 0) return "0";
-    std::string s;
-    while (v) { s.insert(s.begin(), (char)('0' + (int)(v % 10))); v /= 10; }
-    return s;
-}
+static std::string u128_str(uint64_t lo, uint64_t hi) { return rgjson::u128_str(((unsigned __int128)hi << 64) | lo); }
 
 // GameConfig::to_json with skip_serializing_if = is_default (core/src/lib.rs:42-86): default-valued
 // sections are omitted, so `json.loads(dump) == config_dict` holds for the reference's test configs.
@@ -356,25 +314,34 @@ std::string rg_dump_config_json(const RgParsed &p, uint64_t seed_lo, uint64_t se
     bool dung_default = c.room_num_x == z.room_num_x && c.room_num_y == z.room_num_y && c.min_room_x == z.min_room_x && c.min_room_y == z.min_room_y &&
         c.max_empty_rooms == z.max_empty_rooms && c.amulet_level == z.amulet_level && c.maze_rate_inv == z.maze_rate_inv && c.dark_level == z.dark_level &&
         c.hidden_passage_rate_inv == z.hidden_passage_rate_inv && c.locked_door_rate_inv == z.locked_door_rate_inv && c.max_extra_edges == z.max_extra_edges &&
-        c.door_unlock_rate_inv == z.door_unlock_rate_inv && c.passage_unlock_rate_inv == z.passage_unlock_rate_inv;
+        c.door_unlock_rate_inv == z.door_unlock_rate_inv && c.passage_unlock_rate_inv == z.passage_unlock_rate_inv && p.enable_trap;
     if (!dung_default) {
         sep();
         s += "\"dungeon\": {\"style\": \"rogue\", \"room_num_x\": " + std::to_string(c.room_num_x) + ", \"room_num_y\": " + std::to_string(c.room_num_y) +
-             ", \"min_room_size\": {\"x\": " + std::to_string(c.min_room_x) + ", \"y\": " + std::to_string(c.min_room_y) + "}, \"enable_trap\": true" +
+             ", \"min_room_size\": {\"x\": " + std::to_string(c.min_room_x) + ", \"y\": " + std::to_string(c.min_room_y) + "}, \"enable_trap\": " + (p.enable_trap ? "true" : "false") +
              ", \"max_empty_rooms\": " + std::to_string(c.max_empty_rooms) + ", \"amulet_level\": " + std::to_string(c.amulet_level) +
              ", \"maze_rate_inv\": " + std::to_string(c.maze_rate_inv) + ", \"dark_level\": " + std::to_string(c.dark_level) +
              ", \"hidden_passage_rate_inv\": " + std::to_string(c.hidden_passage_rate_inv) + ", \"locked_door_rate_inv\": " + std::to_string(c.locked_door_rate_inv) +
              ", \"max_extra_edges\": " + std::to_string(c.max_extra_edges) + ", \"door_unlock_rate_inv\": " + std::to_string(c.door_unlock_rate_inv) +
              ", \"passage_unlock_rate_inv\": " + std::to_string(c.passage_unlock_rate_inv) + "}";
     }
-    if (c.gold_rate_inv != z.gold_rate_inv || c.gold_base != z.gold_base || c.gold_per_level != z.gold_per_level || c.gold_minimum != z.gold_minimum) {
+    // item::Config has three sections without skip rules (item/mod.rs:24-29): a non-default `item` is written whole
+    if (c.gold_rate_inv != z.gold_rate_inv || c.gold_base != z.gold_base || c.gold_per_level != z.gold_per_level || c.gold_minimum != z.gold_minimum ||
+        !p.weapon_default || !p.armor_default) {
         sep();
-        s += "\"item\": {\"gold\": {\"rate_inv\": " + std::to_string(c.gold_rate_inv) + ", \"base\": " + std::to_string(c.gold_base) +
-             ", \"per_level\": " + std::to_string(c.gold_per_level) + ", \"minimum\": " + std::to_string(c.gold_minimum) + "}}";
+        s += "\"item\": {\"armor\": " + p.armor_json + ", \"gold\": {\"rate_inv\": " + std::to_string(c.gold_rate_inv) + ", \"base\": " + std::to_string(c.gold_base) +
+             ", \"per_level\": " + std::to_string(c.gold_per_level) + ", \"minimum\": " + std::to_string(c.gold_minimum) + "}, \"weapon\": " + p.weapon_json + "}";
     }
-    if (c.hunger_time != z.hunger_time || c.init_hp != z.init_hp) {
+    if (!p.keymap_json.empty()) { sep(); s += "\"keymap\": " + p.keymap_json; }
+    // player::Config (player.rs:17-32): `exps` flattened first, then the fields in declaration order
+    bool exps_default = c.n_level_exps == 21 && memcmp(c.level_exps, DEFAULT_EXPS, sizeof DEFAULT_EXPS) == 0;
+    if (c.hunger_time != z.hunger_time || c.init_hp != z.init_hp || !exps_default || p.init_str != 16 || p.max_items != 27 || !p.init_items_default ||
+        p.heal_threshold != 20) {
         sep();
-        s += "\"player\": {\"hunger_time\": " + std::to_string(c.hunger_time) + ", \"init_hp\": " + std::to_string(c.init_hp) + "}";
+        s += "\"player\": {\"exps\": [";
+        for (int i = 0; i < c.n_level_exps; i++) s += (i ? ", " : "") + std::to_string(c.level_exps[i]);
+        s += "], \"hunger_time\": " + std::to_string(c.hunger_time) + ", \"init_hp\": " + std::to_string(c.init_hp) + ", \"init_str\": " + std::to_string(p.init_str) +
+             ", \"max_items\": " + std::to_string(p.max_items) + ", \"init_items\": " + p.init_items_json + ", \"heal_threshold\": " + std::to_string(p.heal_threshold) + "}";
     }
     bool en_default = p.n_presets == 26;
     for (int i = 0; en_default && i < 26; i++) en_default = p.preset_builtin[i] == i;
@@ -399,4 +366,65 @@ std::string rg_dump_config_json(const RgParsed &p, uint64_t seed_lo, uint64_t se
     sep(); s += std::string("\"hide_dungeon\": ") + (c.hide_dungeon ? "true" : "false");
     s += "}";
     return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The config surface, key by key.  "honoured": the stepper's results depend on it exactly as the engine's do.  "inert": serde reads it, the
+// engine (as driven through python/src) never does -- accepted, type-checked, written back by dump_config, no effect, like the reference.
+// There is no third state: a key the engine reads and the stepper does not implement would have to be a creation error
+// (tests/test_config_schema.py walks this table against the key lists of the reference's structs).
+// ---------------------------------------------------------------------------------------------
+std::string rg_config_schema_json() {
+    static const struct { const char *path, *status, *why; } K[] = {
+        {"width", "honoured", "core/src/lib.rs:45-48,166-184"}, {"height", "honoured", "core/src/lib.rs:49-52"},
+        {"seed", "honoured", "core/src/lib.rs:53-57,157-165"}, {"seed_range", "honoured", "core/src/lib.rs:58-62; only without a seed"},
+        {"hide_dungeon", "honoured", "core/src/lib.rs:83-85; rogue/mod.rs:465-475"},
+        {"keymap", "inert", "GameStateImpl::new overwrites RunTime::keymap with KeyMap::ai (python/src/state_impls.rs:27,40)"},
+        {"dungeon.style", "honoured", "dungeon/mod.rs:16-29: only `rogue` builds; the other variants are unimplemented!() there and an error here"},
+        {"dungeon.room_num_x", "honoured", "rogue/mod.rs:25-27"}, {"dungeon.room_num_y", "honoured", "rogue/mod.rs:28-30"},
+        {"dungeon.min_room_size", "honoured", "rogue/mod.rs:31-33"},
+        {"dungeon.enable_trap", "inert", "rogue/mod.rs:34-36: no trap code exists in the engine"},
+        {"dungeon.max_empty_rooms", "honoured", "rooms.rs:179"}, {"dungeon.amulet_level", "honoured", "enemies.rs:275-285"},
+        {"dungeon.maze_rate_inv", "honoured", "rooms.rs:238"}, {"dungeon.dark_level", "honoured", "rooms.rs:237; floor.rs:430,437"},
+        {"dungeon.hidden_passage_rate_inv", "honoured", "floor.rs:431"}, {"dungeon.locked_door_rate_inv", "honoured", "floor.rs:438"},
+        {"dungeon.max_extra_edges", "honoured", "passages.rs:54"}, {"dungeon.door_unlock_rate_inv", "honoured", "floor.rs:363"},
+        {"dungeon.passage_unlock_rate_inv", "honoured", "floor.rs:359"},
+        {"item.gold.rate_inv", "honoured", "gold.rs:19"}, {"item.gold.base", "honoured", "gold.rs:22"}, {"item.gold.per_level", "honoured", "gold.rs:22"},
+        {"item.gold.minimum", "honoured", "gold.rs:22"},
+        {"item.weapon.weapons", "honoured", "weapon.rs:34-47: the table InitItem::Weapon names are looked up in"},
+        {"item.weapon.weapons[].at_weild", "honoured", "fight.rs:27-33"}, {"item.weapon.weapons[].name", "honoured", "item/mod.rs:189-191"},
+        {"item.weapon.weapons[].init_num", "honoured", "weapon.rs:159: one item-stream draw per InitItem::Weapon"},
+        {"item.weapon.weapons[].at_throw", "inert", "throwing is unreachable from the 19-key ai keymap (input.rs:73-100)"},
+        {"item.weapon.weapons[].attr", "inert", "IS_MANY / CAN_THROW of a weapon: read by inventory code only"},
+        {"item.weapon.weapons[].is_initial", "inert", "read by nothing"}, {"item.weapon.weapons[].appear_rate", "inert", "Handler::gen_item has no caller (handler.rs:42-53)"},
+        {"item.weapon.weapons[].worth", "inert", "read by nothing"}, {"item.weapon.weapons[].launcher", "inert", "only for thrown weapons (fight.rs:12-18)"},
+        {"item.weapon.cursed_rate", "inert", "Handler::gen_item has no caller (handler.rs:42-53)"}, {"item.weapon.powerup_rate", "inert", "Handler::gen_item has no caller"},
+        {"item.armor.armors", "honoured", "armor.rs:46-60: the table InitItem::Armor names are looked up in"},
+        {"item.armor.armors[].name", "honoured", "item/mod.rs:204-206"}, {"item.armor.armors[].def", "honoured", "armor.rs:100-102; fight.rs:80-82"},
+        {"item.armor.armors[].appear_rate", "inert", "Handler::gen_item has no caller"}, {"item.armor.armors[].worth", "inert", "read by nothing"},
+        {"item.armor.cursed_rate", "inert", "Handler::gen_item has no caller"}, {"item.armor.powerup_rate", "inert", "Handler::gen_item has no caller"},
+        {"player.exps", "honoured", "player.rs:308-353"}, {"player.hunger_time", "honoured", "player.rs:107-118,163-176,286"},
+        {"player.init_hp", "honoured", "player.rs:283"},
+        {"player.init_str", "inert", "StatusInner::from_config hard-codes Strength(16) (player.rs:284)"},
+        {"player.max_items", "honoured", "ItemBox capacity: player.rs:83; itembox.rs:21-40"},
+        {"player.init_items", "honoured", "player.rs:136-153; item/mod.rs:181-221"},
+        {"player.init_items[].Weapon.name", "honoured", "item/mod.rs:189-191; player.rs:198-205"},
+        {"player.init_items[].Weapon.num_plus", "inert", "the weapon count is read by nothing reachable"},
+        {"player.init_items[].Weapon.hit_plus", "honoured", "item/mod.rs:195; fight.rs:21-22"}, {"player.init_items[].Weapon.dam_plus", "honoured", "item/mod.rs:196; fight.rs:23"},
+        {"player.init_items[].Armor.name", "honoured", "item/mod.rs:204-206; player.rs:206-213"}, {"player.init_items[].Armor.def_plus", "honoured", "item/mod.rs:208"},
+        {"player.init_items[].Noinit.kind", "honoured", "Gold: core/src/lib.rs:348-353; Weapon / Armor: candidates of equip_from_box (player.rs:214-220)"},
+        {"player.init_items[].Noinit.how_many", "honoured", "the initial gold count (core/src/lib.rs:348-353)"},
+        {"player.init_items[].Noinit.attr", "inert", "dungeon gold is always `many` (item/mod.rs:409), so a merge never consults the pack item's attr"},
+        {"player.heal_threshold", "inert", "Player::heal uses the literal 20 (player.rs:226)"},
+        {"enemies.enemies", "honoured", "enemies.rs:20-21,250-261"}, {"enemies.enemies[].attack", "honoured", "fight.rs:41-50"},
+        {"enemies.enemies[].attr", "honoured", "enemies.rs:126-139"}, {"enemies.enemies[].defense", "honoured", "fight.rs:74-78"},
+        {"enemies.enemies[].exp", "honoured", "enemies.rs:308"}, {"enemies.enemies[].level", "honoured", "enemies.rs:303"},
+        {"enemies.enemies[].tile", "honoured", "core/src/lib.rs:150-155"}, {"enemies.enemies[].rarelity", "honoured", "enemies.rs:250-261"},
+        {"enemies.enemies[].gold", "inert", "copied into Enemy (enemies.rs:450), dropped by nothing"}, {"enemies.enemies[].name", "inert", "only inside GameMsg texts"},
+        {"enemies.appear_rate_gold", "honoured", "enemies.rs:297"}, {"enemies.appear_rate_nogold", "honoured", "enemies.rs:297"},
+    };
+    std::string s = "[";
+    for (size_t i = 0; i < sizeof K / sizeof K[0]; i++)
+        s += std::string(i ? ", " : "") + "{\"path\": " + rgjson::quote(K[i].path) + ", \"status\": \"" + K[i].status + "\", \"why\": " + rgjson::quote(K[i].why) + "}";
+    return s + "]";
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #define RG_MAX_ROOMS 32     // room_num_x * room_num_y (reference default 3x3; no limit there; 32 = the width of the room bitmasks)
 #define RG_MAX_ENEMY_KINDS 26
@@ -35,6 +36,14 @@ struct RgConfig {
     uint32_t gold_rate_inv, gold_base, gold_per_level, gold_minimum;
     uint32_t hunger_time;
     int32_t init_hp;
+    // Player::init_items resolved on the host (player.rs:136-153, item/mod.rs:181-221; rg_items.cpp): what the equipped weapon / armor and the
+    // pack contribute to the turn.  Defaults = the rogue pack: mace 2d4 +1,+1 (weapon.rs:179-188,200-203), ring mail 3 + 1 (armor.rs:68-73).
+    int32_t wpn_times, wpn_max;           // Item::at_weild of Player::weapon, or 1d4 bare hands (fight.rs:27-33)
+    int32_t wpn_hit_plus, wpn_dam_plus;   // Weapon::hit_plus / dam_plus (fight.rs:21-24)
+    int32_t armor_def;                    // Player::arm = def + def_plus of the equipped armor, 0 without one (player.rs:125-132)
+    uint32_t init_gold;                   // how_many of the pack's first Gold item (core/src/lib.rs:348-353)
+    int32_t can_pickup;                   // ItemBox::entry finds a Gold item to merge into or a free slot (itembox.rs:30-40); else gold stays on the floor
+    int32_t n_init_draws;                 // InitItem::Weapon entries: one `rng.range(init_num)` each on the item stream (weapon.rs:159); RgState::init_draws
     uint32_t appear_rate_gold, appear_rate_nogold;
     int32_t n_enemies;                            // length of the rarity-sorted table
     RgMonStat mon[RG_MAX_ENEMY_KINDS + 6];        // monster statuses, stable-sorted by rarity (enemies.rs:250-261)
@@ -57,10 +66,26 @@ struct RgParsed {
     uint32_t preset_gold[RG_MAX_ENEMY_KINDS + 6];
     int n_presets;
     bool enemies_given;
+    // item / player-pack configuration (rg_items.cpp)
+    std::vector<uint32_t> init_draws;  // (lo, hi) per InitItem::Weapon in list order: half-open init_num of the matched WeaponStatus
+    std::string weapon_json, armor_json, init_items_json;  // canonical re-serialisation of item.weapon / item.armor / player.init_items
+    bool weapon_default, armor_default, init_items_default;
+    uint64_t max_items;                // player.max_items (ItemBox capacity, player.rs:26-27,83)
+    int64_t init_str;                  // read by serde, never by the engine (StatusInner::from_config hard-codes 16, player.rs:284): carried for dump_config
+    uint32_t heal_threshold;           // likewise unused by the engine (Player::heal hard-codes 20, player.rs:221-240)
+    bool enable_trap;                  // dungeon.enable_trap: read by serde, no trap code exists (rogue/mod.rs:35)
+    bool exps_given;
+    std::string keymap_json;           // `keymap`: GameStateImpl::new overwrites it with KeyMap::ai (python/src/state_impls.rs:27); carried for dump_config
 };
 
 // Returns "" on success, else the error text ("Failed to parse config: ...").
 std::string rg_parse_config(const char *json, RgParsed *out);
-// true if a and b agree on every field the device code reads
-bool rg_config_equal(const RgConfig &a, const RgConfig &b);
+// true if a and b agree on everything the device code reads (the POD and the init-draw list)
+bool rg_config_equal(const RgParsed &a, const RgParsed &b);
+namespace rgjson { struct JVal; }
+// item.weapon / item.armor / player.{init_items,max_items} -> the resolved fields of cfg + init_draws + the canonical texts (rg_items.cpp).
+// item / player may be NULL (section absent).  Returns "" or the error text.
+std::string rg_resolve_items(const rgjson::JVal *item, const rgjson::JVal *player, RgParsed *out);
+// JSON array describing every GameConfig key the reference's serde structs know and what the stepper does with it (tests/test_config_schema.py)
+std::string rg_config_schema_json();
 std::string rg_dump_config_json(const RgParsed &p, uint64_t seed_lo, uint64_t seed_hi, bool has_seed);

@@ -767,10 +767,11 @@ __device__ __forceinline__ void build_prologue(const RgState &S, Env &E) {
     E.dlevel = 0;
 }
 __device__ __forceinline__ void build_epilogue(const RgState &S, const RgConfig &c, Env &E) {
-    // Player::init_items: mace 1..2, bow 1..2, arrow 8..17 on the item stream (weapon.rs:159,179-188)
-    (void)range32(E.ri, 1, 2); (void)range32(E.ri, 1, 2); (void)range32(E.ri, 8, 17);
+    // Player::init_items (player.rs:136-153): every InitItem::Weapon of the config draws `rng.range(init_num)` on the item stream, in list order
+    // (WeaponStatus::build, weapon.rs:159); the default pack is mace 1..2, bow 1..2, arrow 8..17 (weapon.rs:179-188).  Resolved by rg_items.cpp.
+    for (int i = 0; i < c.n_init_draws; i++) (void)range32(E.ri, S.init_draws[2 * i], S.init_draws[2 * i + 1]);
     E.hp = E.hpmax = c.init_hp; E.plvl = 1; E.exp = 0;
-    E.food = c.hunger_time; E.quiet = 0; E.gold = 0;
+    E.food = c.hunger_time; E.quiet = 0; E.gold = c.init_gold;
 }
 
 // Level generation service.  Generating a level is one long RNG-ordered chain of decisions and tile reads/writes with no parallelism across
@@ -1494,7 +1495,8 @@ __device__ __forceinline__ bool level_up(const RgConfig &c, Env &E, uint32_t exp
 }
 
 // actions::player_attack + fight::player_attack (actions.rs:140-166, fight.rs:6-39):
-// mace 2d4 hit+1 dam+1, strength 16 => +0/+0; the monster is always `running` by the time of the roll
+// the wielded weapon's dice / hit_plus / dam_plus (or bare hands 1d4; the default pack wields a mace 2d4 +1,+1) come resolved from the config
+// (rg_items.cpp); strength 16 => +0 / +0 (fight.rs:89-109); the monster is always `running` by the time of the roll
 __device__ __forceinline__ void player_attack(const RgState &S, const RgConfig &c, Env &E, int slot, uint32_t &react) {
     int idx = slot * E.n + E.e;
     uint32_t w = mon_rd<true>(S, E, slot);
@@ -1502,11 +1504,10 @@ __device__ __forceinline__ void player_attack(const RgState &S, const RgConfig &
     if (!((w >> 24) & MF_ACTIVE)) { w |= (uint32_t)MF_ACTIVE << 24; E.mon_active++; mon_wr<true>(S, E, slot, w); }
     uint32_t type = (w >> 16) & 0xff;
     int64_t def = (int64_t)c.mon[type].defense - (int64_t)lev_add_of(c, E.dlevel);
-    uint32_t rate = attack_rate(E.plvl, def, 1);
+    uint32_t rate = attack_rate(E.plvl, def, c.wpn_hit_plus);
     if (parcent(E.re, rate)) {
-        int dmg = (int)range64(E.re, 1, 5);
-        dmg += (int)range64(E.re, 1, 5);
-        dmg += 1;
+        int dmg = c.wpn_dam_plus;  // Dice::random (character/mod.rs:229-234): `times` rolls of 1..=max as i64, + dam_plus (fight.rs:66)
+        for (int t = 0; t < c.wpn_times; t++) dmg += (int)range64(E.re, 1, (uint64_t)c.wpn_max + 1);
         react |= MSG_HIT_TO;
         int hp = S.mon_hp[idx];
         if (hp <= dmg) {  // Enemy::get_damage (enemies.rs:205-213)
@@ -1669,7 +1670,8 @@ __device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c,
     E.px = nx; E.py = ny;
     react |= R_REDRAW;
     const uint32_t v = win_get(w, nk);
-    if (v & C_GOLD) {  // ItemBox::entry -> Merge into the pack's gold (itembox.rs:30-40)
+    if ((v & C_GOLD) && c.can_pickup) {  // ItemBox::entry -> Merge into the pack's gold, or its first free slot (itembox.rs:30-40); a full pack without
+                                         // a Gold item makes get_item return None and the gold stays on the floor (actions.rs:206-231)
         for (int s = 0; s < nrooms; s++) {
             uint32_t g = S.gold_pos[s * E.n + E.e];
             if (g == (POS(nx, ny) | 0x10000u)) { E.gold += S.gold_amt[s * E.n + E.e]; S.gold_pos[s * E.n + E.e] = 0; }
@@ -1872,7 +1874,7 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
     for (int i = 0; i < n_att; i++) {
         int s = (int)((att_list >> (5 * i)) & 31);
         uint32_t type = (mon_rd<true>(S, E, s) >> 16) & 0xff;
-        uint32_t rate = attack_rate((int64_t)c.mon[type].level + lev_add, 4 /* ring mail 3 + 1 */, 0 /* hit_prob_plus(10) */);
+        uint32_t rate = attack_rate((int64_t)c.mon[type].level + lev_add, c.armor_def /* Player::arm: the default pack wears ring mail 3 + 1 */, 0 /* hit_prob_plus(10) */);
         int sum = 0; bool hit = false;
         for (int k = 0; k < c.mon[type].n_att; k++) {
             if (!parcent(E.re, rate)) continue;
@@ -2155,7 +2157,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     } else if (valid) {
         if (terminal && c.auto_reset) {
             if (taken) {  // the status of a freshly built RunTime (GameConfig::build: level 1, Player::new + init_items, core/src/lib.rs:193-228)
-                E.dlevel = 1; E.gold = 0; E.hp = E.hpmax = c.init_hp; E.plvl = 1; E.exp = 0; E.food = c.hunger_time;
+                E.dlevel = 1; E.gold = c.init_gold; E.hp = E.hpmax = c.init_hp; E.plvl = 1; E.exp = 0; E.food = c.hunger_time;
             }
             write_status(S, c, E);
             S.dc_len[e] = 0; S.dc_head[e] = 0;  // a rebuilt RunTime owns a fresh DistCache

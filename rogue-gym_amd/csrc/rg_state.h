@@ -61,6 +61,8 @@ struct RgState {
                         //     (rng::gen_ranged_seed, core/src/lib.rs:157-165)
     uint32_t *build_ctr;          // [n] builds taken so far: build k of a reseed env uses hash(base, k); taken atomically, so k_step's inline
                                   //     generation and a concurrent k_regen never share or tear a seed
+    const uint32_t *init_draws;   // [cfg.n_init_draws][2]: (lo, hi) of the item-stream draw of every InitItem::Weapon of player.init_items, in list order
+                                  // (WeaponStatus::build, weapon.rs:159; resolved by rg_items.cpp); NULL when there is none
     uint64_t *range_lo, *range_span;  // [2][n] (low word, high word) of seed_range[0] and of seed_range[1] - seed_range[0]; NULL if no env has a range
     // rooms [RG_MAX_ROOMS][n]
     uint32_t *room_rect;  // x0 | y0<<8 | x1<<16 | y1<<24 (half-open; Empty: x0,y0 = up_left)

@@ -126,14 +126,56 @@ class HipVecRogueEnv:
                                           C.c_void_p(out.data_ptr())))
         return out
 
+    def init_comm(self, rank: Optional[int] = None, world: Optional[int] = None, unique_id: Optional[bytes] = None):
+        """Give the handle its own RCCL communicator (rg_comm_init), so that the one collective of the sharded path runs behind the C-ABI
+        (rg_allgather_compact: pack into this rank's slice, ncclAllGather in place on the handle's stream) -- the path a non-Python host
+        binds.  Without arguments the rank / world come from torch.distributed and rank 0's ncclUniqueId is broadcast through it; a host
+        without torch passes all three (the id from `HipVecRogueEnv.comm_unique_id()` on one rank)."""
+        import torch.distributed as dist
+
+        if rank is None or world is None:
+            rank, world = dist.get_rank(), dist.get_world_size()
+        if unique_id is None:
+            box = [self.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            unique_id = box[0]
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._h.check(self._h.L.rg_comm_init(self._h.h, buf, int(rank), int(world)))
+        self._comm = (int(rank), int(world))
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        L = inner.load_library()
+        buf = (C.c_uint8 * 128)()
+        if L.rg_comm_unique_id(buf):
+            raise RuntimeError("Error in rogue-gym: " + L.rg_last_error(None).decode())
+        return bytes(buf)
+
+    def all_gather_records(self, with_hist: bool = False):
+        """u8 [world * num_envs, record] on every rank through the handle's own communicator (init_comm): rg_allgather_compact."""
+        rank, world = self._comm
+        L, h = self._h.L, self._h.h
+        rec = L.rg_compact_record_bytes(h, int(with_hist))
+        key = ("gathered", bool(with_hist))
+        buf = self._scratch.get(key)
+        if buf is None:
+            buf = self._scratch[key] = self.torch.empty((world * self.num_envs, rec), dtype=self.torch.uint8, device=self.device)
+        self._h.check(L.rg_allgather_compact(h, int(with_hist), C.c_void_p(buf.data_ptr())))
+        return buf
+
     def all_gather_obs(self, compact: bool = True):
         """Whole-job observation batch f32 [world * num_envs, C, H, W] on every rank, env order = rank order -- the same type whatever the
         world size (world 1: this rank's own `obs`).  compact=True (default): ONE RCCL all-gather over xGMI of the packed records
-        (552 B per mini env instead of 2 KB .. 330 KB of f32), expanded on the consumer GPU by the HIP encode kernels;
+        (552 B per mini env instead of 2 KB .. 330 KB of f32), expanded on the consumer GPU by the HIP encode kernels -- through the
+        handle's own communicator when init_comm() was called (the C-ABI path), else through torch.distributed;
         compact=False gathers the f32 observation itself (xGMI-bound for the one-hot image)."""
         import torch.distributed as dist
 
         torch = self.torch
+        if compact and getattr(self, "_comm", None) is not None:
+            with_hist = bool(self.image_setting.includes_hist)
+            return self.expand_records(self.all_gather_records(with_hist), packed_has_hist=with_hist)
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return self.obs
         ws = dist.get_world_size()

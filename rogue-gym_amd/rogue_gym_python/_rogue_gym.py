@@ -42,8 +42,8 @@ _lib = None
 _INT_FUNCS = (
     "rg_create", "rg_dims", "rg_env_symbols", "rg_set_stream", "rg_seed", "rg_reset", "rg_step", "rg_step_prefix", "rg_sync", "rg_screen", "rg_hist", "rg_status", "rg_flags",
     "rg_reward", "rg_done", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_encode_host_batch", "rg_obs_host",
-    "rg_host_alloc", "rg_compact_record_bytes", "rg_pack_compact", "rg_expand_compact", "rg_status_vec", "rg_history_enable", "rg_history_keys",
-    "rg_dump_history", "rg_counters", "rg_probe_sclk", "rg_dump_config", "rg_config_canonical", "rg_debug_fetch", "rg_debug_descend", "rg_timing_enable", "rg_timing_read",
+    "rg_host_alloc", "rg_compact_record_bytes", "rg_pack_compact", "rg_expand_compact", "rg_comm_unique_id", "rg_comm_init", "rg_comm_destroy", "rg_allgather_compact", "rg_status_vec", "rg_history_enable", "rg_history_keys",
+    "rg_dump_history", "rg_counters", "rg_probe_sclk", "rg_dump_config", "rg_config_canonical", "rg_config_resolved", "rg_config_schema", "rg_debug_fetch", "rg_debug_descend", "rg_timing_enable", "rg_timing_read",
 )
 
 
@@ -87,12 +87,14 @@ def load_library():
         "rg_obs_host": [vp, i32, u32, i32, vp],
         "rg_host_alloc": [sz, C.POINTER(vp)], "rg_host_free": [vp],
         "rg_compact_record_bytes": [vp, i32], "rg_pack_compact": [vp, i32, vp], "rg_expand_compact": [vp, vp, i32, i32, i32, u32, i32, vp],
+        "rg_comm_unique_id": [vp], "rg_comm_init": [vp, vp, i32, i32], "rg_comm_destroy": [vp], "rg_allgather_compact": [vp, i32, vp],
         "rg_status_vec": [vp, u32, vp],
         "rg_history_enable": [vp, i32], "rg_history_keys": [vp, i32, i32, vp, sz, C.POINTER(u32)],
         "rg_dump_history": [vp, i32, i32, C.c_char_p, sz, C.POINTER(sz)],
         "rg_counters": [vp, C.POINTER(C.c_uint64), i32], "rg_probe_sclk": [vp, C.POINTER(C.c_double)],
         "rg_timing_enable": [vp, i32], "rg_timing_read": [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
         "rg_dump_config": [vp, i32, C.c_char_p, sz], "rg_config_canonical": [C.c_char_p, C.c_char_p, sz],
+        "rg_config_resolved": [C.c_char_p, C.c_char_p, sz], "rg_config_schema": [C.c_char_p, sz, C.POINTER(sz)],
         "rg_debug_fetch": [vp, i32, C.POINTER(RgDebugState), vp], "rg_debug_descend": [vp],
     }
     for name, argtypes in sig.items():
@@ -140,9 +142,30 @@ class _PinnedPool:
         self.free = {}
 
 
-def _view(ptr, shape, dtype):
-    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
-    return np.frombuffer((C.c_uint8 * n).from_address(ptr), dtype=dtype).reshape(shape)
+class _Lease:
+    """One pooled pinned buffer on loan.  It goes back to the pool when the LAST array that views it is collected -- not when the StateBatch
+    that asked for it is: `obs = env.images()` kept in a rollout buffer stays valid (and unchanged) for as long as the caller holds it, like the
+    independent arrays the reference returns (python/src/lib.rs:78,95)."""
+    __slots__ = ("pool", "ptr", "nbytes")
+
+    def __init__(self, pool, nbytes):
+        self.pool, self.nbytes = pool, nbytes
+        self.ptr = pool.take(nbytes)
+
+    def __del__(self):
+        try:
+            self.pool.give(self.ptr, self.nbytes)  # a closed pool frees it instead (hipHostFree)
+        except Exception:
+            pass
+
+
+def _leased(pool, shape, dtype):
+    """A numpy array over a freshly leased pinned buffer; every view / slice of it keeps the lease (numpy base -> ctypes array -> lease)."""
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    lease = _Lease(pool, nbytes)
+    raw = (C.c_uint8 * nbytes).from_address(lease.ptr)
+    raw._lease = lease
+    return np.frombuffer(raw, dtype=dtype).reshape(shape)
 
 
 class _Handle:
@@ -240,24 +263,15 @@ class StateBatch:
         self._hd = handle
         n, h, w = handle.n, handle.height, handle.width
         self.n, self.symbols = n, handle.symbols
-        sizes = (n * h * w, n * h * w, n * 40, n * 4)
-        self._bufs = [(handle.pool.take(b), b) for b in sizes]
-        p = [b[0] for b in self._bufs]
-        handle.check(handle.L.rg_fetch_states(handle.h, p[0], p[1], p[2], p[3]))
-        self.screen = _view(p[0], (n, h, w), np.uint8)
-        self.hist = _view(p[1], (n, h, w), np.uint8)
-        self.status = _view(p[2], (n, 10), np.int32)
-        self.flags = _view(p[3], (n,), np.uint32)
+        # pinned, pooled buffers; each array owns its lease, so an array (or any slice of it) a caller keeps outlives this batch safely
+        self.screen = _leased(handle.pool, (n, h, w), np.uint8)
+        self.hist = _leased(handle.pool, (n, h, w), np.uint8)
+        self.status = _leased(handle.pool, (n, 10), np.int32)
+        self.flags = _leased(handle.pool, (n,), np.uint32)
+        handle.check(handle.L.rg_fetch_states(handle.h, self.screen.ctypes.data, self.hist.ctypes.data, self.status.ctypes.data, self.flags.ctypes.data))
         self._epoch = handle.epoch
         self._items = {}
         self._images = {}
-
-    def __del__(self):
-        try:
-            for ptr, nbytes in self._bufs:
-                self._hd.pool.give(ptr, nbytes)
-        except Exception:
-            pass
 
     def __len__(self):
         return self.n
@@ -311,9 +325,7 @@ class StateBatch:
         c = (self.symbols if kind else 1) + bin(flag).count("1") + (1 if with_hist else 0)
         nbytes = self.n * c * h * w * 4
         if nbytes <= _IMAGE_BATCH_LIMIT and not hd.pool.closed:  # pinned, pooled: a fresh 16 MB numpy array per step costs more in page faults than the copy
-            ptr = hd.pool.take(nbytes)
-            self._bufs.append((ptr, nbytes))
-            img = _view(ptr, (self.n, c, h, w), np.float32)
+            img = _leased(hd.pool, (self.n, c, h, w), np.float32)
         else:
             img = np.empty((self.n, c, h, w), np.float32)
         if hd.h is not None and hd.epoch == self._epoch:

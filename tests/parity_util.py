@@ -73,6 +73,7 @@ def compare_internal(hip, oracles, envs, where=""):
         sc = o.scalars()
         got = dict(px=d.px, py=d.py, level=d.dungeon_level, hp=d.hp, hp_max=d.hp_max, exp=d.exp, plevel=d.player_level, food_left=d.food_left,
                    quiet=d.quiet, gold=d.pack_gold, n_monsters=d.n_monsters)
+        sc = {k: sc[k] for k in got}  # (the oracle also reports its pack: n_pack / weapon_slot / armor_slot have no device-side counterpart)
         assert got == sc, "%s env %d scalars %s vs %s" % (where, i, got, sc)
         assert d.steps == o.flags()["steps"], "%s env %d steps" % (where, i)
         rs, _ = o.rng()
