@@ -44,8 +44,10 @@ typedef struct rg_handle rg_t;
 
 /* Replaces GameState::__new__ / ParallelGameState::new (python/src/lib.rs:217-225,270-294) and
  * ThreadConductor::new (thread_impls.rs:14-34): parses one GameConfig JSON per env
- * (core/src/lib.rs:42-86).  Envs may differ in anything but width / height: envs with equal configs (seeds aside) form a group that is
- * stepped as one homogeneous batch, and the handle presents all groups in the caller's env order.  Allocates the SoA
+ * (core/src/lib.rs:42-86).  Envs may differ in anything: envs with equal configs (seeds aside) form a group that is
+ * stepped as one homogeneous batch, and the handle presents all groups in the caller's env order.  When the groups differ in width / height
+ * there is no [n_env][H][W] tensor: rg_screen / rg_hist / rg_obs_* / rg_pack_compact / rg_expand_compact / rg_obs_host then fail with a message
+ * that says so, and rg_fetch_states delivers the screens in a ragged layout (rg_env_dims); everything else works unchanged.  Allocates the SoA
  * state for n_env environments on HIP device `device`, generates every level-1 dungeon and
  * draws the first screens.  auto_reset != 0 selects ThreadConductor::step semantics (terminal
  * envs are rebuilt inside rg_step and report the post-reset state with is_terminal forced
@@ -58,6 +60,8 @@ const char *rg_last_error(const rg_t *h);
 
 /* GameState::screen_size / symbols (python/src/lib.rs:226-228,255-257,295-300) */
 int rg_dims(const rg_t *h, int *height, int *width, int *symbols, int *n_env);
+/* Height and width of every env's own config (host arrays of n_env i32; either may be NULL).  Equal for all envs unless the batch mixes sizes. */
+int rg_env_dims(const rg_t *h, int32_t *heights, int32_t *widths);
 /* `symbols` of every env's own config (GameStateImpl::new computes it per env, state_impls.rs:21-25; PlayerState.symbols): out_host = i32 [n_env].
  * rg_dims reports env 0's, like ParallelGameState::symbols (python/src/lib.rs:281-285,298-300). */
 int rg_env_symbols(const rg_t *h, int32_t *out_host);
@@ -109,7 +113,8 @@ int rg_obs_channels(const rg_t *h, int symbol, uint32_t status_flag, int with_hi
 int rg_status_vec(rg_t *h, uint32_t status_flag, int32_t *out_host);
 
 /* Host copies for the value-object API (ParallelGameState::states/step return Vec<PlayerState>):
- * synchronous D2H of the mirrors; any pointer may be NULL. */
+ * synchronous D2H of the mirrors; any pointer may be NULL.  screen / hist: u8 [n_env][H][W]; for a batch that mixes sizes the envs follow
+ * each other in env order, env i taking H_i * W_i bytes (rg_env_dims). */
 int rg_fetch_states(rg_t *h, uint8_t *screen, uint8_t *hist, int32_t *status, uint32_t *flags);
 
 /* Stateless encode of ONE host-side PlayerState snapshot on the GPU (PlayerState.gray_image &c.

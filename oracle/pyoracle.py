@@ -381,6 +381,15 @@ class OracleEnv:
         return self._image(self._L.orc_symbol_image, self.symbols, flag, with_hist)
 
 
+def kat_edges(xr, yr, direction, inclusive=True):
+    """passages::edges on RectRange::from_ranges(xr, yr); direction in ("Up", "Down", "Left", "Right")."""
+    xs, ys = (C.c_int * 256)(), (C.c_int * 256)()
+    L = lib()
+    L.orc_kat_edges.argtypes = [C.c_int] * 6 + [C.c_void_p] * 2
+    n = L.orc_kat_edges(xr[0], yr[0], xr[1], yr[1], ["Up", "Down", "Left", "Right"].index(direction), int(inclusive), xs, ys)
+    return [[xs[i], ys[i]] for i in range(n)]
+
+
 def kat_u32(seed, n):
     out = np.empty(n, np.uint32)
     lib().orc_kat_u32(seed & 0xFFFFFFFFFFFFFFFF, seed >> 64, n, out.ctypes.data)

@@ -412,6 +412,10 @@ static int edges(const rect_t *range, int direction, int inclusive, int *xs, int
     }
     return n;
 }
+int orc_kat_edges(int x0, int y0, int x1, int y1, int direction, int inclusive, int *xs, int *ys) { /* for passages.rs:272-296 */
+    rect_t r = {x0, y0, x1, y1};
+    return edges(&r, direction, inclusive, xs, ys);
+}
 static int maze_has_cd(const room_t *rm, int x, int y) { int id = rect_index(&rm->range, x, y); return id >= 0 && rm->maze_passages[id]; }
 /* select_start_or_end (passages.rs:143-179) */
 static void select_start_or_end(orc_env *e, const room_t *rm, int direction, int *ox, int *oy) {

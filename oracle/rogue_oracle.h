@@ -126,6 +126,9 @@ void orc_rng(const orc_env *e, uint32_t state[12], uint64_t counts[3]);
 /* Dungeon::move_enemy with skip = |_| false (rogue/mod.rs:339-375), for the reference KAT
  * rogue/mod.rs:566-578.  Returns 0 CantMove, 1 CanMove (nx,ny set), 2 Reach. */
 int orc_move_enemy_kat(orc_env *e, int fx, int fy, int tx, int ty, int *nx, int *ny);
+/* passages::edges (passages.rs:181-219) on the half-open rect [x0,x1) x [y0,y1), for the reference KAT passages.rs:272-296.
+ * direction: 0 Up 1 Down 2 Left 3 Right (Direction order, coord.rs:198-208).  Returns the number of cells written to xs / ys. */
+int orc_kat_edges(int x0, int y0, int x1, int y1, int direction, int inclusive, int *xs, int *ys);
 /* test hook: generate the next level and place the player as on a successful '>' (actions.rs:27-33,121-138) without the turn around it */
 void orc_debug_descend(orc_env *e);
 

@@ -64,6 +64,9 @@ struct rg_handle {
     uint8_t *d_keys_sub = nullptr;     // (sub-handle) keys of its envs gathered from the handle's key vector
     int planes_sym = 0;                // one-hot depth of the handle's symbol image (= symbols of env 0's config, like ParallelGameState::symbols)
     bool screens_stale = true;         // (parent) S.screen / S.hist / S.flags need assembling
+    bool mixed = false;                // (parent) the groups differ in width / height (python/src/lib.rs:270-294 takes ANY GameConfig per env): there is no
+                                       // [n_env][H][W] tensor then -- screens travel as ragged host copies (rg_fetch_states), the tensor entry points refuse
+    std::vector<size_t> ragged_off;    // (mixed parent) [n + 1] byte offset of env i's H_i * W_i screen in the ragged env-order layout
     size_t stat_rows = 0;        // workload counters: one row of 8 per k_step block (summed by rg_counters)
     RgState *d_SP = nullptr;     // device-resident copy of SP: k_step reads the spare's pointers from it on the rare take path (one kernel argument
                                  // instead of a second 60-pointer struct in SGPRs)
@@ -93,6 +96,7 @@ struct TimedLaunch {  // times one kernel launch with an event pair when timing 
     }
     hipEvent_t start_ev() const { return on && ext_ ? h->ev[k][h->ev_used[k]] : nullptr; }
     hipEvent_t stop_ev() const { return on && ext_ ? h->ev[k][h->ev_used[k] + 1] : nullptr; }
+    void cancel() { on = false; }  // nothing was launched: leave the (unrecorded) pair unused
     void stop() { if (on) { if (!ext_) (void)hipEventRecord(h->ev[k][h->ev_used[k] + 1], h->stream); h->ev_used[k] += 2; on = false; } }
     ~TimedLaunch() { stop(); }
 };
@@ -286,8 +290,10 @@ static int assemble_screens(rg_handle *h) {
     for (rg_handle *sh : h->sub) {
         SUBCHK(h, sh, flush_render(sh));
         const int m = sh->S.n;
-        rgk_scatter_rows(sh->S.screen, h->S.screen, sh->d_ext, m, h->S.hw, h->stream);
-        rgk_scatter_rows(sh->S.hist, h->S.hist, sh->d_ext, m, h->S.hw, h->stream);
+        if (!h->mixed) {  // (a mixed-size batch has no common screen tensor: its screens stay with the groups, rg_fetch_states reads them there)
+            rgk_scatter_rows(sh->S.screen, h->S.screen, sh->d_ext, m, h->S.hw, h->stream);
+            rgk_scatter_rows(sh->S.hist, h->S.hist, sh->d_ext, m, h->S.hw, h->stream);
+        }
         rgk_scatter_rows(sh->S.flags, h->S.flags, sh->d_ext, m, 4, h->stream);
     }
     HIPCHK(h, hipGetLastError());
@@ -323,15 +329,11 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
         }
     }
     if (reps.size() == 1) return create_homog(reps[0], seeds.data(), n_env, max_steps, device, auto_reset, out);
-    for (size_t k = 1; k < reps.size(); k++)
-        if (reps[k].cfg.width != reps[0].cfg.width || reps[k].cfg.height != reps[0].cfg.height) {
-            g_create_err = "configs of one batch must share width and height (env " + std::to_string(members[k][0]) + " is " + std::to_string(reps[k].cfg.width) + "x" +
-                           std::to_string(reps[k].cfg.height) + ", env " + std::to_string(members[0][0]) + " is " + std::to_string(reps[0].cfg.width) + "x" +
-                           std::to_string(reps[0].cfg.height) + "): the batch is exposed as [n_env][H][W] tensors";
-            return 1;
-        }
+    bool mixed = false;
+    for (size_t k = 1; k < reps.size(); k++) mixed = mixed || reps[k].cfg.width != reps[0].cfg.width || reps[k].cfg.height != reps[0].cfg.height;
     rg_handle *h = new rg_handle();
     h->device = device;
+    h->mixed = mixed;
     h->g_of = g_of; h->l_of = l_of;
     for (size_t k = 0; k < reps.size(); k++) {
         std::vector<EnvSeed> gs(members[k].size());
@@ -345,6 +347,10 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
         if (!ok) { g_create_err = "device allocation failed"; destroy_handle(h); return 1; }
         sh->S.ext = sh->d_ext;
     }
+    if (mixed) {
+        h->ragged_off.assign((size_t)n_env + 1, 0);
+        for (int i = 0; i < n_env; i++) h->ragged_off[i + 1] = h->ragged_off[i] + (size_t)reps[g_of[i]].cfg.width * reps[g_of[i]].cfg.height;
+    }
     rg_handle *first = h->sub[g_of[0]];
     h->parsed = first->parsed; h->cfg = first->cfg;
     h->planes_sym = first->cfg.symbols;  // ParallelGameState::new takes `symbols` from configs[0] (python/src/lib.rs:281-285)
@@ -353,7 +359,7 @@ int rg_create(const char *const *cfg_json, int n_env, uint64_t max_steps, int de
     memset(&S, 0, sizeof S);
     const size_t n = (size_t)n_env, hw = (size_t)h->cfg.width * h->cfg.height;
     S.n = n_env; S.hw = (int)hw; S.n_keys = n_env;
-    bool ok = dev_alloc(h, &S.screen, n * hw) && dev_alloc(h, &S.hist, n * hw) && dev_alloc(h, &S.status, n * 10) && dev_alloc(h, &S.flags, n) &&
+    bool ok = (mixed || (dev_alloc(h, &S.screen, n * hw) && dev_alloc(h, &S.hist, n * hw))) && dev_alloc(h, &S.status, n * 10) && dev_alloc(h, &S.flags, n) &&
               dev_alloc(h, &S.reward, n) && dev_alloc(h, &S.done, n) && dev_alloc(h, &h->d_err, 4) && dev_alloc(h, &h->d_probe, 4);
     if (!ok) { g_create_err = h->err; destroy_handle(h); return 1; }
     S.err_any = h->d_err;
@@ -385,6 +391,22 @@ int rg_dims(const rg_t *h, int *height, int *width, int *symbols, int *n_env) {
     if (symbols) *symbols = h->planes_sym;
     if (n_env) *n_env = h->S.n;
     return 0;
+}
+
+int rg_env_dims(const rg_t *h, int32_t *heights, int32_t *widths) {
+    for (int i = 0; i < h->S.n; i++) {
+        const RgConfig &c = h->sub.empty() ? h->cfg : h->sub[h->g_of[i]]->cfg;
+        if (heights) heights[i] = c.height;
+        if (widths) widths[i] = c.width;
+    }
+    return 0;
+}
+// the entry points that hand out or fill [n_env][..][H][W] tensors cannot serve a batch whose envs differ in width / height
+static bool refuse_mixed(rg_handle *h, const char *what) {
+    if (!h->mixed) return false;
+    h->err = std::string(what) + ": the envs of this batch differ in width / height, so there is no [n_env][H][W] tensor (per-env sizes: rg_env_dims; "
+             "ragged host copies: rg_fetch_states; or one handle per size)";
+    return true;
 }
 
 int rg_env_symbols(const rg_t *h, int32_t *out_host) {
@@ -535,8 +557,8 @@ int rg_sync(rg_t *h) {
 
 // mirrors up to date: the pending render of an ordinary handle, the assembly of a parent's
 static int flush_mirrors(rg_handle *h) { return h->sub.empty() ? flush_render(h) : assemble_screens(h); }
-int rg_screen(rg_t *h, uint8_t **dev) { HIPCHK(h, hipSetDevice(h->device)); if (flush_mirrors(h)) return 1; *dev = h->S.screen; return 0; }
-int rg_hist(rg_t *h, uint8_t **dev) { HIPCHK(h, hipSetDevice(h->device)); if (flush_mirrors(h)) return 1; *dev = h->S.hist; return 0; }
+int rg_screen(rg_t *h, uint8_t **dev) { if (refuse_mixed(h, "rg_screen")) return 1; HIPCHK(h, hipSetDevice(h->device)); if (flush_mirrors(h)) return 1; *dev = h->S.screen; return 0; }
+int rg_hist(rg_t *h, uint8_t **dev) { if (refuse_mixed(h, "rg_hist")) return 1; HIPCHK(h, hipSetDevice(h->device)); if (flush_mirrors(h)) return 1; *dev = h->S.hist; return 0; }
 int rg_status(rg_t *h, int32_t **dev) { *dev = h->S.status; return 0; }
 int rg_flags(rg_t *h, uint32_t **dev) { HIPCHK(h, hipSetDevice(h->device)); if (flush_mirrors(h)) return 1; *dev = h->S.flags; return 0; }
 int rg_reward(rg_t *h, float **dev) { *dev = h->S.reward; return 0; }
@@ -547,6 +569,7 @@ int rg_obs_channels(const rg_t *h, int symbol, uint32_t status_flag, int with_hi
 }
 
 static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, float *out_dev) {
+    if (refuse_mixed(h, kind ? "rg_obs_symbol" : "rg_obs_gray")) return 1;
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->sub.empty()) {  // every group encodes its envs straight into the handle's tensor (RgState::ext)
         for (rg_handle *sh : h->sub) {
@@ -573,7 +596,7 @@ static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, fl
             h->render_pending = false;
             return 0;
         }
-        t.on = false;
+        t.cancel();  // H*W % 8 != 0: nothing was launched, the fallback below brackets its own pair
     }
     if (flush_render(h)) return 1;
     {
@@ -591,6 +614,21 @@ int rg_fetch_states(rg_t *h, uint8_t *screen, uint8_t *hist, int32_t *status, ui
     HIPCHK(h, hipSetDevice(h->device));
     if (flush_mirrors(h)) return 1;
     size_t n = (size_t)h->S.n, hw = (size_t)h->S.hw;
+    if (h->mixed) {  // ragged env-order layout: env i's H_i x W_i bytes at ragged_off[i] (rg_env_dims); group by group, rows scattered on the host
+        std::vector<uint8_t> tmp;
+        for (rg_handle *sh : h->sub) {
+            const size_t m = (size_t)sh->S.n, ghw = (size_t)sh->S.hw;
+            for (int which = 0; which < 2; which++) {
+                uint8_t *dst = which ? hist : screen;
+                if (!dst) continue;
+                tmp.resize(m * ghw);
+                HIPCHK(h, hipMemcpyAsync(tmp.data(), which ? sh->S.hist : sh->S.screen, m * ghw, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                for (size_t l = 0; l < m; l++) memcpy(dst + h->ragged_off[sh->ext[l]], tmp.data() + l * ghw, ghw);
+            }
+        }
+        screen = hist = nullptr;
+    }
     if (screen) HIPCHK(h, hipMemcpyAsync(screen, h->S.screen, n * hw, hipMemcpyDeviceToHost, h->stream));
     if (hist) HIPCHK(h, hipMemcpyAsync(hist, h->S.hist, n * hw, hipMemcpyDeviceToHost, h->stream));
     if (status) HIPCHK(h, hipMemcpyAsync(status, h->S.status, n * 40, hipMemcpyDeviceToHost, h->stream));
@@ -655,6 +693,7 @@ int rg_encode_host(int device, const uint8_t *screen, const uint8_t *hist, const
 // PlayerState images of the whole batch into host memory (the value-object API's batched path): the fused k_obs pass into a device scratch
 // kept by the handle, then one D2H copy.  out_host should be pinned (rg_host_alloc) for full PCIe rate.
 int rg_obs_host(rg_t *h, int kind, uint32_t status_flag, int with_hist, float *out_host) {
+    if (refuse_mixed(h, "rg_obs_host")) return 1;
     HIPCHK(h, hipSetDevice(h->device));
     const size_t bytes = (size_t)h->S.n * rg_obs_channels(h, kind, status_flag, with_hist) * h->S.hw * 4;
     if (h->obs_scratch_cap < bytes) {
@@ -677,6 +716,7 @@ void rg_host_free(void *p) { if (p) (void)hipHostFree(p); }
 int rg_compact_record_bytes(const rg_t *h, int with_hist) { return h->S.hw + 40 + (with_hist ? h->S.hw : 0); }
 
 int rg_pack_compact(rg_t *h, int with_hist, uint8_t *out_dev) {
+    if (refuse_mixed(h, "rg_pack_compact")) return 1;
     HIPCHK(h, hipSetDevice(h->device));
     if (h->S.hw & 3) { h->err = "rg_pack_compact needs H*W divisible by 4"; return 1; }
     if (flush_mirrors(h)) return 1;
@@ -768,6 +808,7 @@ int rg_allgather_compact(rg_t *h, int with_hist, uint8_t *out_dev) {
 }
 
 int rg_expand_compact(rg_t *h, const uint8_t *packed_dev, int n, int packed_has_hist, int kind, uint32_t status_flag, int with_hist, float *out_dev) {
+    if (refuse_mixed(h, "rg_expand_compact")) return 1;
     HIPCHK(h, hipSetDevice(h->device));
     if (h->S.hw & 3) { h->err = "rg_expand_compact needs H*W divisible by 4"; return 1; }
     if (with_hist && !packed_has_hist) { h->err = "rg_expand_compact: the packed batch carries no history plane"; return 1; }

@@ -40,6 +40,8 @@ __device__ __forceinline__ uint32_t tile_to_sym(uint32_t t) {
 
 // exact n / d for the small non-negative operands of this engine (n < 2^20, 0 < d < 2^12): one v_rcp instead of the
 // ~30-instruction integer division sequence
+// (v_rcp_f32 instead of the IEEE-rounded reciprocal would also be exact for n < 2^21 and saves ~10 instructions per call: measured neutral,
+// k_build 54.1 vs 54.4 us per level, 524 vs 524 M env-steps/s -- round 3)
 __device__ __forceinline__ int small_div(int n, int d) { return (int)(((float)n + 0.5f) * __frcp_rn((float)d)); }
 
 #define POS(x, y) ((uint32_t)(((x) << 8) | (y)))

@@ -2265,7 +2265,7 @@ void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const 
     static const int epw_env = getenv("ROGUE_GYM_HIP_EPW") ? atoi(getenv("ROGUE_GYM_HIP_EPW")) : 0;
     int epw = WAVE;
     while (epw > 16 && (S->n + epw - 1) / epw < 1024) epw >>= 1;
-    if (epw_env >= 8 && epw_env <= 64) epw = epw_env;
+    if (epw_env >= 16 && epw_env <= 64) epw = epw_env;  // (>= 16: S.stats has one row per block of the largest grid, STAIR_BLOCKS + ceil(n / 16); rg_api.cpp)
     // parity >= 0: stair isolation with the list the last render / observation pass wrote into set `parity`
     const int nb = (S->n + epw - 1) / epw;
     const dim3 grid(parity >= 0 ? STAIR_BLOCKS + nb : nb), block(WAVE);

@@ -40,7 +40,7 @@ class RgDebugState(C.Structure):
 _lib = None
 
 _INT_FUNCS = (
-    "rg_create", "rg_dims", "rg_env_symbols", "rg_set_stream", "rg_seed", "rg_reset", "rg_step", "rg_step_prefix", "rg_sync", "rg_screen", "rg_hist", "rg_status", "rg_flags",
+    "rg_create", "rg_dims", "rg_env_dims", "rg_env_symbols", "rg_set_stream", "rg_seed", "rg_reset", "rg_step", "rg_step_prefix", "rg_sync", "rg_screen", "rg_hist", "rg_status", "rg_flags",
     "rg_reward", "rg_done", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_encode_host_batch", "rg_obs_host",
     "rg_host_alloc", "rg_compact_record_bytes", "rg_pack_compact", "rg_expand_compact", "rg_comm_unique_id", "rg_comm_init", "rg_comm_destroy", "rg_allgather_compact", "rg_status_vec", "rg_history_enable", "rg_history_keys",
     "rg_dump_history", "rg_counters", "rg_probe_sclk", "rg_dump_config", "rg_config_canonical", "rg_config_resolved", "rg_config_schema", "rg_debug_fetch", "rg_debug_descend", "rg_timing_enable", "rg_timing_read",
@@ -71,7 +71,7 @@ def load_library():
         "rg_destroy": [vp],
         "rg_last_error": [vp],
         "rg_dims": [vp] + [C.POINTER(i32)] * 4,
-        "rg_env_symbols": [vp, vp],
+        "rg_env_symbols": [vp, vp], "rg_env_dims": [vp, vp, vp],
         "rg_set_stream": [vp, vp],
         "rg_seed": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i32],
         "rg_reset": [vp],
@@ -193,6 +193,9 @@ class _Handle:
         self.env_symbols = np.empty(self.n, np.int32)  # per env: configs of one batch may differ (PlayerState.symbols is the env's own)
         L.rg_env_symbols(h, self.env_symbols.ctypes.data)
         self.uniform_symbols = bool((self.env_symbols == self.symbols).all())
+        self.env_heights, self.env_widths = np.empty(self.n, np.int32), np.empty(self.n, np.int32)  # ... and in size (python/src/lib.rs:270-294)
+        L.rg_env_dims(h, self.env_heights.ctypes.data, self.env_widths.ctypes.data)
+        self.mixed_sizes = bool((self.env_heights != self.height).any() or (self.env_widths != self.width).any())
         self.pool = _PinnedPool(L)
         self.epoch = 0  # bumped by every call that changes the device-side states (a StateBatch remembers the epoch it was taken at)
 
@@ -264,11 +267,20 @@ class StateBatch:
         n, h, w = handle.n, handle.height, handle.width
         self.n, self.symbols = n, handle.symbols
         # pinned, pooled buffers; each array owns its lease, so an array (or any slice of it) a caller keeps outlives this batch safely
-        self.screen = _leased(handle.pool, (n, h, w), np.uint8)
-        self.hist = _leased(handle.pool, (n, h, w), np.uint8)
         self.status = _leased(handle.pool, (n, 10), np.int32)
         self.flags = _leased(handle.pool, (n,), np.uint32)
-        handle.check(handle.L.rg_fetch_states(handle.h, self.screen.ctypes.data, self.hist.ctypes.data, self.status.ctypes.data, self.flags.ctypes.data))
+        self.mixed_sizes = handle.mixed_sizes
+        if not self.mixed_sizes:
+            self.screen = _leased(handle.pool, (n, h, w), np.uint8)
+            self.hist = _leased(handle.pool, (n, h, w), np.uint8)
+            sp, hp = self.screen.ctypes.data, self.hist.ctypes.data
+        else:  # envs of different width / height (ParallelGameState::new takes any config per env): ragged buffers, `screen` / `hist` are lists of per-env views
+            off = np.concatenate(([0], np.cumsum(handle.env_heights.astype(np.int64) * handle.env_widths)))
+            rs, rh = _leased(handle.pool, (int(off[-1]),), np.uint8), _leased(handle.pool, (int(off[-1]),), np.uint8)
+            self.screen = [rs[off[i]:off[i + 1]].reshape(handle.env_heights[i], handle.env_widths[i]) for i in range(n)]
+            self.hist = [rh[off[i]:off[i + 1]].reshape(handle.env_heights[i], handle.env_widths[i]) for i in range(n)]
+            sp, hp = rs.ctypes.data, rh.ctypes.data
+        handle.check(handle.L.rg_fetch_states(handle.h, sp, hp, self.status.ctypes.data, self.flags.ctypes.data))
         self._epoch = handle.epoch
         self._items = {}
         self._images = {}
@@ -286,7 +298,7 @@ class StateBatch:
         st = self._items.get(i)
         if st is None:
             st = self._items[i] = PlayerState(self.screen[i], self.hist[i], self.status[i], int(self._hd.env_symbols[i]), int(self.flags[i]), self._hd.device,
-                                              batch=self, index=i, batch_images=self._hd.uniform_symbols)
+                                              batch=self, index=i, batch_images=self._hd.uniform_symbols and not self.mixed_sizes)
         return st
 
     def __iter__(self):
@@ -319,6 +331,9 @@ class StateBatch:
         key = (int(kind), flag, bool(with_hist))
         img = self._images.get(key)
         if img is not None:
+            return img
+        if self.mixed_sizes:  # no common [N, C, H, W]: one image per env, each in its own size (what the reference's per-state expand gives)
+            img = self._images[key] = [self[i]._image(kind, flag, with_hist) for i in range(self.n)]
             return img
         hd, L = self._hd, self._hd.L
         h, w = self.screen.shape[1:]

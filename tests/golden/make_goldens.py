@@ -47,7 +47,7 @@ def actions_to_keys(acts):
 
 
 golden = {
-    "_source": "python/tests/data.py, test_ff_env.py:14-22, test_st_env.py:27-37, test_parallel.py:51-60, core/src/dungeon/rogue/mod.rs:566-578",
+    "_source": "python/tests/data.py, test_ff_env.py:14-22, test_st_env.py:27-37, test_parallel.py:51-60, core/src/dungeon/rogue/mod.rs:566-578, core/src/dungeon/rogue/passages.rs:272-296",
     "screens": {
         "SEED1_DUNGEON2": refdata.SEED1_DUNGEON2,
         "SEED1_DUNGEON3": refdata.SEED1_DUNGEON3,
@@ -77,6 +77,11 @@ golden = {
                "second": {"keys": "CMD_STR4", "reward_with_stair100": 100.0, "image_shape": [21, 16, 32],
                           "plane17": 3.0, "plane18": 12.0, "status_vec_full": [3, 12, 12, 16, 16, 0, 1, 0, 0]}},
         "move_enemy_kat": {"from": [9, 9], "to": [28, 4], "next": [10, 9]},
+        # core/src/dungeon/rogue/passages.rs:272-296 `test_inclusive_edges`: RectRange 5..10 x 6..9, inclusive edges per direction
+        # (pins rect-iter's corner naming: "upper" = y1 - 1)
+        "inclusive_edges": {"range": {"x": [5, 10], "y": [6, 9]},
+                            "Down": [[x, 8] for x in range(6, 9)], "Up": [[x, 6] for x in range(6, 9)],
+                            "Left": [[5, y] for y in range(7, 8)], "Right": [[9, y] for y in range(7, 8)]},
         "shapes": {"symbol_hist_noenem": [18, 24, 80], "gray": [1, 24, 80], "gray_hist": [2, 24, 80], "space_noenem_full": [26, 24, 80]},
     },
     "ddqn_keys": actions_to_keys(load("data/learned/ddqn-minidungeon/best-actions.json")),

@@ -53,8 +53,8 @@ def test_config_errors_come_before_device_errors(lib):
     assert rc != 0 and msg.startswith("Failed to parse config")
     rc, msg, _ = _create(lib, ['{"dungeon": {"style": "nethack"}}'])
     assert rc != 0 and "nethack" in msg
-    rc, msg, _ = _create(lib, ['{"seed": 1}', '{"seed": 2, "width": 40}'])  # per-env configs may differ in anything but the screen size
-    assert rc != 0 and "share width and height" in msg
+    rc, msg, _ = _create(lib, ['{"seed": 1}', '{"seed": 2, "width": 40}'])  # per-env configs may differ in anything, the screen size included
+    assert rc == 0 or "no HIP device" in msg
     rc, msg, _ = _create(lib, ['{"seed": 1}', '{"seed": 2, "enemies": {"enemies": []}}'])  # a legal mixed batch: only the missing GPU stops it here
     assert rc == 0 or "no HIP device" in msg
 

@@ -554,3 +554,47 @@ def test_mixed_packs_behind_one_handle(goldens):
                 assert np.array_equal(st.screen[i], o.screen()), (t, i, names[i % len(names)])
                 assert [int(v) & 0xFFFFFFFF for v in st.status[i]] == [int(v) for v in o.status_arr()], (t, i, names[i % len(names)])
     game.close()
+
+
+def test_mixed_screen_sizes_behind_one_handle(goldens):
+    """ParallelGameState::new takes ANY GameConfig per env (python/src/lib.rs:270-294), also configs of different width / height: every env
+    then steps on its own grid, `screen_size()` is configs[0]'s (lib.rs:295-297), the states are per-env PlayerState objects of their own
+    shape, and the entry points that need one [N, H, W] tensor say why they cannot serve this batch."""
+    from oracle.pyoracle import OracleEnv
+    from rogue_gym.envs import DungeonType, HipVecRogueEnv, ImageSetting, StatusFlag
+    from rogue_gym_python._rogue_gym import ParallelGameState
+
+    shapes = [dict(goldens["configs"]["mini"]), {"width": 80, "height": 24}, {"width": 48, "height": 20, "dungeon": {"style": "rogue", "room_num_x": 3, "room_num_y": 2}},
+              {"width": 160, "height": 48, "dungeon": {"style": "rogue", "room_num_x": 5, "room_num_y": 4}}]
+    n = 40
+    cfgs = [dict(shapes[i % 4], seed=3000 + i) for i in range(n)]
+    game = ParallelGameState(120, [json.dumps(c) for c in cfgs])
+    assert game.screen_size() == (cfgs[0]["height"], cfgs[0]["width"])
+    oracles = [OracleEnv(c, max_steps=120) for c in cfgs]
+    st = game.states()
+    rng = np.random.RandomState(4)
+    table = np.frombuffer(b"hjklyubnHJKL>s.", np.uint8)
+    for t in range(260):
+        if t:
+            keys = table[rng.randint(0, len(table), n)]
+            st = game.step(keys.tobytes())
+            for i, o in enumerate(oracles):
+                o.step_autoreset(int(keys[i]))
+        for i, o in enumerate(oracles):
+            assert st.screen[i].shape == (cfgs[i].get("height", 24), cfgs[i].get("width", 80))
+            assert np.array_equal(st.screen[i], o.screen()), (t, i)
+            assert np.array_equal(st.hist[i], o.hist()), (t, i)
+            assert [int(v) & 0xFFFFFFFF for v in st.status[i]] == [int(v) for v in o.status_arr()], (t, i)
+            assert bool(st.is_terminal[i]) == o.flags()["is_terminal"], (t, i)
+    # value objects of their own shape, images per env
+    for i in (0, 1, 2, 3):
+        ps = st[i]
+        assert len(ps.dungeon) == cfgs[i].get("height", 24) and len(ps.dungeon[0]) == cfgs[i].get("width", 80)
+        img = ps.gray_image(StatusFlag.DUNGEON_LEVEL.value)
+        assert img.shape == (2, cfgs[i].get("height", 24), cfgs[i].get("width", 80))
+        assert np.array_equal(img, oracles[i].gray_image(StatusFlag.DUNGEON_LEVEL.value))
+    imgs = st.images(0, 0, False)
+    assert isinstance(imgs, list) and imgs[3].shape == (1, 48, 160)
+    game.close()
+    with pytest.raises(RuntimeError, match="differ in width / height"):
+        HipVecRogueEnv(cfgs, image_setting=ImageSetting(DungeonType.GRAY, StatusFlag.EMPTY, False))

@@ -165,3 +165,12 @@ def test_batch_matches_single(goldens):
         assert (be.screen() == e.screen()).all()
         assert be.status() == e.status()
         assert np.array_equal(obs[i], e.gray_image(0))
+
+
+def test_inclusive_edges_kat(goldens):
+    """The reference's own deterministic KAT of passages::edges (passages.rs:272-296), transcribed into the goldens: pins the oracle's
+    edges() -- and with it rect-iter's corner naming -- directly, not only through SEED1_DUNGEON_CLEAR."""
+    from oracle.pyoracle import kat_edges
+    k = goldens["expect"]["inclusive_edges"]
+    for d in ("Down", "Up", "Left", "Right"):
+        assert kat_edges(k["range"]["x"], k["range"]["y"], d, True) == k[d], d
