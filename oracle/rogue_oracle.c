@@ -143,8 +143,8 @@ typedef struct {
     uint8_t *maze_passages;    /* Maze only */
 } room_t;
 
-#define MAX_ROOMS 32
-#define MAX_MON 32
+#define MAX_ROOMS 64   /* rooms.rs:165-211 has no limit; 64 = what the product supports (10 x 4 rooms of 16 x 12 on 160 x 48 is 40) */
+#define MAX_MON 64
 #define DIST_INF 0xFFFFFFFFu
 #define DIST_CACHE_CAP 10
 

@@ -194,16 +194,17 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
     // one DFS stack entry per maze node at most: nodes of the largest assigned area (maze rooms span the area minus one row / column, rooms.rs:240-247)
     const int maze_cap = ((h->cfg.width / h->cfg.room_num_x + 1) / 2) * ((h->cfg.height / h->cfg.room_num_y + 1) / 2) + 1;
     S.maze_cap = maze_cap;
+    const size_t nr = (size_t)h->cfg.room_num_x * h->cfg.room_num_y, ne = 2 * nr;  // slots in use: rooms (= monster / gold slots), corridor records (rg_state.h)
     h->stat_rows = 2048 + (n + 15) / 16;  // >= the largest k_step grid (descent + monster blocks + one block per 16 envs)
     bool ok = dev_alloc(h, &S.cell, n * hw) && dev_alloc(h, &S.screen, n * hw) && dev_alloc(h, &S.hist, n * hw) &&
               dev_alloc(h, &S.p_pos, n) && dev_alloc(h, &S.p_hp, n) && dev_alloc(h, &S.p_hpmax, n) && dev_alloc(h, &S.p_lvl, n) &&
               dev_alloc(h, &S.p_exp, n) && dev_alloc(h, &S.food, n) && dev_alloc(h, &S.quiet, n) && dev_alloc(h, &S.pack_gold, n) &&
               dev_alloc(h, &S.dlevel, n) && dev_alloc(h, &S.steps, n) && dev_alloc(h, &S.flags, n) && dev_alloc(h, &S.reward, n) && dev_alloc(h, &S.done, n) &&
               dev_alloc(h, &S.rng, 12 * n) && dev_alloc(h, &S.seed_lo, n) && dev_alloc(h, &S.seed_hi, n) && dev_alloc(h, &S.reseed, n) &&
-              dev_alloc(h, &S.room_rect, RG_MAX_ROOMS * n) && dev_alloc(h, &S.room_meta, RG_MAX_ROOMS * n) &&
-              dev_alloc(h, &S.mon_w0, RG_MAX_ROOMS * n) && dev_alloc(h, &S.mon_hp, RG_MAX_ROOMS * n) && dev_alloc(h, &S.mon_exp, RG_MAX_ROOMS * n) &&
-              dev_alloc(h, &S.mon_cnt, n) && dev_alloc(h, &S.gold_pos, RG_MAX_ROOMS * n) && dev_alloc(h, &S.gold_amt, RG_MAX_ROOMS * n) &&
-              dev_alloc(h, &S.edge_a, RG_MAX_EDGES * n) && dev_alloc(h, &S.edge_b, RG_MAX_EDGES * n) &&
+              dev_alloc(h, &S.room_rect, nr * n) && dev_alloc(h, &S.room_meta, nr * n) &&
+              dev_alloc(h, &S.mon_w0, nr * n) && dev_alloc(h, &S.mon_hp, nr * n) && dev_alloc(h, &S.mon_exp, nr * n) &&
+              dev_alloc(h, &S.mon_cnt, n) && dev_alloc(h, &S.gold_pos, nr * n) && dev_alloc(h, &S.gold_amt, nr * n) &&
+              dev_alloc(h, &S.edge_a, ne * n) && dev_alloc(h, &S.edge_b, ne * n) &&
               dev_alloc(h, &S.maze_stack, (size_t)maze_cap * n) && dev_alloc(h, &S.build_ctr, n) && dev_alloc(h, &S.stats, 8 * h->stat_rows) && dev_alloc(h, &S.stair_list, 2 * n) && dev_alloc(h, &S.stair_cnt, 8) && dev_alloc(h, &S.stair_mark, 2 * n) &&
               dev_alloc(h, &S.dc_map, h->cfg.n_enemies > 0 ? n * RG_DIST_SLOTS * hw : 16) && dev_alloc(h, &S.dc_key, RG_DIST_SLOTS * n) &&
               dev_alloc(h, &S.dc_head, n) && dev_alloc(h, &S.dc_len, n) && dev_alloc(h, &S.status, n * 10) &&
@@ -229,10 +230,10 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
         RgState &P = h->SP;
         ok = dev_alloc(h, &P.cell, n * hw) && dev_alloc(h, &P.p_pos, n) && dev_alloc(h, &P.p_hp, n) && dev_alloc(h, &P.p_hpmax, n) && dev_alloc(h, &P.p_lvl, n) &&
              dev_alloc(h, &P.p_exp, n) && dev_alloc(h, &P.food, n) && dev_alloc(h, &P.quiet, n) && dev_alloc(h, &P.pack_gold, n) && dev_alloc(h, &P.dlevel, n) &&
-             dev_alloc(h, &P.rng, 12 * n) && dev_alloc(h, &P.room_rect, RG_MAX_ROOMS * n) && dev_alloc(h, &P.room_meta, RG_MAX_ROOMS * n) &&
-             dev_alloc(h, &P.mon_w0, RG_MAX_ROOMS * n) && dev_alloc(h, &P.mon_hp, RG_MAX_ROOMS * n) && dev_alloc(h, &P.mon_exp, RG_MAX_ROOMS * n) &&
-             dev_alloc(h, &P.mon_cnt, n) && dev_alloc(h, &P.gold_pos, RG_MAX_ROOMS * n) && dev_alloc(h, &P.gold_amt, RG_MAX_ROOMS * n) &&
-             dev_alloc(h, &P.edge_a, RG_MAX_EDGES * n) && dev_alloc(h, &P.edge_b, RG_MAX_EDGES * n) && dev_alloc(h, &P.maze_stack, (size_t)maze_cap * n) &&
+             dev_alloc(h, &P.rng, 12 * n) && dev_alloc(h, &P.room_rect, nr * n) && dev_alloc(h, &P.room_meta, nr * n) &&
+             dev_alloc(h, &P.mon_w0, nr * n) && dev_alloc(h, &P.mon_hp, nr * n) && dev_alloc(h, &P.mon_exp, nr * n) &&
+             dev_alloc(h, &P.mon_cnt, n) && dev_alloc(h, &P.gold_pos, nr * n) && dev_alloc(h, &P.gold_amt, nr * n) &&
+             dev_alloc(h, &P.edge_a, ne * n) && dev_alloc(h, &P.edge_b, ne * n) && dev_alloc(h, &P.maze_stack, (size_t)maze_cap * n) &&
              dev_alloc(h, &P.on_stairs, n);
         P.prof = nullptr;
         int lo = 0, hi = 0;
@@ -1085,7 +1086,8 @@ int rg_debug_fetch(rg_t *h, int env, rg_debug_state *out, uint16_t *cells) {
     // monsters sorted by (x, y)
     struct M { uint32_t w; int32_t hp; uint32_t exp; } ms[RG_MAX_ROOMS];
     int cnt = 0;
-    for (int s = 0; s < RG_MAX_ROOMS; s++) {
+    const int n_slots = h->cfg.room_num_x * h->cfg.room_num_y;  // one monster / gold slot per room (floor.rs:106-153)
+    for (int s = 0; s < n_slots; s++) {
         uint32_t w; HIPCHK(h, hipMemcpy(&w, S.mon_w0 + s * n + e, 4, hipMemcpyDeviceToHost));
         if (!((w >> 24) & MF_ALIVE)) continue;
         ms[cnt].w = w;
@@ -1099,7 +1101,7 @@ int rg_debug_fetch(rg_t *h, int env, rg_debug_state *out, uint16_t *cells) {
         out->mon_active[nm] = ((ms[i].w >> 24) & MF_ACTIVE) ? 1 : 0; out->mon_hp[nm] = ms[i].hp; out->mon_exp[nm] = ms[i].exp; nm++;
     }
     out->n_monsters = nm;
-    for (int s = 0; s < RG_MAX_ROOMS; s++) {
+    for (int s = 0; s < n_slots; s++) {
         uint32_t g; HIPCHK(h, hipMemcpy(&g, S.gold_pos + s * n + e, 4, hipMemcpyDeviceToHost));
         if (!(g & 0x10000u)) continue;
         out->gold_x[ng] = (g >> 8) & 0xff; out->gold_y[ng] = g & 0xff;

@@ -4,7 +4,10 @@
 #include <string>
 #include <vector>
 
-#define RG_MAX_ROOMS 32     // room_num_x * room_num_y (reference default 3x3; no limit there; 32 = the width of the room bitmasks)
+#ifndef RG_MAX_ROOMS
+#define RG_MAX_ROOMS 64     // room_num_x * room_num_y (reference default 3x3; no limit there): room sets are 64-bit masks and the generator keeps its
+                            // room table one room per lane of the 64-wide wave; the monster table's `type` / flag byte layout is independent of it
+#endif
 #define RG_MAX_ENEMY_KINDS 26
 #define RG_MAX_W 160        // core/src/lib.rs:134-140
 #define RG_MAX_H 48

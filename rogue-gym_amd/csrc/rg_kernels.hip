@@ -136,7 +136,8 @@ struct Env {
     // generator reads them ~60 times in its RNG-ordered chain (doors, corridors, gold, monsters, placement); from the LDS table each read was a
     // round trip (ds_read, wait, readfirstlane: 100+ cycles), from here it is one v_readlane.  Written to the LDS table once, at the end.
     uint32_t g_rect, g_meta;
-    uint32_t g_ea, g_eb;  // ... and the corridor records (edge k in lane k, <= RG_MAX_EDGES = 64), replayed for the deferred gen_attr draws
+    uint32_t g_ea, g_eb;  // ... and the corridor records (edge k in lane k; a level has fewer than 2 x rooms, records >= 64 -- only possible with more
+                          // than 32 rooms -- go to GenTabs::edge_a / edge_b in LDS), replayed for the deferred gen_attr draws
 };
 __device__ __forceinline__ uint32_t gen_rect(const Env &E, int i) { return lane_get(E.g_rect, i); }
 __device__ __forceinline__ uint32_t gen_meta(const Env &E, int i) { return lane_get(E.g_meta, i); }
@@ -305,16 +306,32 @@ __device__ __forceinline__ int nth_bit(uint32_t m, int nth) {
     for (int i = 0; i < nth; i++) m &= m - 1;
     return __ffs((int)m) - 1;
 }
+// Room sets are bit masks, wave-uniform in the generator (scalar unit).  The generator comes in two instances: BIG = false for room grids of
+// up to 32 rooms (32-bit sets; every corridor record fits the 64 lanes) -- the only one the W <= 32 step kernel contains, whose descent chain
+// bounds the headline launch -- and BIG = true for up to RG_MAX_ROOMS = 64 rooms (64-bit sets, corridor records beyond 64 in LDS): measured on
+// the mini dungeon, the 64-bit form costs a generation 1.3 us of 28 (round 3).
+template <bool BIG> struct RoomSet { typedef uint32_t type; };
+template <> struct RoomSet<true> { typedef uint64_t type; };
+template <typename M> __device__ __forceinline__ M rbit(int i) { return (M)1 << i; }
+template <typename M> __device__ __forceinline__ M rmask_all(int nrooms) { return nrooms >= (int)(8 * sizeof(M)) ? ~(M)0 : (rbit<M>(nrooms) - 1); }
+__device__ __forceinline__ int rpop(uint32_t m) { return __popc(m); }
+__device__ __forceinline__ int rpop(uint64_t m) { return __popcll(m); }
+__device__ __forceinline__ int nth_room(uint32_t m, int nth) { return nth_bit(m, nth); }
+__device__ __forceinline__ int nth_room(uint64_t m, int nth) {
+    for (int i = 0; i < nth; i++) m &= m - 1;
+    return __ffsll((long long)m) - 1;
+}
 // Floor::select_cell (floor.rs:333-346)
-__device__ __forceinline__ bool floor_select(const RgState &S, const RgConfig &c, Env &E, uint32_t non_empty, int mode /*0 stair, 1 player*/, uint32_t &out) {
-    uint32_t cand = non_empty;
+template <typename M>
+__device__ __forceinline__ bool floor_select(const RgState &S, const RgConfig &c, Env &E, M non_empty, int mode /*0 stair, 1 player*/, uint32_t &out) {
+    M cand = non_empty;
     while (cand) {
-        int idx = nth_bit(cand, (int)range64(E.rd, 0, (uint64_t)__popc(cand)));
+        int idx = nth_room(cand, (int)range64(E.rd, 0, (uint64_t)rpop(cand)));
         uint32_t excl = ~0u;
         if (mode == 0) { uint32_t g = uni(S.gold_pos[idx * E.n + E.e]); if (g & 0x10000u) excl = g & 0xffff; }
         else { uint32_t w = uni(S.mon_w0[idx * E.n + E.e]); if ((w >> 24) & MF_ALIVE) excl = w & 0xffff; }
         if (room_select(S, c, E, idx, excl, out)) return true;
-        cand &= ~(1u << idx);
+        cand &= ~rbit<M>(idx);
     }
     return false;
 }
@@ -374,6 +391,7 @@ __device__ __forceinline__ uint32_t select_door(const RgState &S, const RgConfig
 
 // connect_2rooms (passages.rs:84-133): draws the two doors and the bend now, records the corridor for
 // the deferred gen_attr pass (the reference collects Positioned<Surface> in a Vec, floor.rs:73-86)
+template <bool BIG>
 __device__ __forceinline__ void connect_rooms(const RgState &S, const RgConfig &c, Env &E, int r1, int r2, int dir, int &n_edges) {
     if (dir == 0 || dir == 2) { int t = r1; r1 = r2; r2 = t; dir ^= 1; }
     uint32_t s = select_door(S, c, E, r1, dir);
@@ -385,8 +403,10 @@ __device__ __forceinline__ void connect_rooms(const RgState &S, const RgConfig &
     else bend = (int)range32(E.rd, (uint32_t)(POS_X(s) + 1), (uint32_t)POS_X(t));
     if (n_edges < RG_MAX_EDGES) {  // always: RG_MAX_EDGES >= the number of grid-adjacent room pairs (rg_state.h)
         const uint32_t ea = s | (t << 16), eb = (uint32_t)bend | ((uint32_t)(dir == 1) << 8) | ((uint32_t)k1 << 9) | ((uint32_t)k2 << 10);
-        E.g_ea = (int)threadIdx.x == n_edges ? ea : E.g_ea;
-        E.g_eb = (int)threadIdx.x == n_edges ? eb : E.g_eb;
+        if (!BIG || n_edges < WAVE) {  // (<= 32 rooms: fewer than 64 records)
+            E.g_ea = (int)threadIdx.x == n_edges ? ea : E.g_ea;
+            E.g_eb = (int)threadIdx.x == n_edges ? eb : E.g_eb;
+        } else { S.edge_a[n_edges] = ea; S.edge_b[n_edges] = eb; }  // (S = the generator's LDS table view, gen_service)
         n_edges++;
     } else E.err |= RG_FLAG_ERR_INTERNAL;
 }
@@ -437,7 +457,10 @@ __device__ __forceinline__ void paint_corridor(const RgConfig &c, Env &E, uint32
 }
 
 // select_candidate (passages.rs:69-82): reservoir over the grid-neighbour rooms not in `excl_mask`, in ascending id = Up, Left, Right, Down
-__device__ __forceinline__ int select_candidate(const RgConfig &c, Env &E, int nrooms, int node, uint32_t excl_mask, int &dir_out) {
+// excl_set: rooms excluded by id (the spanning tree's `selected`); excl_dirs: candidate slots excluded directly (bit k = slot k in the order
+// Up, Left, Right, Down: the room graph keeps, per room, which of its four neighbours it is already joined to)
+template <typename M>
+__device__ __forceinline__ int select_candidate(const RgConfig &c, Env &E, int nrooms, int node, M excl_set, uint32_t excl_dirs, int &dir_out) {
     const int rnx = c.room_num_x, rny = c.room_num_y;
     const int ny0 = small_div(node, rnx), nx0 = node - ny0 * rnx;
     // candidate slots in ascending room id; direction codes 0 Up 1 Down 2 Left 3 Right
@@ -447,7 +470,7 @@ __device__ __forceinline__ int select_candidate(const RgConfig &c, Env &E, int n
     uint32_t cand = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++)
-        if (ok[k] && !((excl_mask >> ids[k]) & 1u)) cand |= 1u << k;
+        if (ok[k] && !((excl_set >> (ids[k] & (int)(8 * sizeof(M) - 1))) & 1u) && !((excl_dirs >> k) & 1u)) cand |= 1u << k;
     if (!cand) return -1;
     const int k = nth_bit(cand, reservoir4(E.rd, __popc(cand)));
     int res = ids[0];
@@ -463,15 +486,28 @@ __device__ __forceinline__ int select_candidate(const RgConfig &c, Env &E, int n
 // maze stack are read and written hundreds of times in a dependent chain -- against global memory each access is a round trip (a maze room
 // alone cost ~30 us through its global-memory stack).  Copied out to the env's SoA columns when the level is done.
 #define GEN_STACK_LDS 128
+// Sized by the config's room count nr at run time (the mini dungeon's 4 rooms: 420 bytes; a fixed 64-room layout was 2.9 KB of every step wave's
+// LDS and cost the launch ~0.5 us): six tables of nr words, two corridor tables of 2 nr words, the maze stack, nr meta bytes.
 struct GenTabs {
-    uint32_t room_rect[RG_MAX_ROOMS], mon_w0[RG_MAX_ROOMS], mon_exp[RG_MAX_ROOMS], gold_pos[RG_MAX_ROOMS], gold_amt[RG_MAX_ROOMS];
-    int32_t mon_hp[RG_MAX_ROOMS];
-    uint32_t edge_a[RG_MAX_EDGES], edge_b[RG_MAX_EDGES];
-    uint16_t stack[GEN_STACK_LDS];
-    uint8_t room_meta[RG_MAX_ROOMS];
+    uint32_t *room_rect, *mon_w0, *mon_exp, *gold_pos, *gold_amt;
+    int32_t *mon_hp;
+    uint32_t *edge_a, *edge_b;
+    uint16_t *stack;
+    uint8_t *room_meta;
 };
-#define GEN_TABS_BYTES ((sizeof(GenTabs) + 15) & ~(size_t)15)
-#define GEN_SLOT_BYTES(hw) (((((size_t)(hw)) * 2 + 15) & ~(size_t)15) + GEN_TABS_BYTES)
+#define GEN_GRID_BYTES(hw) ((((size_t)(hw)) * 2 + 15) & ~(size_t)15)
+#define GEN_TABS_BYTES(nr) ((((size_t)(nr)) * 41 + GEN_STACK_LDS * 2 + 15) & ~(size_t)15)
+#define GEN_SLOT_BYTES(hw, nr) (GEN_GRID_BYTES(hw) + GEN_TABS_BYTES(nr))
+__device__ __forceinline__ GenTabs gen_tabs(uint8_t *slot, int hw, int nr) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(slot + GEN_GRID_BYTES(hw));
+    GenTabs T;
+    T.room_rect = w; T.mon_w0 = w + nr; T.mon_exp = w + 2 * nr; T.gold_pos = w + 3 * nr; T.gold_amt = w + 4 * nr;
+    T.mon_hp = reinterpret_cast<int32_t *>(w + 5 * nr);
+    T.edge_a = w + 6 * nr; T.edge_b = w + 8 * nr;
+    T.stack = reinterpret_cast<uint16_t *>(w + 10 * nr);
+    T.room_meta = reinterpret_cast<uint8_t *>(T.stack + GEN_STACK_LDS);
+    return T;
+}
 
 // dig_maze (maze.rs:38-89) with an explicit stack (the reference recurses; same visiting and draw order)
 __device__ __forceinline__ void dig_maze(const RgState &S, const RgConfig &c, Env &E, int x0, int y0, int x1, int y1) {
@@ -527,7 +563,9 @@ __device__ __forceinline__ void dig_maze(const RgState &S, const RgConfig &c, En
 }
 
 // Dungeon::new_level_ (rogue/mod.rs:434-481).  Returns the bitmask of non-empty rooms.
-__device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &c, Env &E, Prof &pf) {
+template <bool BIG>
+__device__ __forceinline__ typename RoomSet<BIG>::type gen_level(const RgState &S, const RgConfig &c, Env &E, Prof &pf) {
+    typedef typename RoomSet<BIG>::type rmask_t;
     const int W = c.width, H = c.height, HW = W * H, n = E.n, e = E.e;
     const int rnx = c.room_num_x, nrooms = rnx * c.room_num_y;
     lds_u16 *cell = E.lc;
@@ -553,13 +591,13 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
     // ---- gen_rooms (rooms.rs:165-211) ----
     uint32_t empty_num = range32(E.rd, 0, c.max_empty_rooms + 1);
     if (empty_num >= (uint32_t)nrooms) empty_num = nrooms - 1;
-    uint32_t empty_mask = 0;
+    rmask_t empty_mask = 0;
     {
-        uint32_t sel = nrooms >= 32 ? 0xffffffffu : ((1u << nrooms) - 1u);
+        rmask_t sel = rmask_all<rmask_t>(nrooms);
         for (uint32_t k = 0; k < empty_num; k++) {  // rng.select(0..room_num).take(empty_num): 64-bit nth
-            int id = nth_bit(sel, (int)range64(E.rd, 0, (uint64_t)__popc(sel)));
-            sel &= ~(1u << id);
-            empty_mask |= 1u << id;
+            int id = nth_room(sel, (int)range64(E.rd, 0, (uint64_t)rpop(sel)));
+            sel &= ~rbit<rmask_t>(id);
+            empty_mask |= rbit<rmask_t>(id);
         }
     }
     for (int i = 0; i < nrooms; i++) {  // make_room (rooms.rs:214-269)
@@ -624,40 +662,48 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
     // ---- dig_passges (passages.rs:16-67) ----
     int n_edges = 0;
     {
-        // the room graph's adjacency masks: room i's mask in LANE i of one VGPR (<= 32 rooms <= 64 lanes), read with v_readlane and updated with a
-        // lane-select -- a `uint32_t conn[32]` indexed at run time lived in scratch memory, a memory round trip per access inside this RNG-ordered chain
+        // the room graph (passages.rs:222-270): per room, which of its four grid neighbours it is already joined to -- 4 bits (slot order Up, Left, Right,
+        // Down), room i's in LANE i of one VGPR (<= 64 rooms = 64 lanes), read with v_readlane and updated with a lane-select.  (A `conn[rooms]`
+        // array indexed at run time lived in scratch memory: a memory round trip per access inside this RNG-ordered chain.)
         uint32_t conn_v = 0;
         const int lane_id = (int)threadIdx.x;
         auto conn_get = [&](int i) -> uint32_t { return lane_get(conn_v, i); };
-        auto conn_or = [&](int i, uint32_t bits) { conn_v = lane_id == i ? (conn_v | bits) : conn_v; };
-        uint32_t selected = 0;
+        auto conn_join = [&](int a, int b, int dir_ab) {  // dir_ab: 0 Up 1 Down 2 Left 3 Right, as seen from a
+            const uint32_t slot_of_dir = 0x2130u;         // direction code -> candidate slot (nibbles): Up 0, Down 3, Left 1, Right 2
+            const uint32_t ka = (slot_of_dir >> (4 * dir_ab)) & 3u, kb = (slot_of_dir >> (4 * (dir_ab ^ 1))) & 3u;
+            conn_v = lane_id == a ? (conn_v | (1u << ka)) : (lane_id == b ? (conn_v | (1u << kb)) : conn_v);
+        };
+        rmask_t selected = 0;
         int cur = (int)range64(E.rd, 0, (uint64_t)nrooms), n_sel = 1;
-        selected |= 1u << cur;
+        selected |= rbit<rmask_t>(cur);
         while (n_sel < nrooms) {
             int dir = 0;
-            int nxt = select_candidate(c, E, nrooms, cur, selected, dir);
+            int nxt = select_candidate<rmask_t>(c, E, nrooms, cur, selected, 0u, dir);
             if (nxt >= 0) {
-                selected |= 1u << nxt; n_sel++;
-                conn_or(cur, 1u << nxt); conn_or(nxt, 1u << cur);
-                connect_rooms(S, c, E, cur, nxt, dir, n_edges);
+                selected |= rbit<rmask_t>(nxt); n_sel++;
+                conn_join(cur, nxt, dir);
+                connect_rooms<BIG>(S, c, E, cur, nxt, dir, n_edges);
             } else {
-                cur = nth_bit(selected, (int)range64(E.rd, 0, (uint64_t)n_sel));
+                cur = nth_room(selected, (int)range64(E.rd, 0, (uint64_t)n_sel));
             }
         }
         uint32_t try_num = range32(E.rd, 0, c.max_extra_edges);
         for (uint32_t t = 0; t < try_num; t++) {
             int room1 = (int)range64(E.rd, 0, (uint64_t)nrooms), dir = 0;
-            int room2 = select_candidate(c, E, nrooms, room1, conn_get(room1), dir);
+            int room2 = select_candidate<rmask_t>(c, E, nrooms, room1, (rmask_t)0, conn_get(room1), dir);
             if (room2 >= 0) {
-                conn_or(room1, 1u << room2); conn_or(room2, 1u << room1);
-                connect_rooms(S, c, E, room1, room2, dir, n_edges);
+                conn_join(room1, room2, dir);
+                connect_rooms<BIG>(S, c, E, room1, room2, dir, n_edges);
             }
         }
     }
     pf.mark(11);
-    for (int k = 0; k < n_edges; k++) paint_corridor(c, E, lane_get(E.g_ea, k), lane_get(E.g_eb, k), level);
+    for (int k = 0; k < n_edges; k++) {
+        if (!BIG || k < WAVE) paint_corridor(c, E, lane_get(E.g_ea, k), lane_get(E.g_eb, k), level);
+        else paint_corridor(c, E, uni(S.edge_a[k]), uni(S.edge_b[k]), level);
+    }
 
-    const uint32_t non_empty = (nrooms >= 32 ? 0xffffffffu : ((1u << nrooms) - 1u)) & ~empty_mask;
+    const rmask_t non_empty = rmask_all<rmask_t>(nrooms) & ~empty_mask;
     pf.mark(12);
     // ---- gold (floor.rs:132-153, item/gold.rs:18-24) ----
     for (int i = 0; i < nrooms; i++) {
@@ -721,7 +767,8 @@ __device__ __forceinline__ uint32_t gen_level(const RgState &S, const RgConfig &
 }
 
 // actions::new_level's tail (actions.rs:130-137): place the player and enter the room
-__device__ __forceinline__ void place_player(const RgState &S, const RgConfig &c, Env &E, uint32_t non_empty) {
+template <typename M>
+__device__ __forceinline__ void place_player(const RgState &S, const RgConfig &c, Env &E, M non_empty) {
     uint32_t pos = 0;
     floor_select(S, c, E, non_empty, 1, pos);
     E.px = POS_X(pos); E.py = POS_Y(pos);
@@ -800,11 +847,12 @@ __device__ __forceinline__ void env_to_lane(Env &E, const Env &U) {  // the gene
 }
 static_assert(sizeof(Rng) == 16, "Rng is 4 words");
 
+template <bool BIG>
 __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c, Env &E, int lane, int e, bool need, bool is_build,
                                             uint16_t *lds_grid, Prof &pf) {
     const int HW = c.width * c.height, nrooms = c.room_num_x * c.room_num_y;
     uint8_t *slot = reinterpret_cast<uint8_t *>(lds_grid);
-    GenTabs *T = reinterpret_cast<GenTabs *>(slot + GEN_SLOT_BYTES(HW) - GEN_TABS_BYTES);
+    const GenTabs TT = gen_tabs(slot, HW, nrooms), *T = &TT;
     uint64_t m = __ballot(need);
     while (m) {
         const int src = __ffsll((long long)m) - 1;
@@ -824,7 +872,7 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
         L.maze_stack = S.maze_stack + (size_t)real_e * S.maze_cap;
         U.e = 0; U.n = 1;
         U.g_rect = U.g_meta = U.g_ea = U.g_eb = 0;
-        uint32_t non_empty = gen_level(L, c, U, pf);
+        const typename RoomSet<BIG>::type non_empty = gen_level<BIG>(L, c, U, pf);
         pf.mark(17);
         if (is_build) build_epilogue(L, c, U);
         place_player(L, c, U, non_empty);
@@ -942,6 +990,7 @@ extern __shared__ __align__(16) uint8_t g_smem[];
 // BUILD_EPB envs per wave: a wave generates its levels one after the other, so fewer envs per wave = more waves per SIMD to overlap the
 // generator's latencies (create / rg_reset only; not on the step path)
 #define BUILD_EPB 16
+template <bool BIG>  // (one kernel per generator instance: both in one kernel cost the capped k_regen 20 bytes of scratch)
 __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     const int lane = threadIdx.x;
     const int e = blockIdx.x * BUILD_EPB + lane;
@@ -950,7 +999,7 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     E.e = valid ? e : 0; E.n = S.n; E.cell = E.gcell = S.cell + (size_t)E.e * S.hw; E.err = 0; E.mc = nullptr;
     Prof pf; pf.start(S.prof);
     E.on_stairs = 0;
-    gen_service(S, c, E, lane, e, valid, true, reinterpret_cast<uint16_t *>(g_smem), pf);
+    gen_service<BIG>(S, c, E, lane, e, valid, true, reinterpret_cast<uint16_t *>(g_smem), pf);
     if (blockIdx.x == 0 && lane == 0) stair_recycle(S);
     stair_publish(S, lane, e, valid, E.on_stairs != 0);
     if (!valid) return;
@@ -968,6 +1017,7 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
 // Parity / property-test hook (rg_debug_descend): every env takes Dungeon::new_level + actions::new_level's player placement as if it had
 // pressed '>' on the stairs, without the turn around it -- the descent path of k_step (gen_service, is_build = false) on its own, so tests
 // can look at levels 2..30 of thousands of seeds without walking there.
+template <bool BIG>
 __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
     const int lane = threadIdx.x;
     const int e = blockIdx.x * BUILD_EPB + lane;
@@ -977,7 +1027,7 @@ __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
     load_env(S, E, valid ? e : 0);
     Prof pf; pf.start(nullptr);
     E.on_stairs = 0;
-    gen_service(S, c, E, lane, e, valid, false, reinterpret_cast<uint16_t *>(g_smem), pf);
+    gen_service<BIG>(S, c, E, lane, e, valid, false, reinterpret_cast<uint16_t *>(g_smem), pf);
     if (blockIdx.x == 0 && lane == 0) stair_recycle(S);
     stair_publish(S, lane, e, valid, E.on_stairs != 0);
     if (!valid) return;
@@ -996,7 +1046,14 @@ __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
 // one generation per consumed spare, overlapped with the following steps; k_step's reset then is a copy.
 // SP is an RgState whose core pointers address the spare arrays.  Hand-off per env through sp_ready with
 // agent-scope release/acquire (the consumer kernel runs concurrently on another stream).
-__global__ void __launch_bounds__(WAVE) k_regen(RgState SP, RgConfig c, int epb) {
+#ifdef RG_REGEN_NOCAP
+#define RG_REGEN_ATTR
+#else
+#define RG_REGEN_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))  // <= 128 registers: two generator waves beside a step wave on a SIMD (tests/test_kernel_resources.py)
+#endif
+template <bool BIG>
+__global__ void __launch_bounds__(WAVE) RG_REGEN_ATTR
+k_regen(RgState SP, RgConfig c, int epb) {
     const int lane = threadIdx.x;
     const int e = blockIdx.x * epb + lane;
     const bool valid = lane < epb && e < SP.n;
@@ -1008,7 +1065,7 @@ __global__ void __launch_bounds__(WAVE) k_regen(RgState SP, RgConfig c, int epb)
     E.e = valid ? e : 0; E.n = SP.n; E.cell = E.gcell = SP.cell + (size_t)E.e * SP.hw; E.err = 0; E.mc = nullptr;
     Prof pf; pf.start(nullptr);
     E.on_stairs = 0;
-    gen_service(SP, c, E, lane, e, claim, true, reinterpret_cast<uint16_t *>(g_smem), pf);
+    gen_service<BIG>(SP, c, E, lane, e, claim, true, reinterpret_cast<uint16_t *>(g_smem), pf);
     if (claim) { store_env(SP, E); SP.on_stairs[e] = (uint8_t)E.on_stairs; }
     if (claim && E.err) atomicOr(SP.err_any, E.err);  // (the flag word belongs to the concurrently running k_step)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1761,9 +1818,13 @@ __device__ __forceinline__ int next_pending(const RgState &S, const Env &E, int 
 
 // EnemyHandler::move_actives, RNG part (enemies.rs:399-404, rogue/mod.rs:383): the per-monster draws do not
 // depend on positions, so they are taken first (same per-stream order) to learn whether a dist map is needed.
-__device__ __forceinline__ bool monsters_prepass(const RgState &S, const RgConfig &c, Env &E, uint32_t &rand_mask, uint64_t (&rand_dir)[2]) {
+// A monster that moves at random this turn carries MF_RANDOM and its direction (3 bits) in the flag byte of its CACHE word, next to MF_PENDING --
+// per-lane bit tables for that (a mask + 4 bits per slot) were five registers held across the BFS, and capped the table at 32 slots.
+#define MF_RANDOM 0x08u
+#define MF_DIR_SHIFT 4        // bits 4..6 of the flag byte
+#define MF_TURN_BITS (MF_PENDING | MF_RANDOM | (7u << MF_DIR_SHIFT))   // cache-only bits of the running turn; never stored to global memory
+__device__ __forceinline__ bool monsters_prepass(const RgState &S, const RgConfig &c, Env &E) {
     const int nrooms = c.room_num_x * c.room_num_y;
-    rand_mask = 0; rand_dir[0] = rand_dir[1] = 0;  // 4 bits per monster slot, 16 slots per word
     for (int s = 0; s < nrooms; s++) {  // the taken map: every active monster is pending
         uint32_t w = mon_rd<true>(S, E, s);
         if (((w >> 24) & (MF_ALIVE | MF_ACTIVE)) == (MF_ALIVE | MF_ACTIVE)) E.mc[s * WAVE] = w | ((uint32_t)MF_PENDING << 24);  // PENDING lives in the cache only
@@ -1776,9 +1837,8 @@ __device__ __forceinline__ bool monsters_prepass(const RgState &S, const RgConfi
         if (does_happen(E.re, 2) && (attr & EA_RANDOM)) rnd = true;
         else if (!does_happen(E.re, 5) && (attr & EA_CONFUSED)) rnd = true;
         if (rnd) {
-            rand_mask |= 1u << slot;
-            const uint64_t dbits = range64(E.rd, 0, 8) << ((slot & 15) * 4);
-            if (slot < 16) rand_dir[0] |= dbits; else rand_dir[1] |= dbits;
+            const uint32_t d = (uint32_t)range64(E.rd, 0, 8);
+            E.mc[slot * WAVE] = mon_rd<true>(S, E, slot) | ((MF_RANDOM | (d << MF_DIR_SHIFT)) << 24);
         } else need_map = true;
     }
     return need_map;
@@ -1805,19 +1865,20 @@ __device__ __forceinline__ bool dist_cache_lookup(const RgState &S, const Env &E
 
 // EnemyHandler::move_actives moves + actions::move_active_enemies attacks
 // (enemies.rs:366-424, rogue/mod.rs:339-397, actions.rs:82-119, fight.rs:41-72)
-__device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &c, Env &E, uint32_t rand_mask, const uint64_t (&rand_dir)[2], int map_slot, uint32_t &react) {
+__device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &c, Env &E, int map_slot, uint32_t &react) {
     const int nrooms = c.room_num_x * c.room_num_y, W = c.width, e = E.e;
     const uint16_t *dist = S.dc_map + ((size_t)e * RG_DIST_SLOTS + (map_slot < 0 ? 0 : map_slot)) * S.hw;
     const uint32_t ppos = POS(E.px, E.py);
     uint64_t att_list = 0; int n_att = 0;
     int last = -1, slot;
     while ((last = next_pending(S, E, nrooms, last, slot)) >= 0) {
-        uint32_t w = mon_rd<true>(S, E, slot) & ~((uint32_t)MF_PENDING << 24);
+        const uint32_t wt = mon_rd<true>(S, E, slot);
+        const uint32_t w = wt & ~((uint32_t)MF_TURN_BITS << 24);
         E.mc[slot * WAVE] = w;  // leaves the taken map; not yet in the new one, so it never blocks itself
         int cx = POS_X(w), cy = POS_Y(w);
         uint32_t fin = w & 0xffff;
         bool reach = false;
-        const bool random = (rand_mask >> slot) & 1;
+        const bool random = (wt >> 24) & MF_RANDOM;
         // one round of independent loads: the 3x3 tiles around the monster (can_move needs the target and, for diagonals, its two
         // orthogonal neighbours) and, for a chaser, the 3x3 of the dist map; the decision below then runs on registers only
         uint32_t walk = 0, dv[9];
@@ -1838,7 +1899,7 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
         if (!((walk >> 2) & (walk >> 1) & 1u)) cm &= ~(1u << 6);  // LeftDown: Left, Down
         if (!((walk >> 3) & (walk >> 1) & 1u)) cm &= ~(1u << 7);  // RightDown: Right, Down
         if (random) {  // Dungeon::move_enemy_randomly
-            int d = (int)(((slot < 16 ? rand_dir[0] : rand_dir[1]) >> ((slot & 15) * 4)) & 7);
+            int d = (int)((wt >> (24 + MF_DIR_SHIFT)) & 7u);
             uint32_t np = POS(cx + dir_dx(d), cy + dir_dy(d));
             if (!blocked_for(S, E, nrooms, np, slot) && ((cm >> d) & 1u)) {
                 if (np == ppos) reach = true; else fin = np;
@@ -1856,8 +1917,8 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
             if (!reach && found) fin = bp;
         }
         // A reaching monster stays on its cell, which is one of the player's 8 neighbours; two monsters never end a turn on one cell (a
-        // monster that stays put replaces one that moved onto it, below) => at most 8 attackers, and the 12-entry list cannot overflow.
-        if (reach) { if (n_att < 12) { att_list |= (uint64_t)slot << (5 * n_att); n_att++; } else E.err |= RG_FLAG_ERR_INTERNAL; }
+        // monster that stays put replaces one that moved onto it, below) => at most 8 attackers, and the 10-entry list (6-bit slots) cannot overflow.
+        if (reach) { if (n_att < 10) { att_list |= (uint64_t)slot << (6 * n_att); n_att++; } else E.err |= RG_FLAG_ERR_INTERNAL; }
         if (fin == (w & 0xffff)) {
             // BTreeMap::insert on its own key replaces a monster that already moved onto this cell
             for (int s = 0; s < nrooms; s++) {
@@ -1872,7 +1933,7 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
     bool did_hit = false;
     uint32_t lev_add = lev_add_of(c, E.dlevel);
     for (int i = 0; i < n_att; i++) {
-        int s = (int)((att_list >> (5 * i)) & 31);
+        int s = (int)((att_list >> (6 * i)) & 63);
         uint32_t type = (mon_rd<true>(S, E, s) >> 16) & 0xff;
         uint32_t rate = attack_rate((int64_t)c.mon[type].level + lev_add, c.armor_def /* Player::arm: the default pack wears ring mail 3 + 1 */, 0 /* hit_prob_plus(10) */);
         int sum = 0; bool hit = false;
@@ -2058,7 +2119,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         }
         const bool regenerated = descends && pass == 0;
         if (need_gen) n_inline++;
-        gen_service(S, c, E, lane, e, need_gen, pass == 1, lds_grid, pf);
+        gen_service<(BW != 0)>(S, c, E, lane, e, need_gen, pass == 1, lds_grid, pf);  // W <= 32: at most 12 rooms; the wider instances carry the 64-room generator
         (void)regenerated;  // (a descended lane's monster-cache column was refilled by gen_service from the generator's own table)
         pf.mark(2);
         need_gen = false;
@@ -2068,7 +2129,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         int iter = 0;
         while (__any(running)) {
             bool do_turn = false, need_bfs = false;
-            uint32_t rand_mask = 0; uint64_t rand_dir[2] = {0, 0}; int map_slot = -1;
+            int map_slot = -1;
             FillReq fr; fr.leave = fr.enter = 0;
             if (running) {
                 switch (act) {  // actions::process_action (actions.rs:16-65)
@@ -2095,7 +2156,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             if (do_turn) turn_passed(c, E, react);  // actions::after_turn (actions.rs:67-80)
             pf.mark(29);
             bool need_map = false;
-            if (do_turn && E.mon_active > 0) need_map = monsters_prepass(S, c, E, rand_mask, rand_dir);
+            if (do_turn && E.mon_active > 0) need_map = monsters_prepass(S, c, E);
             pf.mark(30);
             if (need_map) need_bfs = !dist_cache_lookup(S, E, POS(E.px, E.py), map_slot);
             pf.mark(3);
@@ -2112,7 +2173,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
                 if (pf.p) { pf.rec(24, __builtin_amdgcn_s_memtime() - tb0); pf.rec(25, (unsigned long long)__popcll(m)); }
             }
             pf.mark(4);
-            if (do_turn && E.mon_active > 0) ui_dead = monsters_move(S, c, E, rand_mask, rand_dir, map_slot, react);  // `ui` of the LAST after_turn wins
+            if (do_turn && E.mon_active > 0) ui_dead = monsters_move(S, c, E, map_slot, react);  // `ui` of the LAST after_turn wins
             else if (do_turn) ui_dead = false;
             pf.mark(5);
             // a MoveUntil run moves one cell in a fixed direction per iteration => it ends after at most max(W, H) iterations
@@ -2247,12 +2308,13 @@ k_step_w32(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t
 extern "C" {
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
-    size_t smem = GEN_SLOT_BYTES(hw);  // one level at a time per wave: one staging grid + the generator's tables
-    hipLaunchKernelGGL(k_build, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), smem, st, *S, *c);
+    size_t smem = GEN_SLOT_BYTES(hw, c->room_num_x * c->room_num_y);  // one level at a time per wave: one staging grid + the generator's tables
+    if (c->room_num_x * c->room_num_y <= 32) hipLaunchKernelGGL(k_build<false>, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), smem, st, *S, *c);
+    else hipLaunchKernelGGL(k_build<true>, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), smem, st, *S, *c);
 }
 void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     int hw = c->width * c->height;
-    size_t smem = GEN_SLOT_BYTES(hw);  // the generator's staging grid + tables (inline descents, spare misses), shared with ...
+    size_t smem = GEN_SLOT_BYTES(hw, c->room_num_x * c->room_num_y);  // the generator's staging grid + tables (inline descents, spare misses), shared with ...
     const bool n32 = c->width <= 96 && hw <= 4096;  // BFS rows as 32-bit words in registers (bfs_rows_n32): no LDS planes
     const size_t bfs_hi = (c->width <= 32 || n32) ? 0 : (size_t)10 * ((c->width + 63) / 64) * WAVE * 8;  // ... the BFS high distance planes
     if (bfs_hi > smem) smem = bfs_hi;
@@ -2281,16 +2343,19 @@ void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const 
 }
 void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
-    hipLaunchKernelGGL(k_debug_descend, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), GEN_SLOT_BYTES(hw), st, *S, *c);
+    const size_t smem = GEN_SLOT_BYTES(hw, c->room_num_x * c->room_num_y);
+    if (c->room_num_x * c->room_num_y <= 32) hipLaunchKernelGGL(k_debug_descend<false>, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), smem, st, *S, *c);
+    else hipLaunchKernelGGL(k_debug_descend<true>, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), smem, st, *S, *c);
 }
 void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
-    size_t smem = GEN_SLOT_BYTES(hw);
+    size_t smem = GEN_SLOT_BYTES(hw, c->room_num_x * c->room_num_y);
     // envs per wave: a wave generates its claimed spares one after the other, so with 64 envs per wave the launch lasts as long as its unluckiest wave
     // (4-6 claims: 270 us, the next launch queued behind it) and its waves sit beside two or three launches of the step kernels.  8 envs per wave: 0.08
     // claims per wave, the launch is over in about one generation time, and the 8192 blocks that find nothing are gone at once.  (A/B knob.)
     static const int epb_env = getenv("ROGUE_GYM_HIP_REGEN_EPB") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_EPB")) : 0;
     const int epb = (epb_env >= 4 && epb_env <= WAVE) ? epb_env : 8;
-    hipLaunchKernelGGL(k_regen, dim3((SP->n + epb - 1) / epb), dim3(WAVE), smem, st, *SP, *c, epb);
+    if (c->room_num_x * c->room_num_y <= 32) hipLaunchKernelGGL(k_regen<false>, dim3((SP->n + epb - 1) / epb), dim3(WAVE), smem, st, *SP, *c, epb);
+    else hipLaunchKernelGGL(k_regen<true>, dim3((SP->n + epb - 1) / epb), dim3(WAVE), smem, st, *SP, *c, epb);
 }
 }

@@ -121,7 +121,7 @@ def test_config_canonical_roundtrip(lib, goldens):
 
 
 def test_config_validation(lib):
-    for bad, frag in [({"width": 160, "height": 48, "dungeon": {"style": "rogue", "room_num_x": 7, "room_num_y": 5}}, "room_num"),
+    for bad, frag in [({"width": 160, "height": 48, "dungeon": {"style": "rogue", "room_num_x": 13, "room_num_y": 5}}, "room_num"),
                       ({"dungeon": {"style": "rogue", "room_num_x": 5, "room_num_y": 5}}, "min_room_size"),
                       ({"enemies": {"enemies": [99]}}, "builtin"),
                       ({"enemies": {"enemies": [{"name": "x"}]}}, "missing field"),
