@@ -117,6 +117,18 @@ int rg_status_vec(rg_t *h, uint32_t status_flag, int32_t *out_host);
  * each other in env order, env i taking H_i * W_i bytes (rg_env_dims). */
 int rg_fetch_states(rg_t *h, uint8_t *screen, uint8_t *hist, int32_t *status, uint32_t *flags);
 
+/* Device-side snapshots of the two big mirrors, for value-object callers that read mostly status / flags (parallel.py:59-64 uses gold and
+ * is_terminal of every state, nothing else): rg_snapshot_take flushes the pending render and copies screen + hist device-to-device into
+ * `dev` = u8 [2][n_env][H][W] (screen first; allocate with rg_dev_alloc), asynchronously on the handle's stream; rg_dev_read is a synchronous
+ * D2H copy of any part of it (or of any device buffer of the handle) made when a PlayerState's screen is first looked at.  Not for batches that
+ * mix sizes. */
+int rg_dev_alloc(int device, size_t bytes, void **out);
+void rg_dev_free(int device, void *p);
+int rg_snapshot_take(rg_t *h, void *dev);
+int rg_dev_read(rg_t *h, const void *dev_src, void *host_dst, size_t bytes);
+/* the same for `rows` pieces of row_bytes that lie src_pitch apart on the device (screen and history of ONE env of a snapshot: one copy) */
+int rg_dev_read_rows(rg_t *h, const void *dev_src, size_t src_pitch, void *host_dst, size_t row_bytes, int rows);
+
 /* Stateless encode of ONE host-side PlayerState snapshot on the GPU (PlayerState.gray_image &c.
  * called on a cloned value object): uploads, runs the same encode kernel, downloads.
  * kind 0 = gray, 1 = symbol.  Returns non-zero on the symbol-image tile error. */

@@ -638,6 +638,37 @@ int rg_fetch_states(rg_t *h, uint8_t *screen, uint8_t *hist, int32_t *status, ui
     return 0;
 }
 
+// Device-side snapshots for the value-object API.  ParallelGameState::step hands back Vec<PlayerState> -- values that stay valid when the envs move
+// on -- but a caller of the RL loop reads only gold / is_terminal of every state (parallel.py:59-64): shipping 1 KB of screen + history per env
+// over PCIe on every step was what bounded `ParallelRogueEnv.step` (29.5 M env-steps/s at 65 536 envs).  rg_snapshot_take copies the two mirrors
+// device-to-device (67 MB: ~30 us) into a caller-owned device buffer; the host copies are made on first access (rg_dev_read), whole or per env.
+int rg_dev_alloc(int device, size_t bytes, void **out) {
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(out, bytes ? bytes : 16) != hipSuccess) { g_create_err = "hipMalloc failed (" + std::to_string(bytes) + " bytes)"; return 1; }
+    return 0;
+}
+void rg_dev_free(int device, void *p) { if (p && hipSetDevice(device) == hipSuccess) (void)hipFree(p); }
+int rg_snapshot_take(rg_t *h, void *dev) {
+    if (refuse_mixed(h, "rg_snapshot_take")) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (flush_mirrors(h)) return 1;
+    const size_t bytes = (size_t)h->S.n * (size_t)h->S.hw;
+    HIPCHK(h, hipMemcpyAsync(dev, h->S.screen, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(static_cast<uint8_t *>(dev) + bytes, h->S.hist, bytes, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+int rg_dev_read_rows(rg_t *h, const void *dev_src, size_t src_pitch, void *host_dst, size_t row_bytes, int rows) {  // `rows` rows of row_bytes, src_pitch apart -> packed
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy2DAsync(host_dst, row_bytes, dev_src, src_pitch, row_bytes, (size_t)rows, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+int rg_dev_read(rg_t *h, const void *dev_src, void *host_dst, size_t bytes) {
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 // Device scratch of the stateless encode (rg_encode_host*), one per device, grown on demand and kept: the value-object API calls this once per
 // PlayerState.gray_image() &c., and a hipMalloc / hipFree pair per call cost more than the encode itself.
 namespace {

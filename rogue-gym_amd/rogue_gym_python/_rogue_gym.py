@@ -7,6 +7,7 @@ MI355X; this file only marshals.  There is no CPU fallback: importing works anyw
 constructing a GameState without the built library or without a HIP device raises.
 """
 import ctypes as C
+import weakref
 import json
 import os
 
@@ -42,7 +43,7 @@ _lib = None
 _INT_FUNCS = (
     "rg_create", "rg_dims", "rg_env_dims", "rg_env_symbols", "rg_set_stream", "rg_seed", "rg_reset", "rg_step", "rg_step_prefix", "rg_sync", "rg_screen", "rg_hist", "rg_status", "rg_flags",
     "rg_reward", "rg_done", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_encode_host_batch", "rg_obs_host",
-    "rg_host_alloc", "rg_compact_record_bytes", "rg_pack_compact", "rg_expand_compact", "rg_comm_unique_id", "rg_comm_init", "rg_comm_destroy", "rg_allgather_compact", "rg_status_vec", "rg_history_enable", "rg_history_keys",
+    "rg_host_alloc", "rg_dev_alloc", "rg_snapshot_take", "rg_dev_read", "rg_dev_read_rows", "rg_compact_record_bytes", "rg_pack_compact", "rg_expand_compact", "rg_comm_unique_id", "rg_comm_init", "rg_comm_destroy", "rg_allgather_compact", "rg_status_vec", "rg_history_enable", "rg_history_keys",
     "rg_dump_history", "rg_counters", "rg_probe_sclk", "rg_dump_config", "rg_config_canonical", "rg_config_resolved", "rg_config_schema", "rg_debug_fetch", "rg_debug_descend", "rg_timing_enable", "rg_timing_read",
 )
 
@@ -86,6 +87,7 @@ def load_library():
         "rg_encode_host_batch": [i32, i32, vp, vp, vp, i32, i32, i32, u32, i32, i32, vp],
         "rg_obs_host": [vp, i32, u32, i32, vp],
         "rg_host_alloc": [sz, C.POINTER(vp)], "rg_host_free": [vp],
+        "rg_dev_alloc": [i32, sz, C.POINTER(vp)], "rg_dev_free": [i32, vp], "rg_snapshot_take": [vp, vp], "rg_dev_read": [vp, vp, vp, sz], "rg_dev_read_rows": [vp, vp, sz, vp, sz, i32],
         "rg_compact_record_bytes": [vp, i32], "rg_pack_compact": [vp, i32, vp], "rg_expand_compact": [vp, vp, i32, i32, i32, u32, i32, vp],
         "rg_comm_unique_id": [vp], "rg_comm_init": [vp, vp, i32, i32], "rg_comm_destroy": [vp], "rg_allgather_compact": [vp, i32, vp],
         "rg_status_vec": [vp, u32, vp],
@@ -101,6 +103,7 @@ def load_library():
         getattr(L, name).argtypes = argtypes
     L.rg_destroy.restype = None
     L.rg_host_free.restype = None
+    L.rg_dev_free.restype = None
     L.rg_last_error.restype = C.c_char_p
     for name in _INT_FUNCS:
         getattr(L, name).restype = C.c_int
@@ -142,6 +145,35 @@ class _PinnedPool:
         self.free = {}
 
 
+class _DevPool:
+    """Device buffers for the StateBatch snapshots (same take / give protocol as _PinnedPool)."""
+
+    def __init__(self, L, device):
+        self.L, self.device, self.free, self.closed = L, device, {}, False
+
+    def take(self, nbytes):
+        lst = self.free.get(nbytes)
+        if lst:
+            return lst.pop()
+        p = C.c_void_p()
+        if self.L.rg_dev_alloc(self.device, nbytes, C.byref(p)):
+            raise RuntimeError("Error in rogue-gym: " + self.L.rg_last_error(None).decode())
+        return p.value
+
+    def give(self, ptr, nbytes):
+        if self.closed:
+            self.L.rg_dev_free(self.device, C.c_void_p(ptr))
+        else:
+            self.free.setdefault(nbytes, []).append(ptr)
+
+    def close(self):
+        self.closed = True
+        for lst in self.free.values():
+            for ptr in lst:
+                self.L.rg_dev_free(self.device, C.c_void_p(ptr))
+        self.free = {}
+
+
 class _Lease:
     """One pooled pinned buffer on loan.  It goes back to the pool when the LAST array that views it is collected -- not when the StateBatch
     that asked for it is: `obs = env.images()` kept in a rollout buffer stays valid (and unchanged) for as long as the caller holds it, like the
@@ -155,6 +187,21 @@ class _Lease:
     def __del__(self):
         try:
             self.pool.give(self.ptr, self.nbytes)  # a closed pool frees it instead (hipHostFree)
+        except Exception:
+            pass
+
+
+class _DevLease:
+    """A pooled device buffer on loan to one StateBatch (its snapshot of the screen / history mirrors)."""
+    __slots__ = ("pool", "ptr", "nbytes")
+
+    def __init__(self, pool, nbytes):
+        self.pool, self.nbytes = pool, nbytes
+        self.ptr = pool.take(nbytes)
+
+    def __del__(self):
+        try:
+            self.pool.give(self.ptr, self.nbytes)
         except Exception:
             pass
 
@@ -197,6 +244,8 @@ class _Handle:
         L.rg_env_dims(h, self.env_heights.ctypes.data, self.env_widths.ctypes.data)
         self.mixed_sizes = bool((self.env_heights != self.height).any() or (self.env_widths != self.width).any())
         self.pool = _PinnedPool(L)
+        self.dev_pool = _DevPool(L, self.device)
+        self.lazy = {}  # id -> weakref of the StateBatches whose screens still live only in their device snapshot (materialised before the handle goes)
         self.epoch = 0  # bumped by every call that changes the device-side states (a StateBatch remembers the epoch it was taken at)
 
     def check(self, rc):
@@ -205,9 +254,14 @@ class _Handle:
 
     def close(self):
         if getattr(self, "h", None):
+            for ref in list(self.lazy.values()):  # value semantics: states handed out earlier stay readable after close()
+                b = ref()
+                if b is not None:
+                    b._materialise()
             self.L.rg_destroy(self.h)
             self.h = None
             self.pool.close()
+            self.dev_pool.close()
 
     def __del__(self):
         try:
@@ -254,6 +308,7 @@ class _Handle:
         return buf.value.decode()
 
 
+_LAZY_MIN_BYTES = 1 << 20   # batches with at least this many screen bytes keep their screens on the device until they are looked at
 _IMAGE_BATCH_LIMIT = 1 << 28  # bytes: above this a batch does not cache whole-batch images (one-hot images of large batches are GBs)
 
 
@@ -270,20 +325,65 @@ class StateBatch:
         self.status = _leased(handle.pool, (n, 10), np.int32)
         self.flags = _leased(handle.pool, (n,), np.uint32)
         self.mixed_sizes = handle.mixed_sizes
-        if not self.mixed_sizes:
-            self.screen = _leased(handle.pool, (n, h, w), np.uint8)
-            self.hist = _leased(handle.pool, (n, h, w), np.uint8)
-            sp, hp = self.screen.ctypes.data, self.hist.ctypes.data
-        else:  # envs of different width / height (ParallelGameState::new takes any config per env): ragged buffers, `screen` / `hist` are lists of per-env views
+        self._snap = None
+        if self.mixed_sizes:  # envs of different width / height (ParallelGameState::new takes any config per env): ragged buffers, `screen` / `hist` are lists of per-env views
             off = np.concatenate(([0], np.cumsum(handle.env_heights.astype(np.int64) * handle.env_widths)))
             rs, rh = _leased(handle.pool, (int(off[-1]),), np.uint8), _leased(handle.pool, (int(off[-1]),), np.uint8)
-            self.screen = [rs[off[i]:off[i + 1]].reshape(handle.env_heights[i], handle.env_widths[i]) for i in range(n)]
-            self.hist = [rh[off[i]:off[i + 1]].reshape(handle.env_heights[i], handle.env_widths[i]) for i in range(n)]
-            sp, hp = rs.ctypes.data, rh.ctypes.data
-        handle.check(handle.L.rg_fetch_states(handle.h, sp, hp, self.status.ctypes.data, self.flags.ctypes.data))
+            self._screen = [rs[off[i]:off[i + 1]].reshape(handle.env_heights[i], handle.env_widths[i]) for i in range(n)]
+            self._hist = [rh[off[i]:off[i + 1]].reshape(handle.env_heights[i], handle.env_widths[i]) for i in range(n)]
+            handle.check(handle.L.rg_fetch_states(handle.h, rs.ctypes.data, rh.ctypes.data, self.status.ctypes.data, self.flags.ctypes.data))
+        elif n * h * w < _LAZY_MIN_BYTES:  # small batch: one call, four copies
+            self._screen = _leased(handle.pool, (n, h, w), np.uint8)
+            self._hist = _leased(handle.pool, (n, h, w), np.uint8)
+            handle.check(handle.L.rg_fetch_states(handle.h, self._screen.ctypes.data, self._hist.ctypes.data, self.status.ctypes.data, self.flags.ctypes.data))
+        else:
+            # The RL loop reads gold and is_terminal of every state and nothing else (parallel.py:59-64): status + flags (44 B per env) come to the host
+            # now, the screens (1 KB per env) are snapshotted device-to-device (~30 us for 65 536 envs) and cross PCIe only when somebody looks at them
+            self._screen = self._hist = None
+            self._snap = _DevLease(handle.dev_pool, 2 * n * h * w)
+            handle.check(handle.L.rg_snapshot_take(handle.h, C.c_void_p(self._snap.ptr)))
+            handle.check(handle.L.rg_fetch_states(handle.h, None, None, self.status.ctypes.data, self.flags.ctypes.data))  # (synchronises the stream)
+            key, lazy = id(self), handle.lazy
+            lazy[key] = weakref.ref(self, lambda _r, key=key, lazy=lazy: lazy.pop(key, None))
         self._epoch = handle.epoch
         self._items = {}
         self._images = {}
+
+    def _materialise(self):
+        """Host copies of the whole snapshot (one D2H of screen + history into pinned memory); the device buffer goes back to the pool."""
+        if self._snap is None:
+            return
+        hd = self._hd
+        if hd.h is None:
+            raise RuntimeError("Error in rogue-gym: the game was closed")
+        n, h, w = self.n, hd.height, hd.width
+        both = _leased(hd.pool, (2, n, h, w), np.uint8)
+        hd.check(hd.L.rg_dev_read(hd.h, C.c_void_p(self._snap.ptr), both.ctypes.data, both.nbytes))
+        self._screen, self._hist, self._snap = both[0], both[1], None
+        hd.lazy.pop(id(self), None)
+
+    @property
+    def screen(self):
+        """u8 [n, H, W] glyph mirrors (a list of per-env arrays when the batch mixes sizes)."""
+        if self._screen is None:
+            self._materialise()
+        return self._screen
+
+    @property
+    def hist(self):
+        if self._hist is None:
+            self._materialise()
+        return self._hist
+
+    def _row(self, i):
+        """Screen and history of env i: views of the host copies if they exist, else 2 x H*W bytes fetched from the device snapshot."""
+        if self._snap is None:
+            return self._screen[i], self._hist[i]
+        hd = self._hd
+        n, h, w = self.n, hd.height, hd.width
+        both = np.empty((2, h, w), np.uint8)  # one 2-row copy: env i's screen and, n * H * W bytes further, its history
+        hd.check(hd.L.rg_dev_read_rows(hd.h, C.c_void_p(self._snap.ptr + i * h * w), n * h * w, both.ctypes.data, h * w, 2))
+        return both[0], both[1]
 
     def __len__(self):
         return self.n
@@ -297,7 +397,12 @@ class StateBatch:
             raise IndexError(i)
         st = self._items.get(i)
         if st is None:
-            st = self._items[i] = PlayerState(self.screen[i], self.hist[i], self.status[i], int(self._hd.env_symbols[i]), int(self.flags[i]), self._hd.device,
+            # one state costs one small synchronous copy (~25 us); the whole snapshot costs its bytes at PCIe rate -- cheaper from the first access
+            # for a small batch, from the ~100th for a 65 536-env one (67 MB: ~2.7 ms)
+            if self._snap is not None and (self._snap.nbytes <= (16 << 20) or len(self._items) >= 128):
+                self._materialise()
+            scr, hist = self._row(i)
+            st = self._items[i] = PlayerState(scr, hist, self.status[i], int(self._hd.env_symbols[i]), int(self.flags[i]), self._hd.device,
                                               batch=self, index=i, batch_images=self._hd.uniform_symbols and not self.mixed_sizes)
         return st
 
@@ -336,7 +441,7 @@ class StateBatch:
             img = self._images[key] = [self[i]._image(kind, flag, with_hist) for i in range(self.n)]
             return img
         hd, L = self._hd, self._hd.L
-        h, w = self.screen.shape[1:]
+        h, w = hd.height, hd.width
         c = (self.symbols if kind else 1) + bin(flag).count("1") + (1 if with_hist else 0)
         nbytes = self.n * c * h * w * 4
         if nbytes <= _IMAGE_BATCH_LIMIT and not hd.pool.closed:  # pinned, pooled: a fresh 16 MB numpy array per step costs more in page faults than the copy
