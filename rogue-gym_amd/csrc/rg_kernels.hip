@@ -95,6 +95,11 @@ __device__ __forceinline__ int dir_dy(int d) { return (int)((dir_pack(kDYc) >> (
 // optional phase trace (development aid, tools/microbench.py prof): lane 0 of every wave appends (phase, elapsed shader-clock ticks)
 // records to the wave's own 64-word row of S.prof with plain stores -- no atomics, so the trace does not perturb what it measures.
 // Word 0 = number of records, word 63 = whole-wave ticks, word 62 = start | end on the 100 MHz clock.
+#ifdef RG_FINE_PROF
+#define PFM(id) pf.mark(id)
+#else
+#define PFM(id) ((void)0)
+#endif
 struct Prof {
     unsigned long long *p; unsigned long long t, t0, r0; int k;
     __device__ __forceinline__ void start(unsigned long long *pp) { p = pp ? pp + (size_t)blockIdx.x * 64 : nullptr; k = 0; if (p) { r0 = __builtin_amdgcn_s_memrealtime(); t = t0 = __builtin_amdgcn_s_memtime(); } }
@@ -132,6 +137,9 @@ struct Env {
     uint32_t *mc;       // k_step: this lane's column of the wave's LDS monster cache (word s at mc[s * WAVE]); write-through
     uint32_t err;       // RG_FLAG_ERR_INTERNAL if a capacity guard tripped (each guard carries its proof of unreachability)
     uint32_t on_stairs; // set by place_player: the player was put on the staircase of the level just generated
+#ifdef RG_FINE_PROF
+    Prof *pfp;
+#endif
     // generation: the room table of the level being generated, room i's rect / meta in LANE i of one VGPR each (<= 32 rooms <= 64 lanes).  The
     // generator reads them ~60 times in its RNG-ordered chain (doors, corridors, gold, monsters, placement); from the LDS table each read was a
     // round trip (ds_read, wait, readfirstlane: 100+ cycles), from here it is one v_readlane.  Written to the LDS table once, at the end.
@@ -393,9 +401,15 @@ __device__ __forceinline__ uint32_t select_door(const RgState &S, const RgConfig
 // the deferred gen_attr pass (the reference collects Positioned<Surface> in a Vec, floor.rs:73-86)
 template <bool BIG>
 __device__ __forceinline__ void connect_rooms(const RgState &S, const RgConfig &c, Env &E, int r1, int r2, int dir, int &n_edges) {
+#ifdef RG_FINE_PROF
+    Prof &pf = *E.pfp;
+#endif
+    PFM(40);
     if (dir == 0 || dir == 2) { int t = r1; r1 = r2; r2 = t; dir ^= 1; }
     uint32_t s = select_door(S, c, E, r1, dir);
+    PFM(41);
     uint32_t t = select_door(S, c, E, r2, dir ^ 1);
+    PFM(42);
     int k1 = (gen_meta(E, r1) & RM_KIND_MASK) == RK_NORMAL;
     int k2 = (gen_meta(E, r2) & RM_KIND_MASK) == RK_NORMAL;
     int bend;
@@ -409,6 +423,7 @@ __device__ __forceinline__ void connect_rooms(const RgState &S, const RgConfig &
         } else { S.edge_a[n_edges] = ea; S.edge_b[n_edges] = eb; }  // (S = the generator's LDS table view, gen_service)
         n_edges++;
     } else E.err |= RG_FLAG_ERR_INTERNAL;
+    PFM(43);
 }
 // replay one recorded corridor in registration order (passages.rs:98-132 + floor.rs:87-101): start door, end door, then the three legs.
 // The cells of one corridor are distinct, so the lanes fetch them all up front (cell i in lane i), the gen_attr draws run in
@@ -732,7 +747,9 @@ __device__ __forceinline__ typename RoomSet<BIG>::type gen_level(const RgState &
         uint32_t lev_add = lev_add_of(c, level);
         for (int i = 0; i < nrooms; i++) {
             uint32_t pos;
+            PFM(44);
             if (!room_select(S, c, E, i, ~0u, pos)) continue;
+            PFM(45);
             bool has_gold = gen_meta(E, i) & RM_HAS_GOLD;
             if (!parcent(E.re, has_gold ? c.appear_rate_gold : c.appear_rate_nogold)) continue;
             uint32_t len = (uint32_t)c.n_enemies;
@@ -740,6 +757,7 @@ __device__ __forceinline__ typename RoomSet<BIG>::type gen_level(const RgState &
             if (idx > len) { uint32_t rg = len < 5 ? len : 5; idx = (uint32_t)range64(E.re, len - rg, len); }
             if (idx >= len) continue;
             uint32_t type = idx;
+            PFM(46);
             int64_t mlevel = (int64_t)c.mon[type].level + lev_add, hp = 0;
             uint32_t exp_add;
             if (mlevel >= 1 && mlevel < (1 << 24)) {  // every real table: the eight rolls sum to < 2^27, so 32-bit adds and a 32-bit divide (the i64 `/ 6` alone is ~40 instructions)
@@ -754,10 +772,12 @@ __device__ __forceinline__ typename RoomSet<BIG>::type gen_level(const RgState &
                 int64_t base = mlevel == 1 ? hp / 8 : hp / 6;
                 exp_add = mlevel >= 10 ? (uint32_t)base * 20u : (uint32_t)base * 4u;
             }
+            PFM(47);
             S.mon_w0[i * n + e] = pos | (type << 16) | ((uint32_t)MF_ALIVE << 24);
             S.mon_hp[i * n + e] = (int32_t)hp;
             S.mon_exp[i * n + e] = c.mon[type].exp + lev_add * 10u + exp_add;
             E.mon_alive++;
+            PFM(48);
         }
     }
     pf.mark(15);
@@ -872,6 +892,9 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
         L.maze_stack = S.maze_stack + (size_t)real_e * S.maze_cap;
         U.e = 0; U.n = 1;
         U.g_rect = U.g_meta = U.g_ea = U.g_eb = 0;
+#ifdef RG_FINE_PROF
+        U.pfp = &pf;
+#endif
         const typename RoomSet<BIG>::type non_empty = gen_level<BIG>(L, c, U, pf);
         pf.mark(17);
         if (is_build) build_epilogue(L, c, U);
@@ -1000,6 +1023,7 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     Prof pf; pf.start(S.prof);
     E.on_stairs = 0;
     gen_service<BIG>(S, c, E, lane, e, valid, true, reinterpret_cast<uint16_t *>(g_smem), pf);
+    pf.finish();
     if (blockIdx.x == 0 && lane == 0) stair_recycle(S);
     stair_publish(S, lane, e, valid, E.on_stairs != 0);
     if (!valid) return;

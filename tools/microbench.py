@@ -62,7 +62,10 @@ if __name__ == "__main__":
 PHASES = {0: "load", 26: "window load", 1: "pre-gen/post-loop", 2: "gen_service", 28: "player action", 29: "turn_passed", 30: "mon prepass", 3: "dist lookup",
           27: "fill+flush", 4: "bfs", 5: "monsters", 6: "tail", 7: "stores + spare take"}
 GEN_PHASES = {8: "g.clear", 9: "g.rooms", 10: "g.paint", 11: "g.passages", 12: "g.corridors", 13: "g.gold", 14: "g.stair", 15: "g.monsters", 17: "g.reveal", 18: "g.place",
-              19: "g.hand-back", 21: "g.barrier", 16: "g.copy-out", 23: "g.barrier2", 20: "g.total"}
+              19: "g.hand-back", 21: "g.barrier", 16: "g.copy-out", 23: "g.barrier2", 20: "g.total",
+              # -DRG_FINE_PROF builds only: inside connect_rooms (40 = everything between two connects) and the monster loop
+              40: "f.tree/between", 41: "f.door1", 42: "f.door2", 43: "f.bend+record", 44: "f.mon.loop", 45: "f.mon.select", 46: "f.mon.appear+type", 47: "f.mon.hp",
+              48: "f.mon.store"}
 TICK_US = 1.0 / 2350.0  # s_memtime ticks at the shader clock (~2.35 GHz under this load; calibrated against the HIP-event kernel duration)
 
 
@@ -187,6 +190,10 @@ def single_gen(name, cfg, n=1, reps=200):
     L.rg_timing_read(h.h, ms, cnt)
     print("%-20s n=%d k_build avg %.1f us" % (name, n, ms[3] / cnt[3] * 1e3), flush=True)
     h.close()
+
+
+if __name__ == "__main__" and "profb" in sys.argv[1:]:
+    prof("k_build mini (16 envs per wave)", G["configs"]["mini"], b".", n=4096, do_reset=True)
 
 
 if __name__ == "__main__" and "gen1" in sys.argv[1:]:
