@@ -425,6 +425,7 @@ def main():
             "config": {"workload": "%s, %d envs per GPU (%d total), %s-image obs [N,%d,%d,%d] f32, max_steps 1000, auto-reset"
                                    % (hz.desc, n, n * world, hz.obs_kind, env.channels, env.height, env.width), "envs_per_gpu": n,
                        "parallelism": "env-sharded x%d, no data-path collective" % world},
+            "build_id": env._h.L.rg_build_id().decode(),  # sha256[:16] of the library's sources (__graft_entry__.source_id)
             "clock_warm": clock_warm,
             "preroll": preroll,
             "sclk_mhz_after_timed_region": sclk_after,

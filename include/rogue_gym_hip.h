@@ -58,6 +58,10 @@ void rg_destroy(rg_t *h);
 /* error text of the last failed call on `h` (h == NULL: last failed rg_create on this thread) */
 const char *rg_last_error(const rg_t *h);
 
+/* Build id: the first 16 hex digits of the sha256 over the library's sources (the csrc files and this header), so that a test can tell whether the library
+ * that is loaded was built from the sources that are checked out. */
+const char *rg_build_id(void);
+
 /* GameState::screen_size / symbols (python/src/lib.rs:226-228,255-257,295-300) */
 int rg_dims(const rg_t *h, int *height, int *width, int *symbols, int *n_env);
 /* Height and width of every env's own config (host arrays of n_env i32; either may be NULL).  Equal for all envs unless the batch mixes sizes. */

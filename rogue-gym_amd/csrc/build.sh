@@ -4,7 +4,8 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../librogue_gym_hip.so
-F="--offload-arch=gfx950 -std=c++17 -fPIC -Wall -Wno-unused-function"
+ID=$(python3 -c "import sys; sys.path.insert(0, '../..'); import __graft_entry__ as g; print(g.source_id())")   # compiled in as rg_build_id()
+F="--offload-arch=gfx950 -std=c++17 -fPIC -Wall -Wno-unused-function -DRG_BUILD_ID=\"$ID\""
 mkdir -p ../build
 hipcc $F -O3 -c rg_kernels.hip -o ../build/rg_kernels.o
 hipcc $F -Os -c rg_obs.hip -o ../build/rg_obs.o

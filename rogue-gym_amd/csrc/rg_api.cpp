@@ -149,6 +149,12 @@ extern "C" {
 
 const char *rg_last_error(const rg_t *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
+#ifndef RG_BUILD_ID
+#define RG_BUILD_ID "unstamped"
+#endif
+// sha256[:16] of the sources this library was built from (__graft_entry__.source_id); the marker makes it readable from the file without dlopen
+const char *rg_build_id(void) { static const char id[] = "RGBUILDID:" RG_BUILD_ID; return id + 10; }
+
 // what differs between the envs of one config group: the seed, or the range a fresh seed is drawn from
 struct EnvSeed { bool has_seed, has_range; uint64_t lo, hi; unsigned __int128 r0, r1; };
 

@@ -105,6 +105,8 @@ def load_library():
     L.rg_host_free.restype = None
     L.rg_dev_free.restype = None
     L.rg_last_error.restype = C.c_char_p
+    L.rg_build_id.restype = C.c_char_p
+    L.rg_build_id.argtypes = []
     for name in _INT_FUNCS:
         getattr(L, name).restype = C.c_int
     _lib = L

@@ -26,6 +26,13 @@ def test_header_symbols_exported(lib):
         assert hasattr(lib, n), "missing export %s" % n
 
 
+def test_loaded_library_is_built_from_the_checked_out_sources(lib):
+    """The .so is git-ignored and ships prebuilt to the GPU box: its compiled-in build id must be the hash of the sources in the tree."""
+    import __graft_entry__ as g
+    assert lib.rg_build_id().decode() == g.source_id()
+    assert g.library_id(os.path.join(ROOT, "rogue-gym_amd", "librogue_gym_hip.so")) == g.source_id()
+
+
 def _create(lib, cfgs, n=None):
     n = len(cfgs) if n is None else n
     arr = (C.c_char_p * n)(*[c if c is None else c.encode() for c in cfgs])

@@ -5,7 +5,7 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/../rogue-gym_amd/csrc"
 B=../build_$name; mkdir -p $B ../variants
-F="--offload-arch=gfx950 -std=c++17 -fPIC -Wall -Wno-unused-function $*"
+F="--offload-arch=gfx950 -std=c++17 -fPIC -Wall -Wno-unused-function -DRG_BUILD_ID=\"variant-$name\" $*"
 hipcc $F -O3 -c rg_kernels.hip -o $B/rg_kernels.o &
 hipcc $F -Os -c rg_obs.hip -o $B/rg_obs.o &
 hipcc $F -O2 -c rg_api.cpp -o $B/rg_api.o &
