@@ -188,12 +188,19 @@ def spawn_ranks(n):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
+    rc, live = 0, list(procs)
     try:
-        for p in procs:
-            rc = max(rc, abs(p.wait()))
+        while live:  # one rank failing must not leave the others blocked in a collective (and this process waiting on them) forever
+            for p in list(live):
+                r = p.poll()
+                if r is not None:
+                    live.remove(p)
+                    rc = max(rc, abs(r))
+            if rc:
+                break
+            time.sleep(0.2)
     finally:
-        for p in procs:  # one rank died: do not leave the others blocked in a collective
+        for p in procs:
             if p.poll() is None:
                 p.kill()
     return rc

@@ -317,6 +317,50 @@ def test_state_batch_images_and_value_objects(goldens):
     env.close()
 
 
+def test_lazy_state_batches_keep_value_semantics(goldens):
+    """Large batches keep their screens in a device-side snapshot until somebody looks (status / flags only cross PCIe per step).  The states must
+    still behave like the reference's cloned PlayerStates: a batch kept from step 10 shows step 10 whatever the envs did since -- looked at state by
+    state (one 2-row copy each), as a whole, through images(), and after the game was closed."""
+    from rogue_gym.envs import DungeonType, ImageSetting, ParallelRogueEnv, StatusFlag
+
+    n = 20000  # 2 x 10 MB of screens: above the eager threshold and above the "small snapshot" materialise-at-once limit
+    cfg = goldens["configs"]["mini"]
+    st = ImageSetting(DungeonType.GRAY, StatusFlag.DUNGEON_LEVEL, True)
+    env = ParallelRogueEnv([dict(cfg, seed=i) for i in range(n)], max_steps=25, image_setting=st)
+    sample = list(range(0, n, 997))
+    oracles = {i: make_oracles(cfg, [i], max_steps=25)[0] for i in sample}
+    rng = np.random.RandomState(12)
+    kept, want = {}, {}
+    for t in range(40):
+        a = rng.randint(0, 11, n)
+        states, rewards, dones, _ = env.step(a)
+        assert states._snap is not None and states._screen is None  # nothing but status / flags came to the host
+        for i, o in oracles.items():
+            o.step_autoreset(int(ACTION_KEYS[a[i]]))
+            assert int(states.gold[i]) == int(o.status_arr()[1]) and bool(dones[i]) == o.flags()["is_terminal"]
+        if t in (10, 20, 30):
+            kept[t] = states
+            want[t] = {i: (o.screen().copy(), o.hist().copy(), o.gray_image(st.status.value, True)) for i, o in oracles.items()}
+    # step 10: state by state (row copies from the device snapshot; the batch stays un-materialised)
+    for i in sample[:5]:
+        ps = kept[10][i]
+        assert np.array_equal(np.frombuffer("".join(ps.dungeon).encode("latin-1"), np.uint8).reshape(16, 32), want[10][i][0])
+    assert kept[10]._snap is not None
+    assert np.array_equal(kept[10][sample[1]].gray_image_with_hist(st.status.value), want[10][sample[1]][2])  # (a state's image comes from its batch's)
+    # step 20: as a whole
+    scr, hist = kept[20].screen, kept[20].hist
+    assert kept[20]._snap is None and scr.shape == (n, 16, 32)
+    for i in sample:
+        assert np.array_equal(scr[i], want[20][i][0]) and np.array_equal(hist[i], want[20][i][1])
+    # step 30: through images() of a batch the envs have moved past
+    img = st.expand_batch(kept[30])
+    for i in sample:
+        assert np.array_equal(img[i], want[30][i][2])
+    env.close()
+    for i in sample:  # step 10 again, after close(): materialised on the way out
+        assert np.array_equal(kept[10].screen[i], want[10][i][0])
+
+
 def test_workload_counters(goldens):
     import torch
     from rogue_gym.envs import HipVecRogueEnv
