@@ -565,6 +565,34 @@ def test_lockstep_init_items(goldens, name):
         assert set(packs) <= {base, base + 1} and base + 1 in packs
 
 
+def test_stair_seekers_with_a_strong_pack(goldens):
+    """A two-handed sword 4d4 +3,+3 and plate mail 7 + 2 carry a stairs-seeking player far deeper than the default pack: kills, level-ups (the
+    i64 hit-point rolls of Player::level_up), the monster tables of levels 5+ and their to-hit rolls against armor class 9 -- lock step."""
+    from test_gpu_parity import _stair_seeker_keys
+
+    cfg = dict(goldens["configs"]["mini"])
+    cfg["player"] = {"init_hp": 60, "init_items": [_W("two-handed-sword", 0, 3, 3), _A("plate mail", 2), _GOLD]}
+    n = 64
+    seeds = list(range(1700, 1700 + n))
+    hip = HipBatch(cfg, seeds, max_steps=500)
+    oracles = make_oracles(cfg, seeds, max_steps=500)
+    rng = np.random.RandomState(16)
+    stuck = [0] * n
+    deepest, best_plevel = 1, 1
+    for t in range(800):
+        keys = _stair_seeker_keys(oracles, rng, stuck)
+        hip.step(keys)
+        for i, o in enumerate(oracles):
+            o.step_autoreset(int(keys[i]))
+        compare_mirrors(hip, oracles, "t=%d" % t)
+        if t % 100 == 99:
+            compare_internal(hip, oracles, range(n), "t=%d" % t)
+        st = [o.status_arr() for o in oracles]
+        deepest = max(deepest, max(int(s[0]) for s in st))
+        best_plevel = max(best_plevel, max(int(s[7]) for s in st))
+    assert deepest >= 8 and best_plevel >= 4, (deepest, best_plevel)
+
+
 def test_full_pack_leaves_gold_on_the_floor(goldens):
     """HIP only: with a full pack and no Gold item nothing is ever picked up -- the gold count stays 0 over a long random walk although players
     do step onto gold (the '*' is still drawn after they leave), no reward is ever paid."""
