@@ -221,12 +221,12 @@ typedef struct rg_debug_state {
     int32_t px, py, dungeon_level, hp, hp_max, player_level, n_monsters, n_gold;
     uint32_t exp, food_left, quiet, pack_gold, steps;
     uint32_t rng[12];        /* dungeon, item, enemy streams x {x,y,z,w} */
-    int32_t mon_x[64], mon_y[64], mon_type[64], mon_active[64], mon_hp[64];   /* one slot per room, <= 64 rooms */
-    uint32_t mon_exp[64];
-    int32_t gold_x[64], gold_y[64], gold_amount[64];
-    int32_t n_rooms;         /* room_num_x * room_num_y, row-major room ids */
-    uint32_t room_rect[64];  /* x0 | y0<<8 | x1<<16 | y1<<24, half-open (Empty room: x0, y0 = its anchor cell) */
-    int32_t room_meta[64];   /* bits 0-1 kind (0 Normal, 1 Maze, 2 Empty; rooms.rs:11-19), 4 dark, 8 visited, 16 has gold */
+    int32_t mon_x[384], mon_y[384], mon_type[384], mon_active[384], mon_hp[384];   /* one slot per room; 160 x 48 holds at most 40 x 9 = 360 rooms */
+    uint32_t mon_exp[384];
+    int32_t gold_x[384], gold_y[384], gold_amount[384];
+    int32_t n_rooms;          /* room_num_x * room_num_y, row-major room ids */
+    uint32_t room_rect[384];  /* x0 | y0<<8 | x1<<16 | y1<<24, half-open (Empty room: x0, y0 = its anchor cell) */
+    int32_t room_meta[384];   /* bits 0-1 kind (0 Normal, 1 Maze, 2 Empty; rooms.rs:11-19), 4 dark, 8 visited, 16 has gold */
 } rg_debug_state;
 /* cells: u16 [H][W] = surface (bits 0-2, rogue/mod.rs:137-147) | door<<3 | CellAttr<<4 (field.rs:107-124) */
 int rg_debug_fetch(rg_t *h, int env, rg_debug_state *out, uint16_t *cells);

@@ -340,8 +340,8 @@ class OracleEnv:
         return dict(zip(keys, (int(v) for v in a)))
 
     def monsters(self):
-        buf = (OrcMonster * 128)()
-        n = self._L.orc_monsters(self._e, buf, 128)
+        buf = (OrcMonster * 512)()
+        n = self._L.orc_monsters(self._e, buf, 512)
         return [dict(x=m.x, y=m.y, type=m.type, active=m.active, running=m.running, hp=m.hp, max_hp=m.max_hp,
                      level=m.level, defense=m.defense, exp=m.exp) for m in buf[:n]]
 

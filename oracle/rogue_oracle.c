@@ -143,8 +143,9 @@ typedef struct {
     uint8_t *maze_passages;    /* Maze only */
 } room_t;
 
-#define MAX_ROOMS 64   /* rooms.rs:165-211 has no limit; 64 = what the product supports (10 x 4 rooms of 16 x 12 on 160 x 48 is 40) */
-#define MAX_MON 64
+#define MAX_ROOMS 384  /* rooms.rs:165-211 has no limit; geometry does: 160 x 48 with min_room_size 3 holds at most 40 x 9 = 360 rooms (stack scratch only:
+                        * the per-level room table and the monster tables are sized by the config) */
+#define MAX_MON MAX_ROOMS
 #define DIST_INF 0xFFFFFFFFu
 #define DIST_CACHE_CAP 10
 
@@ -152,10 +153,10 @@ typedef struct { int x, y, kind; } pcell_t; /* Positioned<Surface> */
 
 typedef struct {
     int n_rooms;
-    room_t rooms[MAX_ROOMS];
+    room_t *rooms;             /* [n_rooms], allocated per level (gen_rooms) */
     uint8_t *surface, *attr, *doors;
     int32_t *gold;      /* amount or -1 (Floor.items, floor.rs:25) */
-    uint8_t non_empty[MAX_ROOMS];
+    uint8_t *non_empty;        /* [n_rooms] */
 } floor_t;
 
 typedef struct { uint32_t *map; int kx, ky; } dcache_t;
@@ -183,8 +184,8 @@ struct orc_env {
     dcache_t dcache[DIST_CACHE_CAP]; int n_dcache;
     /* enemies */
     mstat_t stats[32]; int n_stats;       /* monster statuses sorted by rarity (enemies.rs:250-261); mon_t.type indexes this */
-    mon_t placed[MAX_MON]; int n_placed;  /* asleep */
-    mon_t active[MAX_MON]; int n_active;
+    mon_t *placed; int n_placed;  /* asleep; [rooms] each: at most one spawn per room per level (floor.rs:106-130) */
+    mon_t *active; int n_active;
     /* player (player.rs:280-306) */
     int px, py;
     int64_t hp, hp_max, plevel;
@@ -378,6 +379,8 @@ static void gen_rooms(orc_env *e, floor_t *fl, uint32_t level) {
         }
     }
     fl->n_rooms = room_num;
+    fl->rooms = calloc((size_t)room_num, sizeof(room_t));
+    fl->non_empty = calloc((size_t)room_num, 1);
     for (int i = 0; i < room_num; i++) {
         int x = i % rnx, y = i / rnx;
         int rsx = rsx0, rsy = rsy0, llx, lly;
@@ -532,7 +535,7 @@ static uint8_t gen_attr(orc_env *e, int surface, int is_dark, uint32_t level) {
 }
 static void floor_free(floor_t *fl) {
     for (int i = 0; i < fl->n_rooms; i++) room_free(&fl->rooms[i]);
-    free(fl->surface); free(fl->attr); free(fl->doors); free(fl->gold);
+    free(fl->surface); free(fl->attr); free(fl->doors); free(fl->gold); free(fl->rooms); free(fl->non_empty);
     memset(fl, 0, sizeof *fl);
 }
 /* Floor::gen_floor (floor.rs:50-104) */
@@ -1220,12 +1223,14 @@ orc_env *orc_new(const orc_config *cfg, uint64_t max_steps) {
     int n = e->W * e->H;
     e->screen = malloc(n); memset(e->screen, ' ', n);
     e->hist = calloc(n, 1);
+    e->placed = calloc((size_t)cfg->room_num_x * cfg->room_num_y + 1, sizeof(mon_t));
+    e->active = calloc((size_t)cfg->room_num_x * cfg->room_num_y + 1, sizeof(mon_t));
     if (runtime_build(e)) { orc_free(e); return NULL; } /* GameConfig::build failed in Player::init_items (core/src/lib.rs:209) */
     mirror_reset(e);
     e->steps = 0;
     return e;
 }
-void orc_free(orc_env *e) { if (!e) return; runtime_free(e); free(e->past_visited); free(e->screen); free(e->hist); free(e); }
+void orc_free(orc_env *e) { if (!e) return; runtime_free(e); free(e->past_visited); free(e->screen); free(e->hist); free(e->placed); free(e->active); free(e); }
 void orc_set_seed(orc_env *e, uint64_t lo, uint64_t hi) { e->cfg.seed_lo = lo; e->cfg.seed_hi = hi; }
 int orc_reset(orc_env *e) {
     if (runtime_build(e)) return 1; /* cannot happen: the same config built in orc_new */

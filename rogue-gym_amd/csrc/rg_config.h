@@ -4,10 +4,9 @@
 #include <string>
 #include <vector>
 
-#ifndef RG_MAX_ROOMS
-#define RG_MAX_ROOMS 64     // room_num_x * room_num_y (reference default 3x3; no limit there): room sets are 64-bit masks and the generator keeps its
-                            // room table one room per lane of the 64-wide wave; the monster table's `type` / flag byte layout is independent of it
-#endif
+#define RG_MAX_ROOMS 384    // room_num_x * room_num_y.  The reference has no limit (rooms.rs:165-211); geometry has: 160 x 48 with min_room_size 3 holds at most
+                            // 40 x 9 = 360 rooms.  Three generator instances (rg_kernels.hip): <= 32 rooms, <= 64, <= 384.
+#define RG_OBS_MAX_ROOMS 64 // the fused observation kernel stages its overlay tables in LDS for up to 64 rooms; larger grids take the unfused render + encode
 #define RG_MAX_ENEMY_KINDS 26
 #define RG_MAX_W 160        // core/src/lib.rs:134-140
 #define RG_MAX_H 48

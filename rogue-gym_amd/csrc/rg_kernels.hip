@@ -147,10 +147,16 @@ struct Env {
     uint32_t g_ea, g_eb;  // ... and the corridor records (edge k in lane k; a level has fewer than 2 x rooms, records >= 64 -- only possible with more
                           // than 32 rooms -- go to GenTabs::edge_a / edge_b in LDS), replayed for the deferred gen_attr draws
 };
-__device__ __forceinline__ uint32_t gen_rect(const Env &E, int i) { return lane_get(E.g_rect, i); }
-__device__ __forceinline__ uint32_t gen_meta(const Env &E, int i) { return lane_get(E.g_meta, i); }
-__device__ __forceinline__ void gen_set_rect(Env &E, int i, uint32_t v) { E.g_rect = (int)threadIdx.x == i ? v : E.g_rect; }
-__device__ __forceinline__ void gen_set_meta(Env &E, int i, uint32_t v) { E.g_meta = (int)threadIdx.x == i ? v : E.g_meta; }
+// GM = the generator instance: 0 up to 32 rooms, 1 up to 64 (both: lane-indexed registers), 2 up to RG_MAX_ROOMS (more rooms than lanes: the
+// tables stay in the generator's LDS view S = L of gen_service, column 0 of a one-env SoA)
+template <int GM> __device__ __forceinline__ uint32_t gen_rect(const RgState &S, const Env &E, int i) { return GM < 2 ? lane_get(E.g_rect, i) : uni(S.room_rect[i]); }
+template <int GM> __device__ __forceinline__ uint32_t gen_meta(const RgState &S, const Env &E, int i) { return GM < 2 ? lane_get(E.g_meta, i) : uni((uint32_t)S.room_meta[i]); }
+template <int GM> __device__ __forceinline__ void gen_set_rect(const RgState &S, Env &E, int i, uint32_t v) {
+    if (GM < 2) E.g_rect = (int)threadIdx.x == i ? v : E.g_rect; else S.room_rect[i] = v;
+}
+template <int GM> __device__ __forceinline__ void gen_set_meta(const RgState &S, Env &E, int i, uint32_t v) {
+    if (GM < 2) E.g_meta = (int)threadIdx.x == i ? v : E.g_meta; else S.room_meta[i] = (uint8_t)v;
+}
 
 // ---------------------------------------------------------------------------------------------
 // monsters table helpers
@@ -207,17 +213,18 @@ __device__ __forceinline__ void activate_room(const RgState &S, const RgConfig &
 // field-of-view at level entry (floor.rs:201-312).  The per-step form lives in move_player (register window).
 // ---------------------------------------------------------------------------------------------
 // Floor::player_in(cd, init = true) on the LDS staging grid, wave-uniform (called from place_player)
+template <int GM>
 __device__ __forceinline__ void player_in_init(const RgState &S, const RgConfig &c, Env &E, int x, int y) {
     lds_u16 *cell = E.lc;
     int W = c.width;
     int rid = room_id_of(c, x, y);
     if (rid >= 0) {
-        uint32_t meta = gen_meta(E, rid);
+        uint32_t meta = gen_meta<GM>(S, E, rid);
         if (!(meta & RM_VISITED)) {  // Floor::enters_room (floor.rs:231-247)
-            gen_set_meta(E, rid, meta | RM_VISITED);
+            gen_set_meta<GM>(S, E, rid, meta | RM_VISITED);
             if ((meta & RM_KIND_MASK) == RK_NORMAL && !(meta & RM_DARK)) {
                 int x0, y0, x1, y1;
-                unpack_rect(gen_rect(E, rid), x0, y0, x1, y1);
+                unpack_rect(gen_rect<GM>(S, E, rid), x0, y0, x1, y1);
                 const int rw = x1 - x0, area = rw * (y1 - y0);
                 for (int t = threadIdx.x; t < area; t += WAVE) {  // one cell per lane
                     const int yy = small_div(t, rw), xx = t - yy * rw;
@@ -284,12 +291,13 @@ __device__ __forceinline__ int rect_count(const RgConfig &c, const Env &E, int x
 // free-cell selection.  The reference keeps a FenwickSet per room; only `nth` over "members minus a
 // handful of filled cells" is ever observed during level creation, so the set is
 // implicit: interior cells (Normal) or C_MAZE cells (Maze) in row-major order, minus `excl`.
+template <int GM>
 __device__ __forceinline__ bool room_select(const RgState &S, const RgConfig &c, Env &E, int rid, uint32_t excl /* pos or ~0u */, uint32_t &out) {
-    uint32_t meta = gen_meta(E, rid);
+    uint32_t meta = gen_meta<GM>(S, E, rid);
     int kind = meta & RM_KIND_MASK;
     if (kind == RK_EMPTY) return false;
     int x0, y0, x1, y1;
-    unpack_rect(gen_rect(E, rid), x0, y0, x1, y1);
+    unpack_rect(gen_rect<GM>(S, E, rid), x0, y0, x1, y1);
     if (kind == RK_NORMAL) {
         int iw = x1 - x0 - 2, ih = y1 - y0 - 2;
         int count = iw * ih;
@@ -314,32 +322,96 @@ __device__ __forceinline__ int nth_bit(uint32_t m, int nth) {
     for (int i = 0; i < nth; i++) m &= m - 1;
     return __ffs((int)m) - 1;
 }
-// Room sets are bit masks, wave-uniform in the generator (scalar unit).  The generator comes in two instances: BIG = false for room grids of
-// up to 32 rooms (32-bit sets; every corridor record fits the 64 lanes) -- the only one the W <= 32 step kernel contains, whose descent chain
-// bounds the headline launch -- and BIG = true for up to RG_MAX_ROOMS = 64 rooms (64-bit sets, corridor records beyond 64 in LDS): measured on
-// the mini dungeon, the 64-bit form costs a generation 1.3 us of 28 (round 3).
-template <bool BIG> struct RoomSet { typedef uint32_t type; };
-template <> struct RoomSet<true> { typedef uint64_t type; };
-template <typename M> __device__ __forceinline__ M rbit(int i) { return (M)1 << i; }
-template <typename M> __device__ __forceinline__ M rmask_all(int nrooms) { return nrooms >= (int)(8 * sizeof(M)) ? ~(M)0 : (rbit<M>(nrooms) - 1); }
-__device__ __forceinline__ int rpop(uint32_t m) { return __popc(m); }
-__device__ __forceinline__ int rpop(uint64_t m) { return __popcll(m); }
-__device__ __forceinline__ int nth_room(uint32_t m, int nth) { return nth_bit(m, nth); }
-__device__ __forceinline__ int nth_room(uint64_t m, int nth) {
+// Room sets are bit masks, wave-uniform in the generator (scalar unit).  The generator comes in three instances (GM): 0 for room grids of up to 32
+// rooms (32-bit sets; every corridor record fits the 64 lanes) -- the only one the W <= 32 step kernel contains, whose descent chain bounds the
+// headline launch --, 1 for up to 64 rooms (64-bit sets, corridor records beyond 64 in LDS; measured on the mini dungeon, the 64-bit form costs a
+// generation 1.3 us of 28), and 2 for up to RG_MAX_ROOMS = 384 (six 64-bit words; the room table in LDS instead of one room per lane): the
+// reference has no limit (rooms.rs:165-211), geometry has -- 160 x 48 with min_room_size 3 holds at most 40 x 9 = 360 rooms.
+struct RS6 { uint64_t w[6]; };
+template <int GM> struct RoomSet { typedef uint32_t type; };
+template <> struct RoomSet<1> { typedef uint64_t type; };
+template <> struct RoomSet<2> { typedef RS6 type; };
+__device__ __forceinline__ int nth_set64_scalar(uint64_t m, int nth) {
     for (int i = 0; i < nth; i++) m &= m - 1;
     return __ffsll((long long)m) - 1;
 }
+// -- 32 / 64-bit sets
+__device__ __forceinline__ void rs_clear(uint32_t &m) { m = 0; }
+__device__ __forceinline__ void rs_clear(uint64_t &m) { m = 0; }
+__device__ __forceinline__ void rs_fill(uint32_t &m, int n) { m = n >= 32 ? ~0u : ((1u << n) - 1u); }
+__device__ __forceinline__ void rs_fill(uint64_t &m, int n) { m = n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+__device__ __forceinline__ void rs_set(uint32_t &m, int i) { m |= 1u << i; }
+__device__ __forceinline__ void rs_set(uint64_t &m, int i) { m |= 1ull << i; }
+__device__ __forceinline__ void rs_reset(uint32_t &m, int i) { m &= ~(1u << i); }
+__device__ __forceinline__ void rs_reset(uint64_t &m, int i) { m &= ~(1ull << i); }
+__device__ __forceinline__ bool rs_test(uint32_t m, int i) { return (m >> (i & 31)) & 1u; }
+__device__ __forceinline__ bool rs_test(uint64_t m, int i) { return (m >> (i & 63)) & 1ull; }
+__device__ __forceinline__ int rs_count(uint32_t m) { return __popc(m); }
+__device__ __forceinline__ int rs_count(uint64_t m) { return __popcll(m); }
+__device__ __forceinline__ int rs_nth(uint32_t m, int nth) { return nth_bit(m, nth); }
+__device__ __forceinline__ int rs_nth(uint64_t m, int nth) { return nth_set64_scalar(m, nth); }
+__device__ __forceinline__ bool rs_any(uint32_t m) { return m != 0; }
+__device__ __forceinline__ bool rs_any(uint64_t m) { return m != 0; }
+__device__ __forceinline__ void rs_remove(uint32_t &m, uint32_t o) { m &= ~o; }
+__device__ __forceinline__ void rs_remove(uint64_t &m, uint64_t o) { m &= ~o; }
+// -- six-word sets (word index by select chains: a run-time array index would put the set into scratch memory)
+__device__ __forceinline__ void rs_clear(RS6 &m) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) m.w[j] = 0;
+}
+__device__ __forceinline__ void rs_fill(RS6 &m, int n) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) { const int r = n - 64 * j; m.w[j] = r >= 64 ? ~0ull : (r > 0 ? ((1ull << r) - 1ull) : 0ull); }
+}
+__device__ __forceinline__ void rs_set(RS6 &m, int i) {
+    const uint64_t b = 1ull << (i & 63); const int k = i >> 6;
+#pragma unroll
+    for (int j = 0; j < 6; j++) m.w[j] |= j == k ? b : 0ull;
+}
+__device__ __forceinline__ void rs_reset(RS6 &m, int i) {
+    const uint64_t b = 1ull << (i & 63); const int k = i >> 6;
+#pragma unroll
+    for (int j = 0; j < 6; j++) m.w[j] &= j == k ? ~b : ~0ull;
+}
+__device__ __forceinline__ bool rs_test(const RS6 &m, int i) {
+    const int k = i >> 6; uint64_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) w = j == k ? m.w[j] : w;
+    return i >= 0 && ((w >> (i & 63)) & 1ull);
+}
+__device__ __forceinline__ int rs_count(const RS6 &m) {
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) c += __popcll(m.w[j]);
+    return c;
+}
+__device__ __forceinline__ int rs_nth(const RS6 &m, int nth) {
+    int res = -1;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const int c = __popcll(m.w[j]);
+        if (res < 0 && nth < c) res = 64 * j + nth_set64_scalar(m.w[j], nth);
+        nth -= c;
+    }
+    return res;
+}
+__device__ __forceinline__ bool rs_any(const RS6 &m) { return (m.w[0] | m.w[1] | m.w[2] | m.w[3] | m.w[4] | m.w[5]) != 0; }
+__device__ __forceinline__ void rs_remove(RS6 &m, const RS6 &o) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) m.w[j] &= ~o.w[j];
+}
 // Floor::select_cell (floor.rs:333-346)
-template <typename M>
-__device__ __forceinline__ bool floor_select(const RgState &S, const RgConfig &c, Env &E, M non_empty, int mode /*0 stair, 1 player*/, uint32_t &out) {
-    M cand = non_empty;
-    while (cand) {
-        int idx = nth_room(cand, (int)range64(E.rd, 0, (uint64_t)rpop(cand)));
+template <int GM>
+__device__ __forceinline__ bool floor_select(const RgState &S, const RgConfig &c, Env &E, const typename RoomSet<GM>::type &non_empty, int mode /*0 stair, 1 player*/,
+                                             uint32_t &out) {
+    typename RoomSet<GM>::type cand = non_empty;
+    while (rs_any(cand)) {
+        int idx = rs_nth(cand, (int)range64(E.rd, 0, (uint64_t)rs_count(cand)));
         uint32_t excl = ~0u;
         if (mode == 0) { uint32_t g = uni(S.gold_pos[idx * E.n + E.e]); if (g & 0x10000u) excl = g & 0xffff; }
         else { uint32_t w = uni(S.mon_w0[idx * E.n + E.e]); if ((w >> 24) & MF_ALIVE) excl = w & 0xffff; }
-        if (room_select(S, c, E, idx, excl, out)) return true;
-        cand &= ~rbit<M>(idx);
+        if (room_select<GM>(S, c, E, idx, excl, out)) return true;
+        rs_reset(cand, idx);
     }
     return false;
 }
@@ -353,11 +425,12 @@ __device__ __forceinline__ uint32_t gen_attr_corridor(const RgConfig &c, Env &E,
     return 0;
 }
 // select_start_or_end (passages.rs:143-179).  dir: 0 Up 1 Down 2 Left 3 Right
+template <int GM>
 __device__ __forceinline__ uint32_t select_door(const RgState &S, const RgConfig &c, Env &E, int rid, int dir) {
-    uint32_t meta = gen_meta(E, rid);
+    uint32_t meta = gen_meta<GM>(S, E, rid);
     int kind = meta & RM_KIND_MASK;
     int x0, y0, x1, y1;
-    unpack_rect(gen_rect(E, rid), x0, y0, x1, y1);
+    unpack_rect(gen_rect<GM>(S, E, rid), x0, y0, x1, y1);
     if (kind == RK_EMPTY) return POS(x0, y0);
     if (kind == RK_NORMAL) {  // edges(range, dir, inclusive): the wall without its corners; SliceRandom::choose = 64-bit draw
         if (dir < 2) {
@@ -399,25 +472,25 @@ __device__ __forceinline__ uint32_t select_door(const RgState &S, const RgConfig
 
 // connect_2rooms (passages.rs:84-133): draws the two doors and the bend now, records the corridor for
 // the deferred gen_attr pass (the reference collects Positioned<Surface> in a Vec, floor.rs:73-86)
-template <bool BIG>
+template <int GM>
 __device__ __forceinline__ void connect_rooms(const RgState &S, const RgConfig &c, Env &E, int r1, int r2, int dir, int &n_edges) {
 #ifdef RG_FINE_PROF
     Prof &pf = *E.pfp;
 #endif
     PFM(40);
     if (dir == 0 || dir == 2) { int t = r1; r1 = r2; r2 = t; dir ^= 1; }
-    uint32_t s = select_door(S, c, E, r1, dir);
+    uint32_t s = select_door<GM>(S, c, E, r1, dir);
     PFM(41);
-    uint32_t t = select_door(S, c, E, r2, dir ^ 1);
+    uint32_t t = select_door<GM>(S, c, E, r2, dir ^ 1);
     PFM(42);
-    int k1 = (gen_meta(E, r1) & RM_KIND_MASK) == RK_NORMAL;
-    int k2 = (gen_meta(E, r2) & RM_KIND_MASK) == RK_NORMAL;
+    int k1 = (gen_meta<GM>(S, E, r1) & RM_KIND_MASK) == RK_NORMAL;
+    int k2 = (gen_meta<GM>(S, E, r2) & RM_KIND_MASK) == RK_NORMAL;
     int bend;
     if (dir == 1) bend = (int)range32(E.rd, (uint32_t)(POS_Y(s) + 1), (uint32_t)POS_Y(t));
     else bend = (int)range32(E.rd, (uint32_t)(POS_X(s) + 1), (uint32_t)POS_X(t));
-    if (n_edges < RG_MAX_EDGES) {  // always: RG_MAX_EDGES >= the number of grid-adjacent room pairs (rg_state.h)
+    if (n_edges < 2 * c.room_num_x * c.room_num_y) {  // always: a level has fewer corridors than 2 x rooms, the size of the record tables (rg_state.h)
         const uint32_t ea = s | (t << 16), eb = (uint32_t)bend | ((uint32_t)(dir == 1) << 8) | ((uint32_t)k1 << 9) | ((uint32_t)k2 << 10);
-        if (!BIG || n_edges < WAVE) {  // (<= 32 rooms: fewer than 64 records)
+        if (GM == 0 || n_edges < WAVE) {  // (<= 32 rooms: fewer than 64 records)
             E.g_ea = (int)threadIdx.x == n_edges ? ea : E.g_ea;
             E.g_eb = (int)threadIdx.x == n_edges ? eb : E.g_eb;
         } else { S.edge_a[n_edges] = ea; S.edge_b[n_edges] = eb; }  // (S = the generator's LDS table view, gen_service)
@@ -475,7 +548,7 @@ __device__ __forceinline__ void paint_corridor(const RgConfig &c, Env &E, uint32
 // excl_set: rooms excluded by id (the spanning tree's `selected`); excl_dirs: candidate slots excluded directly (bit k = slot k in the order
 // Up, Left, Right, Down: the room graph keeps, per room, which of its four neighbours it is already joined to)
 template <typename M>
-__device__ __forceinline__ int select_candidate(const RgConfig &c, Env &E, int nrooms, int node, M excl_set, uint32_t excl_dirs, int &dir_out) {
+__device__ __forceinline__ int select_candidate(const RgConfig &c, Env &E, int nrooms, int node, const M &excl_set, uint32_t excl_dirs, int &dir_out) {
     const int rnx = c.room_num_x, rny = c.room_num_y;
     const int ny0 = small_div(node, rnx), nx0 = node - ny0 * rnx;
     // candidate slots in ascending room id; direction codes 0 Up 1 Down 2 Left 3 Right
@@ -485,7 +558,7 @@ __device__ __forceinline__ int select_candidate(const RgConfig &c, Env &E, int n
     uint32_t cand = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++)
-        if (ok[k] && !((excl_set >> (ids[k] & (int)(8 * sizeof(M) - 1))) & 1u) && !((excl_dirs >> k) & 1u)) cand |= 1u << k;
+        if (ok[k] && !rs_test(excl_set, ok[k] ? ids[k] : 0) && !((excl_dirs >> k) & 1u)) cand |= 1u << k;
     if (!cand) return -1;
     const int k = nth_bit(cand, reservoir4(E.rd, __popc(cand)));
     int res = ids[0];
@@ -511,7 +584,7 @@ struct GenTabs {
     uint8_t *room_meta;
 };
 #define GEN_GRID_BYTES(hw) ((((size_t)(hw)) * 2 + 15) & ~(size_t)15)
-#define GEN_TABS_BYTES(nr) ((((size_t)(nr)) * 41 + GEN_STACK_LDS * 2 + 15) & ~(size_t)15)
+#define GEN_TABS_BYTES(nr) ((((size_t)(nr)) * 42 + GEN_STACK_LDS * 2 + 15) & ~(size_t)15)   // (+ a byte per room behind room_meta: the room graph of GM 2)
 #define GEN_SLOT_BYTES(hw, nr) (GEN_GRID_BYTES(hw) + GEN_TABS_BYTES(nr))
 __device__ __forceinline__ GenTabs gen_tabs(uint8_t *slot, int hw, int nr) {
     uint32_t *w = reinterpret_cast<uint32_t *>(slot + GEN_GRID_BYTES(hw));
@@ -578,9 +651,9 @@ __device__ __forceinline__ void dig_maze(const RgState &S, const RgConfig &c, En
 }
 
 // Dungeon::new_level_ (rogue/mod.rs:434-481).  Returns the bitmask of non-empty rooms.
-template <bool BIG>
-__device__ __forceinline__ typename RoomSet<BIG>::type gen_level(const RgState &S, const RgConfig &c, Env &E, Prof &pf) {
-    typedef typename RoomSet<BIG>::type rmask_t;
+template <int GM>
+__device__ __forceinline__ typename RoomSet<GM>::type gen_level(const RgState &S, const RgConfig &c, Env &E, Prof &pf) {
+    typedef typename RoomSet<GM>::type rmask_t;
     const int W = c.width, H = c.height, HW = W * H, n = E.n, e = E.e;
     const int rnx = c.room_num_x, nrooms = rnx * c.room_num_y;
     lds_u16 *cell = E.lc;
@@ -606,13 +679,15 @@ __device__ __forceinline__ typename RoomSet<BIG>::type gen_level(const RgState &
     // ---- gen_rooms (rooms.rs:165-211) ----
     uint32_t empty_num = range32(E.rd, 0, c.max_empty_rooms + 1);
     if (empty_num >= (uint32_t)nrooms) empty_num = nrooms - 1;
-    rmask_t empty_mask = 0;
+    rmask_t empty_mask;
+    rs_clear(empty_mask);
     {
-        rmask_t sel = rmask_all<rmask_t>(nrooms);
+        rmask_t sel;
+        rs_fill(sel, nrooms);
         for (uint32_t k = 0; k < empty_num; k++) {  // rng.select(0..room_num).take(empty_num): 64-bit nth
-            int id = nth_room(sel, (int)range64(E.rd, 0, (uint64_t)rpop(sel)));
-            sel &= ~rbit<rmask_t>(id);
-            empty_mask |= rbit<rmask_t>(id);
+            int id = rs_nth(sel, (int)range64(E.rd, 0, (uint64_t)rs_count(sel)));
+            rs_reset(sel, id);
+            rs_set(empty_mask, id);
         }
     }
     for (int i = 0; i < nrooms; i++) {  // make_room (rooms.rs:214-269)
@@ -620,7 +695,7 @@ __device__ __forceinline__ typename RoomSet<BIG>::type gen_level(const RgState &
         assigned_area(c, i, ax0, ay0, ax1, ay1);
         int rsx = ax1 - ax0, rsy = ay1 - ay0;
         uint32_t rect; uint8_t meta;
-        if ((empty_mask >> i) & 1) {
+        if (rs_test(empty_mask, i)) {
             int x = (int)range32(E.rd, 1, (uint32_t)(rsx - 1)) + ax0;
             int y = (int)range32(E.rd, 1, (uint32_t)(rsy - 1)) + ay0;
             rect = (uint32_t)x | ((uint32_t)y << 8);
@@ -641,17 +716,17 @@ __device__ __forceinline__ typename RoomSet<BIG>::type gen_level(const RgState &
                 meta = RK_NORMAL | (dark ? RM_DARK : 0);
             }
         }
-        gen_set_rect(E, i, rect);
-        gen_set_meta(E, i, meta);
+        gen_set_rect<GM>(S, E, i, rect);
+        gen_set_meta<GM>(S, E, i, meta);
     }
     pf.mark(9);
     // ---- paint rooms in id order (floor.rs:61-71; Room::draw rooms.rs:58-82) ----
     for (int i = 0; i < nrooms; i++) {
-        uint32_t meta = gen_meta(E, i);
+        uint32_t meta = gen_meta<GM>(S, E, i);
         int kind = meta & RM_KIND_MASK;
         if (kind == RK_EMPTY) continue;
         int x0, y0, x1, y1;
-        unpack_rect(gen_rect(E, i), x0, y0, x1, y1);
+        unpack_rect(gen_rect<GM>(S, E, i), x0, y0, x1, y1);
         if (kind == RK_NORMAL) {
             const uint16_t fl = (uint16_t)(S_FLOOR | ((meta & RM_DARK) ? C_DARK : 0));
             const int rw = x1 - x0, rh = y1 - y0, area = rw * rh;
@@ -680,62 +755,73 @@ __device__ __forceinline__ typename RoomSet<BIG>::type gen_level(const RgState &
         // the room graph (passages.rs:222-270): per room, which of its four grid neighbours it is already joined to -- 4 bits (slot order Up, Left, Right,
         // Down), room i's in LANE i of one VGPR (<= 64 rooms = 64 lanes), read with v_readlane and updated with a lane-select.  (A `conn[rooms]`
         // array indexed at run time lived in scratch memory: a memory round trip per access inside this RNG-ordered chain.)
+        // (GM 2, more rooms than lanes: a byte per room in LDS, right behind the generator's room_meta table -- gen_tabs)
         uint32_t conn_v = 0;
+        uint8_t *conn_lds = S.room_meta + nrooms;
+        if (GM == 2) {
+            for (int i = threadIdx.x; i < nrooms; i += WAVE) conn_lds[i] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
         const int lane_id = (int)threadIdx.x;
-        auto conn_get = [&](int i) -> uint32_t { return lane_get(conn_v, i); };
+        auto conn_get = [&](int i) -> uint32_t { return GM < 2 ? lane_get(conn_v, i) : uni((uint32_t)conn_lds[i]); };
         auto conn_join = [&](int a, int b, int dir_ab) {  // dir_ab: 0 Up 1 Down 2 Left 3 Right, as seen from a
             const uint32_t slot_of_dir = 0x2130u;         // direction code -> candidate slot (nibbles): Up 0, Down 3, Left 1, Right 2
             const uint32_t ka = (slot_of_dir >> (4 * dir_ab)) & 3u, kb = (slot_of_dir >> (4 * (dir_ab ^ 1))) & 3u;
-            conn_v = lane_id == a ? (conn_v | (1u << ka)) : (lane_id == b ? (conn_v | (1u << kb)) : conn_v);
+            if (GM < 2) conn_v = lane_id == a ? (conn_v | (1u << ka)) : (lane_id == b ? (conn_v | (1u << kb)) : conn_v);
+            else { conn_lds[a] = (uint8_t)(uni((uint32_t)conn_lds[a]) | (1u << ka)); conn_lds[b] = (uint8_t)(uni((uint32_t)conn_lds[b]) | (1u << kb)); }
         };
-        rmask_t selected = 0;
+        rmask_t selected, none;
+        rs_clear(selected); rs_clear(none);
         int cur = (int)range64(E.rd, 0, (uint64_t)nrooms), n_sel = 1;
-        selected |= rbit<rmask_t>(cur);
+        rs_set(selected, cur);
         while (n_sel < nrooms) {
             int dir = 0;
             int nxt = select_candidate<rmask_t>(c, E, nrooms, cur, selected, 0u, dir);
             if (nxt >= 0) {
-                selected |= rbit<rmask_t>(nxt); n_sel++;
+                rs_set(selected, nxt); n_sel++;
                 conn_join(cur, nxt, dir);
-                connect_rooms<BIG>(S, c, E, cur, nxt, dir, n_edges);
+                connect_rooms<GM>(S, c, E, cur, nxt, dir, n_edges);
             } else {
-                cur = nth_room(selected, (int)range64(E.rd, 0, (uint64_t)n_sel));
+                cur = rs_nth(selected, (int)range64(E.rd, 0, (uint64_t)n_sel));
             }
         }
         uint32_t try_num = range32(E.rd, 0, c.max_extra_edges);
         for (uint32_t t = 0; t < try_num; t++) {
             int room1 = (int)range64(E.rd, 0, (uint64_t)nrooms), dir = 0;
-            int room2 = select_candidate<rmask_t>(c, E, nrooms, room1, (rmask_t)0, conn_get(room1), dir);
+            int room2 = select_candidate<rmask_t>(c, E, nrooms, room1, none, conn_get(room1), dir);
             if (room2 >= 0) {
                 conn_join(room1, room2, dir);
-                connect_rooms<BIG>(S, c, E, room1, room2, dir, n_edges);
+                connect_rooms<GM>(S, c, E, room1, room2, dir, n_edges);
             }
         }
     }
     pf.mark(11);
     for (int k = 0; k < n_edges; k++) {
-        if (!BIG || k < WAVE) paint_corridor(c, E, lane_get(E.g_ea, k), lane_get(E.g_eb, k), level);
+        if (GM == 0 || k < WAVE) paint_corridor(c, E, lane_get(E.g_ea, k), lane_get(E.g_eb, k), level);
         else paint_corridor(c, E, uni(S.edge_a[k]), uni(S.edge_b[k]), level);
     }
 
-    const rmask_t non_empty = rmask_all<rmask_t>(nrooms) & ~empty_mask;
+    rmask_t non_empty;
+    rs_fill(non_empty, nrooms);
+    rs_remove(non_empty, empty_mask);
     pf.mark(12);
     // ---- gold (floor.rs:132-153, item/gold.rs:18-24) ----
     for (int i = 0; i < nrooms; i++) {
         uint32_t pos;
-        if (!room_select(S, c, E, i, ~0u, pos)) continue;
+        if (!room_select<GM>(S, c, E, i, ~0u, pos)) continue;
         if (!does_happen(E.ri, c.gold_rate_inv)) continue;
         uint32_t num = range32(E.ri, 0, c.gold_base + c.gold_per_level * level) + c.gold_minimum;
         S.gold_pos[i * n + e] = pos | 0x10000u;
         S.gold_amt[i * n + e] = num;
-        gen_set_meta(E, i, gen_meta(E, i) | RM_HAS_GOLD);
+        gen_set_meta<GM>(S, E, i, gen_meta<GM>(S, E, i) | RM_HAS_GOLD);
         cell[POS_Y(pos) * W + POS_X(pos)] |= C_GOLD;
     }
     pf.mark(13);
     // ---- stair (floor.rs:156-167) ----
     {
         uint32_t pos;
-        if (floor_select(S, c, E, non_empty, 0, pos)) {
+        if (floor_select<GM>(S, c, E, non_empty, 0, pos)) {
             uint32_t v = uni(cell[POS_Y(pos) * W + POS_X(pos)]);
             cell[POS_Y(pos) * W + POS_X(pos)] = (uint16_t)((v & ~C_SURF_MASK) | S_STAIR);
         }
@@ -748,9 +834,9 @@ __device__ __forceinline__ typename RoomSet<BIG>::type gen_level(const RgState &
         for (int i = 0; i < nrooms; i++) {
             uint32_t pos;
             PFM(44);
-            if (!room_select(S, c, E, i, ~0u, pos)) continue;
+            if (!room_select<GM>(S, c, E, i, ~0u, pos)) continue;
             PFM(45);
-            bool has_gold = gen_meta(E, i) & RM_HAS_GOLD;
+            bool has_gold = gen_meta<GM>(S, E, i) & RM_HAS_GOLD;
             if (!parcent(E.re, has_gold ? c.appear_rate_gold : c.appear_rate_nogold)) continue;
             uint32_t len = (uint32_t)c.n_enemies;
             uint32_t idx = range32(E.re, mn, mx);
@@ -787,13 +873,13 @@ __device__ __forceinline__ typename RoomSet<BIG>::type gen_level(const RgState &
 }
 
 // actions::new_level's tail (actions.rs:130-137): place the player and enter the room
-template <typename M>
-__device__ __forceinline__ void place_player(const RgState &S, const RgConfig &c, Env &E, M non_empty) {
+template <int GM>
+__device__ __forceinline__ void place_player(const RgState &S, const RgConfig &c, Env &E, const typename RoomSet<GM>::type &non_empty) {
     uint32_t pos = 0;
-    floor_select(S, c, E, non_empty, 1, pos);
+    floor_select<GM>(S, c, E, non_empty, 1, pos);
     E.px = POS_X(pos); E.py = POS_Y(pos);
     E.on_stairs = (uni(E.lc[E.py * c.width + E.px]) & C_SURF_MASK) == S_STAIR;  // (select_cell only avoids characters: the stairs are a legal spot)
-    player_in_init(S, c, E, E.px, E.py);
+    player_in_init<GM>(S, c, E, E.px, E.py);
 }
 
 // GameConfig::build (core/src/lib.rs:193-228), split around the level generator
@@ -867,7 +953,7 @@ __device__ __forceinline__ void env_to_lane(Env &E, const Env &U) {  // the gene
 }
 static_assert(sizeof(Rng) == 16, "Rng is 4 words");
 
-template <bool BIG>
+template <int GM>
 __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c, Env &E, int lane, int e, bool need, bool is_build,
                                             uint16_t *lds_grid, Prof &pf) {
     const int HW = c.width * c.height, nrooms = c.room_num_x * c.room_num_y;
@@ -895,13 +981,13 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
 #ifdef RG_FINE_PROF
         U.pfp = &pf;
 #endif
-        const typename RoomSet<BIG>::type non_empty = gen_level<BIG>(L, c, U, pf);
+        const typename RoomSet<GM>::type non_empty = gen_level<GM>(L, c, U, pf);
         pf.mark(17);
         if (is_build) build_epilogue(L, c, U);
-        place_player(L, c, U, non_empty);
+        place_player<GM>(L, c, U, non_empty);
         pf.mark(18);
         U.e = real_e; U.n = real_n;
-        if (lane < nrooms) { T->room_rect[lane] = U.g_rect; T->room_meta[lane] = (uint8_t)U.g_meta; }  // the room table, for the copy-out below
+        if (GM < 2 && lane < nrooms) { T->room_rect[lane] = U.g_rect; T->room_meta[lane] = (uint8_t)U.g_meta; }  // the room table, for the copy-out below (GM 2: already there)
         if (lane == src) {
             env_to_lane(E, U); need = false;
             // k_step's LDS monster cache of the requesting lane: filled straight from the generator's table (the alternative -- reloading the column
@@ -911,12 +997,13 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
         pf.mark(19);
         __syncthreads();
         pf.mark(21);
-        // tables: one room slot per lane; grid: 16 bytes per lane
-        if (lane < nrooms) {
-            const size_t g = (size_t)lane * real_n + real_e;
-            S.room_rect[g] = T->room_rect[lane]; S.room_meta[g] = T->room_meta[lane];
-            S.mon_w0[g] = T->mon_w0[lane]; S.mon_hp[g] = T->mon_hp[lane]; S.mon_exp[g] = T->mon_exp[lane];
-            S.gold_pos[g] = T->gold_pos[lane]; S.gold_amt[g] = T->gold_amt[lane];
+        // tables: one room slot per lane (and round, with more rooms than lanes); grid: 16 bytes per lane
+        for (int r = lane; r < nrooms; r += WAVE) {
+            const size_t g = (size_t)r * real_n + real_e;
+            S.room_rect[g] = T->room_rect[r]; S.room_meta[g] = T->room_meta[r];
+            S.mon_w0[g] = T->mon_w0[r]; S.mon_hp[g] = T->mon_hp[r]; S.mon_exp[g] = T->mon_exp[r];
+            S.gold_pos[g] = T->gold_pos[r]; S.gold_amt[g] = T->gold_amt[r];
+            if (GM < 2) break;
         }
         {
             uint16_t *dst = S.cell + (size_t)real_e * HW;
@@ -1013,7 +1100,7 @@ extern __shared__ __align__(16) uint8_t g_smem[];
 // BUILD_EPB envs per wave: a wave generates its levels one after the other, so fewer envs per wave = more waves per SIMD to overlap the
 // generator's latencies (create / rg_reset only; not on the step path)
 #define BUILD_EPB 16
-template <bool BIG>  // (one kernel per generator instance: both in one kernel cost the capped k_regen 20 bytes of scratch)
+template <int GM>  // (one kernel per generator instance: two in one kernel cost the capped k_regen 20 bytes of scratch)
 __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     const int lane = threadIdx.x;
     const int e = blockIdx.x * BUILD_EPB + lane;
@@ -1022,7 +1109,7 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     E.e = valid ? e : 0; E.n = S.n; E.cell = E.gcell = S.cell + (size_t)E.e * S.hw; E.err = 0; E.mc = nullptr;
     Prof pf; pf.start(S.prof);
     E.on_stairs = 0;
-    gen_service<BIG>(S, c, E, lane, e, valid, true, reinterpret_cast<uint16_t *>(g_smem), pf);
+    gen_service<GM>(S, c, E, lane, e, valid, true, reinterpret_cast<uint16_t *>(g_smem), pf);
     pf.finish();
     if (blockIdx.x == 0 && lane == 0) stair_recycle(S);
     stair_publish(S, lane, e, valid, E.on_stairs != 0);
@@ -1041,7 +1128,7 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
 // Parity / property-test hook (rg_debug_descend): every env takes Dungeon::new_level + actions::new_level's player placement as if it had
 // pressed '>' on the stairs, without the turn around it -- the descent path of k_step (gen_service, is_build = false) on its own, so tests
 // can look at levels 2..30 of thousands of seeds without walking there.
-template <bool BIG>
+template <int GM>
 __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
     const int lane = threadIdx.x;
     const int e = blockIdx.x * BUILD_EPB + lane;
@@ -1051,7 +1138,7 @@ __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
     load_env(S, E, valid ? e : 0);
     Prof pf; pf.start(nullptr);
     E.on_stairs = 0;
-    gen_service<BIG>(S, c, E, lane, e, valid, false, reinterpret_cast<uint16_t *>(g_smem), pf);
+    gen_service<GM>(S, c, E, lane, e, valid, false, reinterpret_cast<uint16_t *>(g_smem), pf);
     if (blockIdx.x == 0 && lane == 0) stair_recycle(S);
     stair_publish(S, lane, e, valid, E.on_stairs != 0);
     if (!valid) return;
@@ -1075,9 +1162,8 @@ __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
 #else
 #define RG_REGEN_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))  // <= 128 registers: two generator waves beside a step wave on a SIMD (tests/test_kernel_resources.py)
 #endif
-template <bool BIG>
-__global__ void __launch_bounds__(WAVE) RG_REGEN_ATTR
-k_regen(RgState SP, RgConfig c, int epb) {
+template <int GM>
+__device__ __forceinline__ void regen_body(const RgState &SP, const RgConfig &c, int epb) {
     const int lane = threadIdx.x;
     const int e = blockIdx.x * epb + lane;
     const bool valid = lane < epb && e < SP.n;
@@ -1089,13 +1175,16 @@ k_regen(RgState SP, RgConfig c, int epb) {
     E.e = valid ? e : 0; E.n = SP.n; E.cell = E.gcell = SP.cell + (size_t)E.e * SP.hw; E.err = 0; E.mc = nullptr;
     Prof pf; pf.start(nullptr);
     E.on_stairs = 0;
-    gen_service<BIG>(SP, c, E, lane, e, claim, true, reinterpret_cast<uint16_t *>(g_smem), pf);
+    gen_service<GM>(SP, c, E, lane, e, claim, true, reinterpret_cast<uint16_t *>(g_smem), pf);
     if (claim) { store_env(SP, E); SP.on_stairs[e] = (uint8_t)E.on_stairs; }
     if (claim && E.err) atomicOr(SP.err_any, E.err);  // (the flag word belongs to the concurrently running k_step)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (claim) __hip_atomic_store(&SP.sp_ready[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+template <int GM> __global__ void __launch_bounds__(WAVE) RG_REGEN_ATTR k_regen(RgState SP, RgConfig c, int epb) { regen_body<GM>(SP, c, epb); }
+// (the 384-room instance does not fit the 128-register cap without scratch; its configs run at one step wave per SIMD anyway)
+__global__ void __launch_bounds__(WAVE) k_regen_huge(RgState SP, RgConfig c, int epb) { regen_body<2>(SP, c, epb); }
 
 // ---------------------------------------------------------------------------------------------
 // wave-cooperative bit-parallel BFS (Floor::make_dist_map, floor.rs:395-416)
@@ -1846,7 +1935,8 @@ __device__ __forceinline__ int next_pending(const RgState &S, const Env &E, int 
 // per-lane bit tables for that (a mask + 4 bits per slot) were five registers held across the BFS, and capped the table at 32 slots.
 #define MF_RANDOM 0x08u
 #define MF_DIR_SHIFT 4        // bits 4..6 of the flag byte
-#define MF_TURN_BITS (MF_PENDING | MF_RANDOM | (7u << MF_DIR_SHIFT))   // cache-only bits of the running turn; never stored to global memory
+#define MF_REACH 0x80u        // stands next to the player and attacks at the end of this turn (actions::move_active_enemies, actions.rs:82-119)
+#define MF_TURN_BITS (MF_PENDING | MF_RANDOM | (7u << MF_DIR_SHIFT) | MF_REACH)   // cache-only bits of the running turn; never stored to global memory
 __device__ __forceinline__ bool monsters_prepass(const RgState &S, const RgConfig &c, Env &E) {
     const int nrooms = c.room_num_x * c.room_num_y;
     for (int s = 0; s < nrooms; s++) {  // the taken map: every active monster is pending
@@ -1893,7 +1983,7 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
     const int nrooms = c.room_num_x * c.room_num_y, W = c.width, e = E.e;
     const uint16_t *dist = S.dc_map + ((size_t)e * RG_DIST_SLOTS + (map_slot < 0 ? 0 : map_slot)) * S.hw;
     const uint32_t ppos = POS(E.px, E.py);
-    uint64_t att_list = 0; int n_att = 0;
+    int n_att = 0;
     int last = -1, slot;
     while ((last = next_pending(S, E, nrooms, last, slot)) >= 0) {
         const uint32_t wt = mon_rd<true>(S, E, slot);
@@ -1940,9 +2030,9 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
             }
             if (!reach && found) fin = bp;
         }
-        // A reaching monster stays on its cell, which is one of the player's 8 neighbours; two monsters never end a turn on one cell (a
-        // monster that stays put replaces one that moved onto it, below) => at most 8 attackers, and the 10-entry list (6-bit slots) cannot overflow.
-        if (reach) { if (n_att < 10) { att_list |= (uint64_t)slot << (6 * n_att); n_att++; } else E.err |= RG_FLAG_ERR_INTERNAL; }
+        // A reaching monster stays on its cell and is remembered by a bit of its cache word (a packed slot list in a register capped the table
+        // at 64 slots): the attacks below run in BTreeMap order = ascending position, which is the order these monsters were visited in.
+        if (reach) { E.mc[slot * WAVE] = w | ((uint32_t)MF_REACH << 24); n_att++; }
         if (fin == (w & 0xffff)) {
             // BTreeMap::insert on its own key replaces a monster that already moved onto this cell
             for (int s = 0; s < nrooms; s++) {
@@ -1956,8 +2046,17 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
     if (n_att > 0) E.quiet = 0;  // player.buttle()
     bool did_hit = false;
     uint32_t lev_add = lev_add_of(c, E.dlevel);
+    int last_key = -1;
     for (int i = 0; i < n_att; i++) {
-        int s = (int)((att_list >> (6 * i)) & 63);
+        int s = -1, best = 0x7fffffff;
+        for (int q = 0; q < nrooms; q++) {  // the next attacker: smallest position above the last one
+            const uint32_t o = mon_rd<true>(S, E, q);
+            const int key = (int)(o & 0xffff);
+            if (((o >> 24) & MF_REACH) && key > last_key && key < best) { best = key; s = q; }
+        }
+        if (s < 0) break;
+        last_key = best;
+        E.mc[s * WAVE] = mon_rd<true>(S, E, s) & ~((uint32_t)MF_REACH << 24);
         uint32_t type = (mon_rd<true>(S, E, s) >> 16) & 0xff;
         uint32_t rate = attack_rate((int64_t)c.mon[type].level + lev_add, c.armor_def /* Player::arm: the default pack wears ring mail 3 + 1 */, 0 /* hit_prob_plus(10) */);
         int sum = 0; bool hit = false;
@@ -1971,7 +2070,10 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
             react |= MSG_HIT_FROM;
             did_hit = true;
             E.hp = E.hp - sum > 0 ? E.hp - sum : 0;  // Player::get_damage (player.rs:177-184)
-            if (E.hp == 0) { react |= R_GRAVE; return true; }
+            if (E.hp == 0) {  // the player died: the remaining attackers do not get their turn (and a MoveUntil run goes on: leave no marks behind)
+                for (int q = 0; q < nrooms; q++) E.mc[q * WAVE] = mon_rd<true>(S, E, q) & ~((uint32_t)MF_REACH << 24);
+                react |= R_GRAVE; return true;
+            }
         } else react |= MSG_MISS_FROM;
     }
     if (did_hit) react |= R_STATUS;
@@ -2053,7 +2155,7 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
 
 // One wave's share of a step: lane i plays the key of env `e` (any env index -- the lanes of a wave need not hold consecutive envs), `valid`
 // lanes only; the other lanes still take part in the wave-cooperative services.
-template <int BW>
+template <int BW, int GM>
 __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__restrict__ SPd, const RgConfig &c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset,
                                           const int e, const bool valid_in, const int stair_role) {
     // stair_role: 0 = no stair isolation, 1 = this wave serves listed (on-stairs) envs, 2 = index-order wave: listed envs are somebody else's
@@ -2143,7 +2245,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         }
         const bool regenerated = descends && pass == 0;
         if (need_gen) n_inline++;
-        gen_service<(BW != 0)>(S, c, E, lane, e, need_gen, pass == 1, lds_grid, pf);  // W <= 32: at most 12 rooms; the wider instances carry the 64-room generator
+        gen_service<GM>(S, c, E, lane, e, need_gen, pass == 1, lds_grid, pf);  // W <= 32: at most 12 rooms; the wider instances carry the 64-room generator
         (void)regenerated;  // (a descended lane's monster-cache column was refilled by gen_service from the generator's own table)
         pf.mark(2);
         need_gen = false;
@@ -2286,7 +2388,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
 
 // (the body is spelled out twice -- below for the capped W <= 32 instance -- rather than shared through a device function: routing the template through
 // one more inlined call changed the allocation of the wider instances for the worse, 141 -> 153 us on the default 80x24 dungeon)
-#define RG_STEP_BLOCK_BODY(BWV) \
+#define RG_STEP_BLOCK_BODY(BWV, GMV) \
     __builtin_amdgcn_s_setprio(3); \
     const int lane = threadIdx.x; \
     if (blockIdx.x == 0 && lane == 0) stair_recycle(S); \
@@ -2299,7 +2401,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         bool v; int e; \
         if (stair) { e = list[i0]; v = lane == 0 && e < S.n_keys && keys[e] == '>'; } \
         else { v = lane < epw && i0 + lane < items; e = v ? i0 + lane : 0; } \
-        if (!stair || __any(v)) step_wave<BWV>(S, SPd, c, keys, use_spares, mc_offset, e, v, parity >= 0 ? (stair ? 1 : 2) : 0); \
+        if (!stair || __any(v)) step_wave<BWV, GMV>(S, SPd, c, keys, use_spares, mc_offset, e, v, parity >= 0 ? (stair ? 1 : 2) : 0); \
         if (!stair || items <= STAIR_BLOCKS) break; \
         __syncthreads(); \
         uint32_t t = 0; \
@@ -2313,7 +2415,7 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, const RgState *__restr
     // STAIR_BLOCKS are handed out one at a time through a counter, so that a block busy with a descent (60 us) never has a second one queued behind
     // it while its neighbours sit idle.  An entry whose env does not press '>' stays with its index-order wave (step_wave's rule, applied here before
     // anything else of the env is loaded: such a block is gone in ~2 us).
-    RG_STEP_BLOCK_BODY(BW)
+    RG_STEP_BLOCK_BODY(BW, (BW != 0 ? 1 : 0))
 }
 // The W <= 32 instance with the register allocation capped for TWO waves per SIMD (256 VGPRs).  With the 5x5 window in LDS it needs ~250: told to,
 // the allocator fits it without a spill (left alone it lands on either side of the line from build to build).  Every block of a 65 536-env launch
@@ -2322,19 +2424,30 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, const RgState *__restr
 // for every other wave).  The wider instances spill under the cap (15-136 VGPRs: a measured loss) and keep their natural allocation.
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_step_w32(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset, int epw, int parity) {
-    RG_STEP_BLOCK_BODY(0)
+    RG_STEP_BLOCK_BODY(0, 0)
+}
+// More than 64 rooms (only possible on wide grids: 65 rooms need W >= 65): the generic row-width class with the 384-room generator.  Its LDS
+// monster table (a column of `rooms` words per lane) exceeds the 64 KB default, see rgk_step.
+__global__ void __launch_bounds__(WAVE) k_step_huge(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset,
+                                                    int epw, int parity) {
+    RG_STEP_BLOCK_BODY(4, 2)
 }
 #undef RG_STEP_BLOCK_BODY
 
 // ---------------------------------------------------------------------------------------------
 // host-callable launchers (used by rg_api.cpp)
 // ---------------------------------------------------------------------------------------------
+static int gen_mode_of(const RgConfig *c) { const int nr = c->room_num_x * c->room_num_y; return nr <= 32 ? 0 : (nr <= 64 ? 1 : 2); }
 extern "C" {
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw, c->room_num_x * c->room_num_y);  // one level at a time per wave: one staging grid + the generator's tables
-    if (c->room_num_x * c->room_num_y <= 32) hipLaunchKernelGGL(k_build<false>, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), smem, st, *S, *c);
-    else hipLaunchKernelGGL(k_build<true>, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), smem, st, *S, *c);
+    const dim3 grid((S->n + BUILD_EPB - 1) / BUILD_EPB);
+    switch (gen_mode_of(c)) {
+    case 0: hipLaunchKernelGGL(k_build<0>, grid, dim3(WAVE), smem, st, *S, *c); break;
+    case 1: hipLaunchKernelGGL(k_build<1>, grid, dim3(WAVE), smem, st, *S, *c); break;
+    default: hipLaunchKernelGGL(k_build<2>, grid, dim3(WAVE), smem, st, *S, *c);
+    }
 }
 void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     int hw = c->width * c->height;
@@ -2358,7 +2471,12 @@ void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const 
     // (ev0 / ev1: optional events stamped with this dispatch's own begin and end -- rg_timing; ev1 alone: the completion event k_regen's stream waits for)
 #define RG_LAUNCH_STEP(K) do { if (ev0 || ev1) hipExtLaunchKernelGGL(K, grid, block, (uint32_t)smem, st, ev0, ev1, 0, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity); \
                                else hipLaunchKernelGGL(K, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity); } while (0)
-    if (c->width <= 32) RG_LAUNCH_STEP(k_step_w32);
+    if (gen_mode_of(c) == 2) {
+        // the LDS monster table of a > 64-room dungeon (256 B per room and wave) goes beyond the 64 KB a kernel gets by default: raise the kernel's limit once
+        static size_t raised = 0;
+        if (smem > raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_huge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); raised = smem; }
+        RG_LAUNCH_STEP(k_step_huge);
+    } else if (c->width <= 32) RG_LAUNCH_STEP(k_step_w32);
     else if (n32 && c->width <= 64) RG_LAUNCH_STEP(k_step<1>);
     else if (n32) RG_LAUNCH_STEP(k_step<2>);
     else if (c->width <= 128) RG_LAUNCH_STEP(k_step<3>);
@@ -2368,8 +2486,12 @@ void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const 
 void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
     const size_t smem = GEN_SLOT_BYTES(hw, c->room_num_x * c->room_num_y);
-    if (c->room_num_x * c->room_num_y <= 32) hipLaunchKernelGGL(k_debug_descend<false>, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), smem, st, *S, *c);
-    else hipLaunchKernelGGL(k_debug_descend<true>, dim3((S->n + BUILD_EPB - 1) / BUILD_EPB), dim3(WAVE), smem, st, *S, *c);
+    const dim3 grid((S->n + BUILD_EPB - 1) / BUILD_EPB);
+    switch (gen_mode_of(c)) {
+    case 0: hipLaunchKernelGGL(k_debug_descend<0>, grid, dim3(WAVE), smem, st, *S, *c); break;
+    case 1: hipLaunchKernelGGL(k_debug_descend<1>, grid, dim3(WAVE), smem, st, *S, *c); break;
+    default: hipLaunchKernelGGL(k_debug_descend<2>, grid, dim3(WAVE), smem, st, *S, *c);
+    }
 }
 void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
@@ -2379,7 +2501,11 @@ void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
     // claims per wave, the launch is over in about one generation time, and the 8192 blocks that find nothing are gone at once.  (A/B knob.)
     static const int epb_env = getenv("ROGUE_GYM_HIP_REGEN_EPB") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_EPB")) : 0;
     const int epb = (epb_env >= 4 && epb_env <= WAVE) ? epb_env : 8;
-    if (c->room_num_x * c->room_num_y <= 32) hipLaunchKernelGGL(k_regen<false>, dim3((SP->n + epb - 1) / epb), dim3(WAVE), smem, st, *SP, *c, epb);
-    else hipLaunchKernelGGL(k_regen<true>, dim3((SP->n + epb - 1) / epb), dim3(WAVE), smem, st, *SP, *c, epb);
+    const dim3 grid((SP->n + epb - 1) / epb);
+    switch (gen_mode_of(c)) {
+    case 0: hipLaunchKernelGGL(k_regen<0>, grid, dim3(WAVE), smem, st, *SP, *c, epb); break;
+    case 1: hipLaunchKernelGGL(k_regen<1>, grid, dim3(WAVE), smem, st, *SP, *c, epb); break;
+    default: hipLaunchKernelGGL(k_regen_huge, grid, dim3(WAVE), smem, st, *SP, *c, epb);
+    }
 }
 }

@@ -27,7 +27,6 @@ __device__ __forceinline__ bool in_same_room(const RgState &S, const RgConfig &c
 
 __global__ void __launch_bounds__(RENDER_THREADS) k_render(RgState S, RgConfig c) {
     __shared__ uint8_t s_scr[RG_MAX_W * RG_MAX_H];
-    __shared__ uint16_t s_cell_at[2 * RG_MAX_ROOMS];  // cell words under gold / monster overlays
     const int tid = threadIdx.x, W = c.width, H = c.height, HW = W * H, n = S.n;
     const int nrooms = c.room_num_x * c.room_num_y;
     for (int e = blockIdx.x; e < n; e += gridDim.x) {
@@ -48,8 +47,8 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RgState S, RgConfig c
         const uint32_t ppos = S.p_pos[e];
         const int px = POS_X(ppos), py = POS_Y(ppos);
         // draw priority: player > gold > monster (core/src/lib.rs:271-283): lowest priority first
-        if (tid < nrooms) {
-            uint32_t w = S.mon_w0[tid * n + e];
+        for (int r = tid; r < nrooms; r += RENDER_THREADS) {  // (a grid may have more rooms than the block has threads)
+            uint32_t w = S.mon_w0[r * n + e];
             if ((w >> 24) & MF_ALIVE) {
                 int x = POS_X(w), y = POS_Y(w);
                 uint32_t v = cell[y * W + x];
@@ -59,8 +58,8 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RgState S, RgConfig c
             }
         }
         __syncthreads();
-        if (tid < nrooms) {
-            uint32_t g = S.gold_pos[tid * n + e];
+        for (int r = tid; r < nrooms; r += RENDER_THREADS) {
+            uint32_t g = S.gold_pos[r * n + e];
             if (g & 0x10000u) {
                 int x = POS_X(g), y = POS_Y(g);
                 if ((cell[y * W + x] & (C_VISIBLE | C_DRAWN)) && y >= 1 && y < H - 1) s_scr[y * W + x] = '*';
@@ -80,7 +79,6 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RgState S, RgConfig c
             S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | (upd_hist ? RG_FLAG_HIST_DIRTY : 0u))) | ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u);
         __syncthreads();
     }
-    (void)s_cell_at;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -184,8 +182,8 @@ __device__ __forceinline__ void store_obs(float4 *p, float4 v) {
     __builtin_nontemporal_store(nv, reinterpret_cast<f4v *>(p));
 }
 struct ObsTabs {  // per-env entity/room tables staged in LDS: every global load of an env is issued up front, in one round trip
-    uint32_t rect[RG_MAX_ROOMS], mon[RG_MAX_ROOMS], gold[RG_MAX_ROOMS];
-    uint8_t meta[RG_MAX_ROOMS];
+    uint32_t rect[RG_OBS_MAX_ROOMS], mon[RG_OBS_MAX_ROOMS], gold[RG_OBS_MAX_ROOMS];
+    uint8_t meta[RG_OBS_MAX_ROOMS];
     uint32_t ppos, pad[3];
 };
 #define OBS_ENV_BYTES(hw) ((((size_t)(hw) + sizeof(ObsTabs)) + 15) & ~(size_t)15)
@@ -457,6 +455,7 @@ void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st) {
 int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, int planes_sym, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     int hw = c->width * c->height;
     if (hw & 7) return 0;
+    if (c->room_num_x * c->room_num_y > RG_OBS_MAX_ROOMS) return 0;  // the fused kernel's LDS overlay tables hold 64 rooms (one thread per room + the player): unfused path
     int q8 = hw / 8;
     int tpe = q8 >= OBS_THREADS ? OBS_THREADS : ((q8 + 63) / 64) * 64;  // threads per env: a whole number of waves
     if (tpe > OBS_THREADS) tpe = OBS_THREADS;

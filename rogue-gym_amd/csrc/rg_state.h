@@ -39,7 +39,7 @@ enum { RK_NORMAL = 0, RK_MAZE = 1, RK_EMPTY = 2 };
 
 // Every connect_2rooms call joins a pair of grid-adjacent rooms that was not joined before (dig_passges excludes joined pairs, passages.rs:33-66),
 // so a level has at most rnx*(rny-1) + rny*(rnx-1) < 2 * rooms corridors whatever max_extra_edges says.
-#define RG_MAX_EDGES (2 * RG_MAX_ROOMS)
+#define RG_MAX_EDGES (2 * RG_MAX_ROOMS)   // (the tables are allocated per config: 2 x its rooms)
 
 struct RgState {
     int32_t n;          // environments on this device
@@ -64,18 +64,18 @@ struct RgState {
     const uint32_t *init_draws;   // [cfg.n_init_draws][2]: (lo, hi) of the item-stream draw of every InitItem::Weapon of player.init_items, in list order
                                   // (WeaponStatus::build, weapon.rs:159; resolved by rg_items.cpp); NULL when there is none
     uint64_t *range_lo, *range_span;  // [2][n] (low word, high word) of seed_range[0] and of seed_range[1] - seed_range[0]; NULL if no env has a range
-    // rooms [RG_MAX_ROOMS][n]
+    // rooms [rooms of the config][n]
     uint32_t *room_rect;  // x0 | y0<<8 | x1<<16 | y1<<24 (half-open; Empty: x0,y0 = up_left)
     uint8_t *room_meta;
-    // monsters [RG_MAX_ROOMS][n] (at most one spawn per room per level, floor.rs:106-130)
+    // monsters [rooms][n] (at most one spawn per room per level, floor.rs:106-130)
     uint32_t *mon_w0;
     int32_t *mon_hp;
     uint32_t *mon_exp;
     uint32_t *mon_cnt;  // [n] alive | active<<8
-    // gold [RG_MAX_ROOMS][n]: pos | 0x10000 when present; amounts
+    // gold [rooms][n]: pos | 0x10000 when present; amounts
     uint32_t *gold_pos, *gold_amt;
     // generator scratch
-    uint32_t *edge_a, *edge_b;  // [RG_MAX_EDGES][n] corridor records, replayed for gen_attr (floor.rs:73-102)
+    uint32_t *edge_a, *edge_b;  // [2 x rooms][n] corridor records, replayed for gen_attr (floor.rs:73-102)
     uint16_t *maze_stack;       // [n][maze_cap]: DFS stack of a maze room too large for the LDS stack
     int32_t maze_cap;           // >= the maze nodes of the largest assigned area (one stack entry per node at most)
     // DistCache (rogue/mod.rs:492-518)

@@ -31,10 +31,10 @@ class RgDebugState(C.Structure):
         ("player_level", C.c_int32), ("n_monsters", C.c_int32), ("n_gold", C.c_int32),
         ("exp", C.c_uint32), ("food_left", C.c_uint32), ("quiet", C.c_uint32), ("pack_gold", C.c_uint32), ("steps", C.c_uint32),
         ("rng", C.c_uint32 * 12),
-        ("mon_x", C.c_int32 * 64), ("mon_y", C.c_int32 * 64), ("mon_type", C.c_int32 * 64), ("mon_active", C.c_int32 * 64), ("mon_hp", C.c_int32 * 64),
-        ("mon_exp", C.c_uint32 * 64),
-        ("gold_x", C.c_int32 * 64), ("gold_y", C.c_int32 * 64), ("gold_amount", C.c_int32 * 64),
-        ("n_rooms", C.c_int32), ("room_rect", C.c_uint32 * 64), ("room_meta", C.c_int32 * 64),
+        ("mon_x", C.c_int32 * 384), ("mon_y", C.c_int32 * 384), ("mon_type", C.c_int32 * 384), ("mon_active", C.c_int32 * 384), ("mon_hp", C.c_int32 * 384),
+        ("mon_exp", C.c_uint32 * 384),
+        ("gold_x", C.c_int32 * 384), ("gold_y", C.c_int32 * 384), ("gold_amount", C.c_int32 * 384),
+        ("n_rooms", C.c_int32), ("room_rect", C.c_uint32 * 384), ("room_meta", C.c_int32 * 384),
     ]
 
 

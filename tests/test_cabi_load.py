@@ -128,7 +128,8 @@ def test_config_canonical_roundtrip(lib, goldens):
 
 
 def test_config_validation(lib):
-    for bad, frag in [({"width": 160, "height": 48, "dungeon": {"style": "rogue", "room_num_x": 13, "room_num_y": 5}}, "room_num"),
+    for bad, frag in [({"width": 160, "height": 48, "dungeon": {"style": "rogue", "room_num_x": 41, "room_num_y": 10}}, "room_num"),      # 410 rooms: beyond any geometry
+                      ({"width": 160, "height": 48, "dungeon": {"style": "rogue", "room_num_x": 33, "room_num_y": 8}}, "min_room_size"),  # rooms of 4 x 6 < min 4 + 1
                       ({"dungeon": {"style": "rogue", "room_num_x": 5, "room_num_y": 5}}, "min_room_size"),
                       ({"enemies": {"enemies": [99]}}, "builtin"),
                       ({"enemies": {"enemies": [{"name": "x"}]}}, "missing field"),

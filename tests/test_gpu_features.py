@@ -208,31 +208,34 @@ def test_lockstep_varied_rates_default_size(goldens):
     lockstep(cfg, list(range(96)), keys, max_steps=150, check_every=1, internal_every=50)
 
 
-def test_forty_and_sixty_four_rooms(goldens):
+def test_room_grids_beyond_32_rooms(goldens):
     """The reference has no room-count limit (rooms.rs:165-211) and core/src/lib.rs:134-140 allows 160x48: 10x4 rooms of 16x12 is a valid config
-    (VERDICT r2 item 6).  Room sets are 64-bit masks here, the generator's room table is one room per lane: up to 64 rooms, lock step with the
-    oracle -- levels with more than 64 corridor records included (8x8 rooms: up to 112 adjacent pairs)."""
-    from rogue_gym_python._rogue_gym import GameState
-
+    (VERDICT r2 item 6), and so is everything up to what geometry allows -- 32x8 = 256 rooms with the default min_room_size 4, 40x9 = 360 with 3.
+    Three generator instances: 32-bit room sets (<= 32 rooms), 64-bit (<= 64, corridor records beyond the 64th in LDS), six words + the room table
+    in LDS (<= 384).  Lock step with the oracle, then deeper levels straight from the generator."""
     rng = np.random.RandomState(9)
-    for rx, ry, n, extra in ((10, 4, 24, 5), (8, 8, 16, 60), (8, 4, 24, 5)):   # 40 rooms, 64 rooms with many extra edges, exactly 32
-        cfg = {"width": 160, "height": 48, "dungeon": {"style": "rogue", "room_num_x": rx, "room_num_y": ry, "max_extra_edges": extra}}
-        keys = [ALL_KEYS[rng.randint(0, len(ALL_KEYS), n)] for _ in range(100)]
-        lockstep(cfg, list(range(100 * rx, 100 * rx + n)), keys, max_steps=80, check_every=4, internal_every=25)
-    # deeper levels of the 40-room dungeon (dark rooms, mazes, locked doors; up to 40 monsters), straight from the generator
-    cfg = {"width": 160, "height": 48, "dungeon": {"style": "rogue", "room_num_x": 10, "room_num_y": 4}}
-    seeds = list(range(20))
-    hip = HipBatch(cfg, seeds)
-    oracles = make_oracles(cfg, seeds)
-    for lvl in range(2, 12):
-        hip.h.check(hip.h.L.rg_debug_descend(hip.h.h))
-        for o in oracles:
-            o.debug_descend()
-        compare_internal(hip, oracles, range(lvl % 3, 20, 3), "level %d" % lvl)  # (the hook leaves the mirrors to the next Redraw: internals only)
-    hip.sync()
-    # beyond 64 rooms the stepper still refuses, loudly and by name (the reference would build 11x6 = 66 rooms of 14x8)
-    with pytest.raises(RuntimeError, match="room_num_x \\* room_num_y must be in 1..=64"):
-        GameState(100, json.dumps({"width": 160, "height": 48, "seed": 1, "dungeon": {"style": "rogue", "room_num_x": 11, "room_num_y": 6}}))
+    cases = ((10, 4, 4, 24, 5, 100), (8, 8, 4, 16, 60, 100), (8, 4, 4, 24, 5, 60),       # 40 rooms; 64 with > 64 corridor records; exactly 32
+             (11, 6, 4, 12, 5, 60), (13, 5, 4, 12, 20, 60), (32, 8, 4, 8, 40, 50), (40, 9, 3, 8, 5, 50))   # 66, 65, 256, 360 rooms
+    for rx, ry, mr, n, extra, steps in cases:
+        cfg = {"width": 160, "height": 48, "dungeon": {"style": "rogue", "room_num_x": rx, "room_num_y": ry, "min_room_size": {"x": mr, "y": mr},
+                                                       "max_extra_edges": extra}}
+        keys = [ALL_KEYS[rng.randint(0, len(ALL_KEYS), n)] for _ in range(steps)]
+        hip, oracles = lockstep(cfg, list(range(100 * rx, 100 * rx + n)), keys, max_steps=45, check_every=3, internal_every=20)
+        # ... and the observation tensors of such a grid (the fused kernel holds 64 rooms: beyond that the unfused render + encode runs)
+        img = hip.obs(0, 0x1FF, True)
+        for i in (0, n - 1):
+            assert np.array_equal(img[i], oracles[i].gray_image(0x1FF, True)), (rx, ry, i)
+    for rx, ry, mr in ((10, 4, 4), (13, 5, 4), (32, 8, 4)):   # deeper levels: dark rooms, mazes, locked doors, a monster in most rooms
+        cfg = {"width": 160, "height": 48, "dungeon": {"style": "rogue", "room_num_x": rx, "room_num_y": ry, "min_room_size": {"x": mr, "y": mr}}}
+        seeds = list(range(12))
+        hip = HipBatch(cfg, seeds)
+        oracles = make_oracles(cfg, seeds)
+        for lvl in range(2, 10):
+            hip.h.check(hip.h.L.rg_debug_descend(hip.h.h))
+            for o in oracles:
+                o.debug_descend()
+            compare_internal(hip, oracles, range(lvl % 3, 12, 3), "%dx%d level %d" % (rx, ry, lvl))  # (the hook leaves the mirrors to the next Redraw: internals only)
+        hip.sync()
 
 
 def test_many_extra_edges_fit_the_corridor_table(goldens):
