@@ -181,7 +181,8 @@ int rg_history_keys(rg_t *h, int env, int which, uint8_t *keys, size_t cap, uint
 int rg_dump_history(rg_t *h, int env, int which, char *buf, size_t cap, size_t *needed);
 
 /* Workload counters accumulated by rg_step since the last reset of the counters: out[0] auto-resets, [1] descents, [2] dist maps built (BFS),
- * [3] levels generated inline by the step kernel, [4] spare levels taken, [5] Redraw reactions, [6] keys processed, [7] unused.  Synchronous. */
+ * [3] levels generated inline by the step kernel, [4] spare levels taken, [5] Redraw reactions, [6] keys processed, [7] partial dist maps continued over the walkable mask saved with them (a map
+ * begun before a descent or an opening search, grids of 33..96 columns; counted in [2] as well).  Synchronous. */
 int rg_counters(rg_t *h, uint64_t out[8], int reset);
 /* Effective shader clock right now: a one-wave spin kernel on the handle's stream compares s_memtime (shader-clock ticks) with
  * s_memrealtime (constant 100 MHz).  Synchronous; bench.py's evidence for the clock state of a run. */

@@ -213,9 +213,13 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
               dev_alloc(h, &S.edge_a, ne * n) && dev_alloc(h, &S.edge_b, ne * n) &&
               dev_alloc(h, &S.maze_stack, (size_t)maze_cap * n) && dev_alloc(h, &S.build_ctr, n) && dev_alloc(h, &S.stats, 8 * h->stat_rows) && dev_alloc(h, &S.stair_list, 2 * n) && dev_alloc(h, &S.stair_cnt, 8) && dev_alloc(h, &S.stair_mark, 2 * n) &&
               dev_alloc(h, &S.dc_map, h->cfg.n_enemies > 0 ? n * RG_DIST_SLOTS * hw : 16) && dev_alloc(h, &S.dc_key, RG_DIST_SLOTS * n) &&
-              dev_alloc(h, &S.dc_head, n) && dev_alloc(h, &S.dc_len, n) && dev_alloc(h, &S.status, n * 10) &&
+              dev_alloc(h, &S.dc_head, n) && dev_alloc(h, &S.dc_len, n) && dev_alloc(h, &S.dc_part, n) && dev_alloc(h, &S.dc_own, n) && dev_alloc(h, &S.status, n * 10) &&
               dev_alloc(h, &h->d_err, 4) && dev_alloc(h, &h->d_keys, n);
     ok = ok && dev_alloc(h, &S.sp_ready, n) && dev_alloc(h, &h->d_probe, 4);
+    // the grid class whose dist maps may be partial (rg_kernels.hip bfs_rows_n32): one saved walkable mask per map
+    if (ok && h->cfg.n_enemies > 0 && h->cfg.width > 32 && h->cfg.width <= 96 && hw <= 4096)
+        ok = dev_alloc(h, &S.dc_walk, n * RG_DIST_SLOTS * h->cfg.height * ((h->cfg.width + 31) / 32));
+    S.full_bfs = getenv("ROGUE_GYM_HIP_FULL_BFS") != nullptr;
     S.err_any = h->d_err;
     if (ok && !h->range_lo.empty()) {
         ok = dev_alloc(h, &S.range_lo, 2 * n) && dev_alloc(h, &S.range_span, 2 * n) &&

@@ -1116,7 +1116,7 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     if (!valid) return;
     store_env(S, E);
     write_status(S, c, E);
-    S.dc_len[e] = 0; S.dc_head[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
+    S.dc_len[e] = 0; S.dc_head[e] = 0; S.dc_part[e] = 0; S.dc_own[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
     S.steps[e] = 0;
     S.flags[e] = RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY | E.err;
     if (E.err) atomicOr(S.err_any, E.err);
@@ -1128,6 +1128,7 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
 // Parity / property-test hook (rg_debug_descend): every env takes Dungeon::new_level + actions::new_level's player placement as if it had
 // pressed '>' on the stairs, without the turn around it -- the descent path of k_step (gen_service, is_build = false) on its own, so tests
 // can look at levels 2..30 of thousands of seeds without walking there.
+__device__ __forceinline__ void snapshot_walk_service(const RgState &S, const RgConfig &c, int lane, int e, bool want);
 template <int GM>
 __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
     const int lane = threadIdx.x;
@@ -1138,6 +1139,7 @@ __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
     load_env(S, E, valid ? e : 0);
     Prof pf; pf.start(nullptr);
     E.on_stairs = 0;
+    if (S.dc_walk) snapshot_walk_service(S, c, lane, e, valid);  // (defined below) partial dist maps keep the level they were made on
     gen_service<GM>(S, c, E, lane, e, valid, false, reinterpret_cast<uint16_t *>(g_smem), pf);
     if (blockIdx.x == 0 && lane == 0) stair_recycle(S);
     stair_publish(S, lane, e, valid, E.on_stairs != 0);
@@ -1453,42 +1455,77 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {  // sum over the 64 l
 // 32 < W <= 96 with H * W <= 4096 (the reference's default 80 x 24 among them): the row is WN = 2 or 3 32-bit words, everything in registers.
 // The 64-bit-word form below spends two VALU ops on every logic op and three on every shift; here a shift across the word boundary is one
 // v_alignbit_b32 and a level step is ~26 ops per word.  Distances are < the number of walkable cells < 4096 = 3 low + 9 high bit-planes.
+// walkable mask of one grid row as WN 32-bit words (Surface::can_walk, rogue/mod.rs:175-182)
 template <int WN>
-__device__ __forceinline__ void bfs_rows_n32(const RgState &S, const RgConfig &c, bool active, int env, int tx, int ty, int slot, int row) {
+__device__ __forceinline__ void row_walk_mask(const uint16_t *rowp, int W, uint32_t (&wk)[WN]) {
+#pragma unroll
+    for (int k = 0; k < WN; k++) wk[k] = 0u;
+    if ((W & 7) == 0) {
+        const uint4 *r4 = reinterpret_cast<const uint4 *>(rowp);
+#pragma unroll
+        for (int j = 0; j < WN * 4; j++) {  // (fully unrolled: compile-time word indices; the guard is the only run-time part)
+            if (j * 8 < W) {
+                const uint4 v = r4[j];
+                const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+                uint32_t bits = 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    bits |= (uint32_t)can_walk(q[t] & 0xffff) << (2 * t);
+                    bits |= (uint32_t)can_walk(q[t] >> 16) << (2 * t + 1);
+                }
+                wk[j >> 2] |= bits << ((j & 3) * 8);
+            }
+        }
+    } else {
+        for (int x = 0; x < W; x++) {
+            const uint32_t bb = (uint32_t)can_walk(rowp[x]) << (x & 31);
+#pragma unroll
+            for (int k = 0; k < WN; k++)
+                if ((x >> 5) == k) wk[k] |= bb;
+        }
+    }
+}
+
+// 32 < W <= 96 with H * W <= 4096 (the reference's default 80 x 24 among them): the row is WN = 2 or 3 32-bit words, everything in registers.
+// The 64-bit-word form below spends two VALU ops on every logic op and three on every shift; here a shift across the word boundary is one
+// v_alignbit_b32 and a level step is ~26 ops per word.  Distances are < the number of walkable cells < 4096 = 3 low + 9 high bit-planes.
+//
+// PARTIAL MAPS.  A full map of the 80 x 24 dungeon is 100-150 levels (~25 us of a wave that has nothing else to run); what this turn reads of it
+// is the 3 x 3 around every chasing monster, typically a dozen levels out.  The expansion therefore stops at the end of the first 8-level block
+// in which every chaser's own cell (`mcol`: the requesting lane's column of the LDS monster cache, PENDING and not RANDOM) has been reached --
+// or when the frontier dies (then the map is COMPLETE, the return value).  A partial map is exact wherever it has a value, and 0xFFFF elsewhere;
+// monsters_move's choice is the minimum over the 3 x 3 of a monster whose own cell has a value, so every cell that could win has one too (a
+// neighbour without one is farther than the own cell).  The DistCache keeps such a map under the reference's key like any other (stale maps
+// are the reference's behaviour, rogue/mod.rs:504-517): when a later turn needs more of it (dist_map_sufficient), the SAME expansion is run
+// again, farther -- over the walkable mask the map was made from.  That mask is the level's own until something changes it (a descent,
+// a search that opens a hidden passage or a locked door: floor.rs:349-370); right before such a change snapshot_walk_service saves it into the
+// slot (`own`), so the map the reference would have computed in full back then is what the extension continues.
+template <int WN>
+__device__ __forceinline__ bool bfs_rows_n32(const RgState &S, const RgConfig &c, bool active, int env, int tx, int ty, int slot, int row, uint64_t grp_lanes,
+                                             const uint32_t *mcol, bool own) {
     const int W = c.width, H = c.height, HW = W * H;
     const uint16_t *cell = S.cell + (size_t)env * HW;
     const bool row_ok = active && row < H;
-    uint32_t wk[WN], wu[WN], wd[WN], vis[WN], fr[WN], inject[WN], p0[WN], p1[WN], p2[WN], ph[9][WN];
+    uint32_t wk[WN], wu[WN], wd[WN], vis[WN], fr[WN], inject[WN], p0[WN], p1[WN], p2[WN], ph[9][WN], want[WN];
 #pragma unroll
     for (int k = 0; k < WN; k++) {
-        wk[k] = vis[k] = fr[k] = inject[k] = p0[k] = p1[k] = p2[k] = 0u;
+        wk[k] = vis[k] = fr[k] = inject[k] = p0[k] = p1[k] = p2[k] = want[k] = 0u;
 #pragma unroll
         for (int b = 0; b < 9; b++) ph[b][k] = 0u;
     }
-    if (row_ok) {  // walkable mask of my row (Surface::can_walk, rogue/mod.rs:175-182)
-        const uint16_t *rowp = cell + row * W;
-        if ((W & 7) == 0) {
-            const uint4 *r4 = reinterpret_cast<const uint4 *>(rowp);
+    if (row_ok) {
+        if (own) {
+            const uint32_t *wp = S.dc_walk + (((size_t)env * RG_DIST_SLOTS + slot) * H + row) * WN;
 #pragma unroll
-            for (int j = 0; j < WN * 4; j++) {  // (fully unrolled: compile-time word indices; the guard is the only run-time part)
-                if (j * 8 < W) {
-                    const uint4 v = r4[j];
-                    const uint32_t q[4] = {v.x, v.y, v.z, v.w};
-                    uint32_t bits = 0;
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        bits |= (uint32_t)can_walk(q[t] & 0xffff) << (2 * t);
-                        bits |= (uint32_t)can_walk(q[t] >> 16) << (2 * t + 1);
-                    }
-                    wk[j >> 2] |= bits << ((j & 3) * 8);
-                }
-            }
-        } else {
-            for (int x = 0; x < W; x++) {
-                const uint32_t bb = (uint32_t)can_walk(rowp[x]) << (x & 31);
+            for (int k = 0; k < WN; k++) wk[k] = wp[k];
+        } else row_walk_mask<WN>(cell + row * W, W, wk);
+        const int nrooms = c.room_num_x * c.room_num_y;
+        for (int q = 0; q < nrooms; q++) {  // the chasers standing in my row
+            const uint32_t w = mcol[q * WAVE];
+            if (((w >> 24) & (MF_PENDING | MF_RANDOM)) == MF_PENDING && POS_Y(w) == row) {
 #pragma unroll
                 for (int k = 0; k < WN; k++)
-                    if ((x >> 5) == k) wk[k] |= bb;
+                    if ((POS_X(w) >> 5) == k) want[k] |= 1u << (POS_X(w) & 31);
             }
         }
     }
@@ -1500,6 +1537,7 @@ __device__ __forceinline__ void bfs_rows_n32(const RgState &S, const RgConfig &c
         if (row_ok && row == ty && (tx >> 5) == k) inject[k] = 1u << (tx & 31);  // level 0: the target cell itself, walkable or not
     }
     uint32_t blk = 0;
+    uint64_t alive = 0;
     for (;; blk++) {  // levels 8 * blk .. 8 * blk + 7
         uint32_t acc[WN];
 #pragma unroll
@@ -1546,7 +1584,13 @@ __device__ __forceinline__ void bfs_rows_n32(const RgState &S, const RgConfig &c
         bool any = false;
 #pragma unroll
         for (int k = 0; k < WN; k++) any = any || fr[k] != 0u;
-        if (!__any(any) || blk == 511u) break;
+        bool miss = false;
+#pragma unroll
+        for (int k = 0; k < WN; k++) miss = miss || (want[k] & ~vis[k]) != 0u;
+        alive = __ballot(any) & grp_lanes;
+        // my request goes on while it still has a frontier and a chaser it has not reached; the wave goes on while any request does
+        const bool go_on = alive != 0 && (S.full_bfs || (__ballot(miss) & grp_lanes) != 0);
+        if (!__any(go_on) || blk == 511u) break;
     }
     if (row_ok) {  // expand my row: cell x -> u16 distance, 0xFFFF where the cell was never reached
         const int nhi = 32 - __clz((int)blk);  // high planes in use (wave-uniform)
@@ -1582,33 +1626,84 @@ __device__ __forceinline__ void bfs_rows_n32(const RgState &S, const RgConfig &c
         }
     }
     __syncthreads();  // the requesting lanes read their maps right after (monsters_move): the stores of the other lanes must have landed
+    return alive == 0;  // the frontier died: every reachable cell has its distance
 }
 
 // serve every lane of `need` (ballot mask): G requests per round.  BW = width class of the grid (0: W = 32, else 64-bit words per row): the
 // step kernel is instantiated per class, so a narrow grid does not pay the register footprint of the wide-row BFS (above 384 registers a
 // k_regen wave no longer fits beside a step wave on the SIMD).
+// Returns, to every requesting lane, whether its map is COMPLETE (always, except for the partial maps of bfs_rows_n32).  own_req: the lanes whose
+// request continues a map over the walkable mask saved in its slot.
 template <int BW>
-__device__ __forceinline__ void bfs_service(const RgState &S, const RgConfig &c, uint64_t *lds, uint64_t need, int e, int px, int py, int map_slot, int lane) {
+__device__ __forceinline__ bool bfs_service(const RgState &S, const RgConfig &c, uint64_t *lds, uint64_t need, int e, int px, int py, int map_slot, int lane, const uint32_t *mcbase,
+                                            uint64_t own_req) {
     const int H = c.height;
     const int rows_pow2 = H <= 16 ? 16 : (H <= 32 ? 32 : 64);
     const int G = WAVE / rows_pow2;
     const int grp = lane / rows_pow2, row = lane - grp * rows_pow2;
+    const uint64_t grp_lanes = (rows_pow2 == 64 ? ~0ull : ((1ull << rows_pow2) - 1ull)) << (grp * rows_pow2);
+    bool my_complete = true;
     while (need) {
-        int src = -1;
+        int src = -1, served_by = -1;
         for (int g = 0; g < G; g++) {
             int sg = need ? __ffsll((long long)need) - 1 : -1;
             if (need) need &= need - 1;
             if (g == grp) src = sg;
+            if (sg == lane) served_by = g;
         }
         const bool active = src >= 0;
         const int s = active ? src : 0;
         int env_s = __shfl(e, s), tx = __shfl(px, s), ty = __shfl(py, s), sl = __shfl(map_slot, s);
         // width class BW: 0: W = 32 | 1, 2: W <= 64 / 96 and H * W <= 4096 (rows of 2 / 3 32-bit words) | 3, 4: wider or larger (2 / 3 64-bit words)
         if constexpr (BW == 0) bfs_rows_w32(S, c, active, env_s, tx, ty, sl, row);
-        else if constexpr (BW == 1) bfs_rows_n32<2>(S, c, active, env_s, tx, ty, sl, row);
-        else if constexpr (BW == 2) bfs_rows_n32<3>(S, c, active, env_s, tx, ty, sl, row);
-        else bfs_rows<BW - 1, false>(S, c, lds, active, env_s, tx, ty, sl, row);
+        else if constexpr (BW == 1 || BW == 2) {
+            const bool comp = bfs_rows_n32<BW + 1>(S, c, active, env_s, tx, ty, sl, row, grp_lanes, mcbase + s, (own_req >> s) & 1ull);
+            const uint64_t cb = __ballot(comp);  // (uniform inside a group)
+            if (served_by >= 0) my_complete = (cb >> (served_by * rows_pow2)) & 1ull;
+        } else bfs_rows<BW - 1, false>(S, c, lds, active, env_s, tx, ty, sl, row);
     }
+    return my_complete;
+}
+
+// Does the (partial) map in `slot` have a value at every chaser's own cell?  (see bfs_rows_n32)
+__device__ __forceinline__ bool dist_map_sufficient(const RgState &S, const RgConfig &c, const Env &E, int slot) {
+    const uint16_t *dist = S.dc_map + ((size_t)E.e * RG_DIST_SLOTS + slot) * S.hw;
+    const int nrooms = c.room_num_x * c.room_num_y;
+    bool ok = true;
+    for (int q = 0; q < nrooms; q++) {
+        const uint32_t w = E.mc[q * WAVE];
+        if (((w >> 24) & (MF_PENDING | MF_RANDOM)) == MF_PENDING && dist[POS_Y(w) * c.width + POS_X(w)] == DIST_INF) ok = false;
+    }
+    return ok;
+}
+
+// The walkable mask of the envs in `want` is about to change (descent, an opening search): save it into every partial map that still
+// relies on the level's own cells (bits of dc_part without dc_own), so that the map can be continued later exactly as it began (bfs_rows_n32).
+// Reads the cells in global memory: they hold the state before this turn's window write-back.
+__device__ __forceinline__ void snapshot_walk_service(const RgState &S, const RgConfig &c, int lane, int e, bool want) {
+    uint32_t todo = 0;
+    if (want) todo = (uint32_t)S.dc_part[e] & ~(uint32_t)S.dc_own[e];
+    uint64_t m = __ballot(todo != 0);
+    if (!m) return;
+    const int W = c.width, H = c.height, wpr = (W + 31) >> 5;
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int env_s = __shfl(e, src);
+        const uint32_t t = (uint32_t)__shfl((int)todo, src);
+        for (int row = lane; row < H; row += WAVE) {
+            uint32_t wk[3];
+            row_walk_mask<3>(S.cell + (size_t)env_s * S.hw + row * W, W, wk);
+            for (int sl = 0; sl < RG_DIST_SLOTS; sl++) {
+                if (!((t >> sl) & 1u)) continue;
+                uint32_t *o = S.dc_walk + (((size_t)env_s * RG_DIST_SLOTS + sl) * H + row) * wpr;
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    if (k < wpr) o[k] = wk[k];
+            }
+        }
+    }
+    if (todo) S.dc_own[e] = (uint16_t)(S.dc_own[e] | todo);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1879,7 +1974,8 @@ __device__ __forceinline__ void fill_service(const RgState &S, const RgConfig &c
 }
 
 // Floor::search (floor.rs:349-370) on the window (centred on the player)
-__device__ __forceinline__ void do_search(const RgConfig &c, Env &E, Win &w, uint32_t &react) {
+__device__ __forceinline__ bool do_search(const RgConfig &c, Env &E, Win &w, uint32_t &react) {
+    bool opened = false;  // a cell became walkable
 #pragma unroll
     for (int d = 0; d < 8; d++) {
         const int k = WIN_K(kDXc[d], kDYc[d]);
@@ -1892,9 +1988,10 @@ __device__ __forceinline__ void do_search(const RgConfig &c, Env &E, Win &w, uin
             v = (v & ~(C_LOCKED | C_HIDDEN | C_SURF_MASK)) | C_VISIBLE | S_DOOR;
             react |= MSG_SECRET_DOOR;
         }
-        if (v != v_in) { WSET(w, k, v); w.dirty |= 1u << k; }
+        if (v != v_in) { WSET(w, k, v); w.dirty |= 1u << k; opened = true; }
     }
     react |= R_REDRAW;
+    return opened;
 }
 
 // Player::turn_passed + heal (player.rs:163-176,221-240)
@@ -1933,10 +2030,6 @@ __device__ __forceinline__ int next_pending(const RgState &S, const Env &E, int 
 // depend on positions, so they are taken first (same per-stream order) to learn whether a dist map is needed.
 // A monster that moves at random this turn carries MF_RANDOM and its direction (3 bits) in the flag byte of its CACHE word, next to MF_PENDING --
 // per-lane bit tables for that (a mask + 4 bits per slot) were five registers held across the BFS, and capped the table at 32 slots.
-#define MF_RANDOM 0x08u
-#define MF_DIR_SHIFT 4        // bits 4..6 of the flag byte
-#define MF_REACH 0x80u        // stands next to the player and attacks at the end of this turn (actions::move_active_enemies, actions.rs:82-119)
-#define MF_TURN_BITS (MF_PENDING | MF_RANDOM | (7u << MF_DIR_SHIFT) | MF_REACH)   // cache-only bits of the running turn; never stored to global memory
 __device__ __forceinline__ bool monsters_prepass(const RgState &S, const RgConfig &c, Env &E) {
     const int nrooms = c.room_num_x * c.room_num_y;
     for (int s = 0; s < nrooms; s++) {  // the taken map: every active monster is pending
@@ -2170,7 +2263,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     bool live = false;   // this lane processes a key this call
     bool ui_dead = false, terminal = false;
     bool taken = false;  // terminal + auto-reset + spare ready: the spare becomes the live state at the end of the wave (take_spares)
-    uint32_t n_bfs = 0, n_inline = 0, n_taken = 0;  // workload counters (S.stats)
+    uint32_t n_bfs = 0, n_inline = 0, n_taken = 0, n_cont = 0;  // workload counters (S.stats)
     uint32_t key = 0;
     bool listed = false;  // the env is in the stair set this launch reads (its player stands on the stairs)
     // LDS monster cache: column `lane` of [nrooms][64] words behind the generation / BFS staging area
@@ -2244,6 +2337,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             if (need_gen && __hip_atomic_load(&S.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) { taken = true; need_gen = false; n_taken++; }
         }
         const bool regenerated = descends && pass == 0;
+        if constexpr (BW == 1 || BW == 2) { if (pass == 0 && S.dc_walk) snapshot_walk_service(S, c, lane, e, descends); }
         if (need_gen) n_inline++;
         gen_service<GM>(S, c, E, lane, e, need_gen, pass == 1, lds_grid, pf);  // W <= 32: at most 12 rooms; the wider instances carry the 64-room generator
         (void)regenerated;  // (a descended lane's monster-cache column was refilled by gen_service from the generator's own table)
@@ -2254,7 +2348,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         bool running = live && act != ACT_NOOP;
         int iter = 0;
         while (__any(running)) {
-            bool do_turn = false, need_bfs = false;
+            bool do_turn = false, need_bfs = false, opened = false, own_req = false;
             int map_slot = -1;
             FillReq fr; fr.leave = fr.enter = 0;
             if (running) {
@@ -2273,18 +2367,29 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
                     break;
                 }
                 case ACT_SEARCH:
-                    do_search(c, E, w, react);
+                    opened = do_search(c, E, w, react);
                     do_turn = true; running = false;
                     break;
                 }
             }
+            if constexpr (BW == 1 || BW == 2) { if (__any(opened) && S.dc_walk) snapshot_walk_service(S, c, lane, e, opened); }
             pf.mark(28);
             if (do_turn) turn_passed(c, E, react);  // actions::after_turn (actions.rs:67-80)
             pf.mark(29);
             bool need_map = false;
             if (do_turn && E.mon_active > 0) need_map = monsters_prepass(S, c, E);
             pf.mark(30);
-            if (need_map) need_bfs = !dist_cache_lookup(S, E, POS(E.px, E.py), map_slot);
+            if (need_map) {
+                need_bfs = !dist_cache_lookup(S, E, POS(E.px, E.py), map_slot);
+                if constexpr (BW == 1 || BW == 2) {
+                    // a cached PARTIAL map that does not reach one of this turn's chasers is continued (bfs_rows_n32)
+                    if (!need_bfs && ((S.dc_part[e] >> map_slot) & 1u) && !dist_map_sufficient(S, c, E, map_slot)) {
+                        need_bfs = true;
+                        own_req = (S.dc_own[e] >> map_slot) & 1u;
+                        if (own_req) n_cont++;
+                    }
+                }
+            }
             pf.mark(3);
             // whole-room reveals / hides by the wave, then the lanes' changed window cells (the final word on those cells); both before any
             // monster or BFS read of the grid
@@ -2295,7 +2400,15 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             if (need_bfs) n_bfs++;
             if (m) {  // serve the requesting lanes with the whole wave, several maps per round
                 unsigned long long tb0 = pf.p ? __builtin_amdgcn_s_memtime() : 0;
-                bfs_service<BW>(S, c, reinterpret_cast<uint64_t *>(lds_grid), m, e, E.px, E.py, map_slot, lane);
+                const bool complete = bfs_service<BW>(S, c, reinterpret_cast<uint64_t *>(lds_grid), m, e, E.px, E.py, map_slot, lane, E.mc - lane, __ballot(own_req));
+                if constexpr (BW == 1 || BW == 2) {
+                    if (need_bfs) {  // a new map starts from the level's own cells; a complete one needs no saved mask any more
+                        const uint32_t bit = 1u << map_slot;
+                        const uint32_t part = S.dc_part[e], own = S.dc_own[e];
+                        S.dc_part[e] = (uint16_t)(complete ? part & ~bit : part | bit);
+                        S.dc_own[e] = (uint16_t)((own_req && !complete) ? own : own & ~bit);
+                    }
+                } else (void)complete;
                 if (pf.p) { pf.rec(24, __builtin_amdgcn_s_memtime() - tb0); pf.rec(25, (unsigned long long)__popcll(m)); }
             }
             pf.mark(4);
@@ -2324,13 +2437,13 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     if (S.stats) {
         // per-BLOCK rows, plain read-modify-write by the block's own lane 0 (launches of one handle are stream-ordered): no atomics.  (One
         // atomicAdd per wave and counter on a shared 64-byte line -- 7 000 same-line atomics per launch -- cost the kernel 20 us, measured.)
-        const uint32_t cnt[7] = {(uint32_t)__popcll(__ballot(live && terminal && c.auto_reset)), (uint32_t)__popcll(__ballot(descends)),
+        const uint32_t cnt[8] = {(uint32_t)__popcll(__ballot(live && terminal && c.auto_reset)), (uint32_t)__popcll(__ballot(descends)),
                                  wave_sum(n_bfs), wave_sum(n_inline), wave_sum(n_taken), (uint32_t)__popcll(__ballot(live && (react & R_REDRAW))),
-                                 (uint32_t)__popcll(__ballot(live))};
-        if (lane < 7) {
+                                 (uint32_t)__popcll(__ballot(live)), (BW == 1 || BW == 2) ? wave_sum(n_cont) : 0u};
+        if (lane < 8) {
             uint32_t mine = 0;
 #pragma unroll
-            for (int k = 0; k < 7; k++) mine = lane == k ? cnt[k] : mine;
+            for (int k = 0; k < 8; k++) mine = lane == k ? cnt[k] : mine;
             if (mine) S.stats[(size_t)blockIdx.x * 8 + lane] += mine;
         }
     }
@@ -2347,7 +2460,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
                 E.dlevel = 1; E.gold = c.init_gold; E.hp = E.hpmax = c.init_hp; E.plvl = 1; E.exp = 0; E.food = c.hunger_time;
             }
             write_status(S, c, E);
-            S.dc_len[e] = 0; S.dc_head[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
+            S.dc_len[e] = 0; S.dc_head[e] = 0; S.dc_part[e] = 0; S.dc_own[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
             steps = 0;
             flags = RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY;
             klog_new_episode(S, e);

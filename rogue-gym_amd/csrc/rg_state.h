@@ -36,6 +36,11 @@ enum { RK_NORMAL = 0, RK_MAZE = 1, RK_EMPTY = 2 };
 #define MF_ALIVE   0x01u
 #define MF_ACTIVE  0x02u      // in active_enemies (and `running`)
 #define MF_PENDING 0x04u      // active and not yet moved this turn (still in the taken map, enemies.rs:376-380)
+// cache-only bits of the running turn (k_step's LDS monster cache); never stored to global memory
+#define MF_RANDOM 0x08u
+#define MF_DIR_SHIFT 4        // bits 4..6 of the flag byte
+#define MF_REACH 0x80u        // stands next to the player and attacks at the end of this turn (actions::move_active_enemies, actions.rs:82-119)
+#define MF_TURN_BITS (MF_PENDING | MF_RANDOM | (7u << MF_DIR_SHIFT) | MF_REACH)   // cache-only bits of the running turn; never stored to global memory
 
 // Every connect_2rooms call joins a pair of grid-adjacent rooms that was not joined before (dig_passges excludes joined pairs, passages.rs:33-66),
 // so a level has at most rnx*(rny-1) + rny*(rnx-1) < 2 * rooms corridors whatever max_extra_edges says.
@@ -82,6 +87,11 @@ struct RgState {
     uint16_t *dc_map;   // [n][RG_DIST_SLOTS][hw], 0xFFFF = unreachable
     uint16_t *dc_key;   // [RG_DIST_SLOTS][n] target pos
     uint8_t *dc_head, *dc_len;  // [n] FIFO ring
+    // partial maps (grids of 33..96 columns, rg_kernels.hip bfs_rows_n32): bit s of dc_part = slot s holds a map that was not expanded to the end;
+    // bit s of dc_own = its walkable mask was saved into dc_walk when the level's cells were about to change
+    uint16_t *dc_part, *dc_own;  // [n]
+    uint32_t *dc_walk;           // [n][RG_DIST_SLOTS][H][(W + 31) / 32] or null
+    int full_bfs;                // ROGUE_GYM_HIP_FULL_BFS=1: every map is expanded to the end (the A side of tests/test_gpu_features.py::test_partial_dist_maps_*)
     // optional in-kernel phase profile (development aid): [2][32] u64 = {max cycles, sum cycles} per phase, NULL = off
     unsigned long long *prof;
     // spare-level pipeline: 0 = spare must be (re)generated, 1 = ready, 2 = generation in progress

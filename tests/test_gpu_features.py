@@ -687,3 +687,94 @@ def test_mixed_screen_sizes_behind_one_handle(goldens):
     game.close()
     with pytest.raises(RuntimeError, match="differ in width / height"):
         HipVecRogueEnv(cfgs, image_setting=ImageSetting(DungeonType.GRAY, StatusFlag.EMPTY, False))
+
+
+# ---------------------------------------------------------------------------------------------
+# partial dist maps (grids of 33..96 columns: rg_kernels.hip bfs_rows_n32).  A map is expanded only as far as this turn's chasers stand and
+# continued when a later turn needs more of it -- over the walkable cells of the moment it was STARTED (the reference caches whole maps by
+# target cell and never invalidates them: rogue/mod.rs:504-517), which outlive descents and opening searches in a saved mask.
+# ---------------------------------------------------------------------------------------------
+_CHASE = {"dungeon": {"style": "rogue", "room_num_x": 3, "room_num_y": 3, "dark_level": 3, "maze_rate_inv": 6, "max_empty_rooms": 1,
+                      "hidden_passage_rate_inv": 3, "locked_door_rate_inv": 2, "max_extra_edges": 6, "door_unlock_rate_inv": 1, "passage_unlock_rate_inv": 2},
+          "enemies": {"enemies": [0, 1, 2, 5, 7, 8, 10, 18], "appear_rate_gold": 100, "appear_rate_nogold": 100},
+          "player": {"init_hp": 400, "hunger_time": 100000}}
+
+
+def _debug_tuple(h, i):
+    d, cells = h.debug_state(i)
+    mons = sorted((d.mon_x[k], d.mon_y[k], d.mon_type[k], d.mon_active[k], d.mon_hp[k]) for k in range(d.n_monsters))
+    return (d.px, d.py, d.dungeon_level, d.hp, d.exp, d.quiet, d.n_monsters, tuple(d.rng), mons, cells.tobytes())
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("size", [(80, 24), (64, 40), (96, 32), (40, 20)])
+def test_partial_dist_maps_equal_full_maps(goldens, size):
+    """The same envs and keys through two handles of this process: one created with ROGUE_GYM_HIP_FULL_BFS=1 (every map expanded to the end, the
+    form the oracle sweeps were run against), one with partial maps.  Strong players that search a lot, hidden / locked cells that open at once,
+    every room with a mean monster, frequent descents: mirrors after every step, the whole internal state of sampled envs at intervals."""
+    import os
+    from rogue_gym_python import _rogue_gym as inner
+
+    cfg = dict(goldens["configs"]["default"], width=size[0], height=size[1], **_CHASE)
+    n, steps = 3072, 700
+    cfgs = [json.dumps(dict(cfg, seed=9000 + i)) for i in range(n)]
+    os.environ["ROGUE_GYM_HIP_FULL_BFS"] = "1"
+    try:
+        full = inner._Handle(cfgs, 400, auto_reset=True)
+    finally:
+        del os.environ["ROGUE_GYM_HIP_FULL_BFS"]
+    part = inner._Handle(cfgs, 400, auto_reset=True)
+    rng = np.random.RandomState(77)
+    table = np.frombuffer(b"hjklyubnhjklyubnHJKLYUBN>>>>sss.", np.uint8)
+    sample = list(range(0, n, 97))
+    for t in range(steps):
+        keys = np.ascontiguousarray(table[rng.randint(0, len(table), n)])
+        for h in (full, part):
+            h.check(h.L.rg_step(h.h, keys.ctypes.data, 0))
+        a, b = full.fetch(), part.fetch()
+        for x, y, what in zip(a, b, ("screen", "hist", "status", "flags")):
+            if not np.array_equal(x, y):
+                bad = [i for i in range(n) if not np.array_equal(x[i], y[i])]
+                raise AssertionError("t=%d: %s differs for envs %s" % (t, what, bad[:8]))
+        if t % 100 == 99:
+            for i in sample:
+                assert _debug_tuple(full, i) == _debug_tuple(part, i), "t=%d env %d" % (t, i)
+    cf, cp = (C.c_uint64 * 8)(), (C.c_uint64 * 8)()
+    full.check(full.L.rg_counters(full.h, cf, 0))
+    part.check(part.L.rg_counters(part.h, cp, 0))
+    # the partial side builds more (shorter) maps, continues some of them on a later level / after a search opened a door; the full side never does
+    assert cf[7] == 0 and cp[7] > 50 and cp[2] > cf[2] and list(cf)[:2] == list(cp)[:2], (list(cf), list(cp))
+    full.close()
+    part.close()
+
+
+@pytest.mark.timeout(900)
+def test_lockstep_chasers_partial_maps(goldens):
+    """... and against the oracle itself (whole maps, FIFO BFS): the chaser-heavy 80x24 config in lock step, random keys with many searches and
+    descents, then the stairs-seeking policy (many levels, so maps started on one level are continued on the next ones)."""
+    from test_gpu_parity import _stair_seeker_keys
+
+    cfg = dict(goldens["configs"]["default"], **_CHASE)
+    rng = np.random.RandomState(31)
+    table = np.frombuffer(b"hjklyubnhjklyubnHJKLYUBN>>>sss.", np.uint8)
+    keys = [table[rng.randint(0, len(table), 64)] for _ in range(400)]
+    lockstep(cfg, list(range(7000, 7064)), keys, max_steps=300, check_every=1, internal_every=50)
+
+    cfg["dungeon"] = dict(cfg["dungeon"], locked_door_rate_inv=8, hidden_passage_rate_inv=8)
+    cfg["enemies"] = dict(cfg["enemies"], enemies=[2, 5, 7, 10])
+    n = 16
+    seeds = list(range(7100, 7100 + n))
+    hip = HipBatch(cfg, seeds, max_steps=600)
+    oracles = make_oracles(cfg, seeds, max_steps=600)
+    stuck = [0] * n
+    deepest = 1
+    for t in range(500):
+        keys = _stair_seeker_keys(oracles, rng, stuck)
+        hip.step(keys)
+        for i, o in enumerate(oracles):
+            o.step_autoreset(int(keys[i]))
+        compare_mirrors(hip, oracles, "t=%d" % t)
+        if t % 100 == 99:
+            compare_internal(hip, oracles, range(n), "t=%d" % t)
+        deepest = max(deepest, max(int(o.status_arr()[0]) for o in oracles))
+    assert deepest >= 3, deepest
