@@ -243,14 +243,22 @@ def main():
     elif torch.cuda.device_count() < min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
         sys.exit("bench.py: %d ranks on this node but only %d GPU(s) visible (one rank per GPU; ROGUE_GYM_BENCH_ONE_DEVICE=1 is the 1-GPU development mode)"
                  % (world, torch.cuda.device_count()))
+    data_group, data_group_error = None, None
     if world > 1:
+        import datetime
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        if one_device:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # Two process groups.  CONTROL (barrier, max over ranks of the wall time: CPU scalars) is gloo over 127.0.0.1 -- the sharded path has no
+        # data-path collective, so nothing about the GPU interconnect may take the headline down with it.  DATA is backend "nccl" =
+        # RCCL over xGMI: the all-gather legs below run on it (its communicator is created at the first collective, inside the guarded leg).
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+        if not one_device:
+            try:
+                data_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+            except Exception as e:  # noqa: BLE001
+                data_group_error = "%s: %s" % (type(e).__name__, e)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -289,7 +297,7 @@ def main():
         for _ in range(kc):
             hz.step()
         barrier()
-        cdt = torch.tensor([time.perf_counter() - c0], dtype=torch.float64, device=dev)
+        cdt = torch.tensor([time.perf_counter() - c0], dtype=torch.float64)
         if world > 1:
             dist.all_reduce(cdt, op=dist.ReduceOp.MAX)
         for _ in range(args.preroll_steps - kc):
@@ -319,7 +327,7 @@ def main():
     sclk_after = hz.sclk()
     env.check_errors()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_max = float(tmax.item())
@@ -334,7 +342,7 @@ def main():
             for _ in range(K):
                 hz.step()
             barrier()
-            r = torch.tensor([time.perf_counter() - r0], dtype=torch.float64, device=dev)
+            r = torch.tensor([time.perf_counter() - r0], dtype=torch.float64)
             if world > 1:
                 dist.all_reduce(r, op=dist.ReduceOp.MAX)
             runs.append(float(r.item()) / K * 1e3)
@@ -354,7 +362,10 @@ def main():
         rec = env._h.L.rg_compact_record_bytes(env._h.h, 0)
         payload = ("one all-gather per step of %d-byte records (u8 screen [%d,%d] + i32 status [10]) = %.1f MB per rank, expanded to f32 [N,%d,%d,%d] "
                    "on every rank by rg_expand_compact" % (rec, env.height, env.width, rec * n / 1e6, env.channels, env.height, env.width))
-        gather = {"unit": "env-steps/s", "payload": payload}
+        gather = {"unit": "env-steps/s", "payload": payload,
+                  "process_groups": {"control": "gloo: barrier + max over ranks (CPU scalars)",
+                                     "data": "gloo (ROGUE_GYM_BENCH_ONE_DEVICE)" if one_device else ("nccl = RCCL: every all-gather below" if data_group is not None else "unavailable: %s" % data_group_error)}}
+        env.process_group = data_group  # torch.distributed leg: all_gather_into_tensor on the RCCL group
 
         def leg(name):
             for _ in range(5):
@@ -364,7 +375,7 @@ def main():
             for _ in range(args.gather_steps):
                 hz.step(); env.all_gather_obs(compact=True)
             barrier()
-            gdt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=dev)
+            gdt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64)
             dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
             gather[name] = n * world * args.gather_steps / float(gdt.item())
 
@@ -388,7 +399,11 @@ def main():
             done.set()
             t.cancel()
 
-        gather_legs = [("value", lambda: leg("value"))]   # torch.distributed
+        gather_legs = []
+        if one_device or data_group is not None:
+            gather_legs.append(("value", lambda: leg("value")))   # torch.distributed
+        else:
+            gather["value_error"] = "no RCCL process group: %s" % data_group_error
         if not one_device:  # two ranks cannot share one GPU under RCCL: the C-ABI communicator needs one device per rank
             def cabi():
                 env.init_comm()

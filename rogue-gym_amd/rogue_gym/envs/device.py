@@ -178,15 +178,16 @@ class HipVecRogueEnv:
             return self.expand_records(self.all_gather_records(with_hist), packed_has_hist=with_hist)
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return self.obs
-        ws = dist.get_world_size()
+        group = getattr(self, "process_group", None)  # None = the default group; a host whose default group is a CPU one sets its RCCL group here
+        ws = dist.get_world_size(group)
         if not compact:
             out = torch.empty((ws * self.num_envs,) + tuple(self.obs.shape[1:]), dtype=self.obs.dtype, device=self.device)
-            dist.all_gather_into_tensor(out, self.obs)
+            dist.all_gather_into_tensor(out, self.obs, group=group)
             return out
         from .sharding import all_gather_packed
 
         with_hist = bool(self.image_setting.includes_hist)
-        gathered = all_gather_packed(self.packed_records(with_hist))
+        gathered = all_gather_packed(self.packed_records(with_hist), group=group)
         return self.expand_records(gathered, packed_has_hist=with_hist)
 
     def all_gather_compact(self, with_hist: bool = False):
@@ -196,7 +197,7 @@ class HipVecRogueEnv:
 
         packed = self.packed_records(with_hist)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            packed = all_gather_packed(packed)
+            packed = all_gather_packed(packed, group=getattr(self, "process_group", None))
         return unpack_records(packed, self.height, self.width, with_hist)
 
     def status_vec(self, flag=None):
