@@ -1,0 +1,153 @@
+"""Config fuzzer for the parity gate: random VALID GameConfigs (sizes 32x16 .. 160x48 incl. widths that are not multiples of 8, room grids from 1x1 to the
+geometric maximum, every dungeon / gold / enemy / player rate, random packs, random monster subsets) played in lock step by the HIP stepper and the C
+oracle on random keys.  Mirrors are compared after every step, the internal state (tiles, doors, gold, monsters, every RNG word) at intervals.
+
+    python tools/fuzz_parity.py [--configs 40] [--envs 48] [--steps 150] [--seed 1] [--minutes 0]
+
+Needs a GPU.  Prints one line per config; a failing config is printed as JSON (and appended to gpurun_out/fuzz_failures.jsonl) so that it can be turned
+into a regression test.  Exit code 1 if anything differed.  Development / soak tool: tests/test_gpu_fuzz.py runs a small fixed-seed slice of it."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "rogue-gym_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+WEAPONS = ["mace", "long-sword", "bow", "arrow", "dagger", "two-handed-sword", "dart", "shuriken", "spear"]
+ARMORS = ["leather armor", "ring mail", "studded leather armor", "scale mail", "chain mail", "splint mail", "banded mail", "plate mail"]
+
+
+def random_config(rng):
+    """One random config; may still be refused by the validator (min_room_size vs the room grid): the caller skips those."""
+    if rng.rand() < 0.35:
+        w, h = [(32, 16), (80, 24), (64, 32), (40, 20), (96, 40), (160, 48), (128, 24)][rng.randint(0, 7)]
+    else:
+        w, h = int(rng.randint(32, 161)), int(rng.randint(16, 49))
+    rx = int(rng.randint(1, max(2, min(12, w // 6) + 1)))
+    ry = int(rng.randint(1, max(2, min(7, h // 5) + 1)))
+    if rng.rand() < 0.08:  # many small rooms: the 64-room and 384-room generator instances
+        rx, ry = max(rx, w // int(rng.randint(4, 9))), max(ry, h // int(rng.randint(5, 8)))
+    rooms = rx * ry
+    d = {"style": "rogue", "room_num_x": rx, "room_num_y": ry,
+         "dark_level": int(rng.choice([1, 2, 3, 5, 10, 1000])), "maze_rate_inv": int(rng.choice([1, 2, 4, 15, 1000])),
+         "max_empty_rooms": int(rng.randint(0, max(1, min(rooms, 6)))),
+         "hidden_passage_rate_inv": int(rng.choice([1, 2, 4, 40, 1000])), "locked_door_rate_inv": int(rng.choice([1, 2, 5, 40, 1000])),
+         "max_extra_edges": int(rng.choice([1, 2, 5, 12, 400])),
+         "door_unlock_rate_inv": int(rng.choice([1, 2, 5])), "passage_unlock_rate_inv": int(rng.choice([1, 3, 5]))}
+    if rng.rand() < 0.3:
+        d["amulet_level"] = int(rng.randint(1, 6))
+    cfg = {"width": w, "height": h, "dungeon": d, "hide_dungeon": bool(rng.rand() < 0.7)}
+    if rng.rand() < 0.7:
+        cfg["item"] = {"armor": {}, "weapon": {},
+                       "gold": {"rate_inv": int(rng.randint(1, 5)), "base": int(rng.randint(0, 120)), "per_level": int(rng.randint(0, 40)), "minimum": int(rng.randint(0, 9))}}
+    r = rng.rand()
+    if r < 0.15:
+        cfg["enemies"] = {"enemies": []}
+    elif r < 0.75:
+        k = int(rng.randint(1, 12))
+        cfg["enemies"] = {"enemies": sorted(int(v) for v in rng.choice(26, k, replace=False)),
+                          "appear_rate_gold": int(rng.randint(0, 101)), "appear_rate_nogold": int(rng.randint(0, 101))}
+    p = {}
+    if rng.rand() < 0.6:
+        p["init_hp"] = int(rng.choice([3, 12, 40, 200, 1000]))
+    if rng.rand() < 0.4:
+        p["hunger_time"] = int(rng.choice([40, 150, 1300, 100000]))
+    if rng.rand() < 0.4:
+        items = []
+        if rng.rand() < 0.8:
+            items.append({"Weapon": {"name": str(rng.choice(WEAPONS)), "num_plus": int(rng.randint(0, 3)), "hit_plus": int(rng.randint(0, 4)), "dam_plus": int(rng.randint(0, 4))}})
+        if rng.rand() < 0.8:
+            items.append({"Armor": {"name": str(rng.choice(ARMORS)), "def_plus": int(rng.randint(0, 3))}})
+        if rng.rand() < 0.5:
+            items.append({"Weapon": {"name": str(rng.choice(WEAPONS)), "num_plus": 0, "hit_plus": 0, "dam_plus": 0}})
+        if rng.rand() < 0.85:  # without a Gold item in the pack nothing can be picked up (itembox.rs:30-40)
+            items.append({"Noinit": {"kind": "Gold", "how_many": int(rng.randint(0, 500)), "attr": 4}})
+        p["init_items"] = items
+        if "item" not in cfg:
+            cfg["item"] = {"armor": {}, "weapon": {}, "gold": {"rate_inv": 2, "base": 50, "per_level": 10, "minimum": 2}}
+    if p:
+        cfg["player"] = p
+    return cfg
+
+
+def run_one(cfg, n_env, steps, rng, inner, lockstep):
+    max_steps = int(rng.choice([25, 60, 150, 1000]))
+    table = np.frombuffer([b".hjklnbuy>shjklnbuyHJKLYUBN", b"hjklyubn>>>sss", b"HJKLYUBNhjkl>s."][rng.randint(0, 3)], np.uint8)
+    keys = [table[rng.randint(0, len(table), n_env)] for _ in range(steps)]
+    seeds = [int(v) for v in rng.randint(0, 1 << 30, n_env)]
+    if rng.rand() < 0.7:
+        lockstep(cfg, seeds, keys, max_steps=max_steps, check_every=1, internal_every=max(10, steps // 6))
+        return
+    # deep start: 1 .. 28 forced descents on both engines (the descent path of k_step on its own), every level compared, then lock-step play there
+    # -- the monster tables, dark rooms, mazes and hidden cells of levels the random policy never reaches, on this config's geometry
+    from parity_util import HipBatch, compare_internal, make_oracles
+    hip = HipBatch(cfg, seeds, max_steps=10 ** 6)
+    oracles = make_oracles(cfg, seeds, max_steps=10 ** 6)
+    depth = int(rng.randint(1, 29))
+    for lv in range(depth):
+        hip.h.check(hip.h.L.rg_debug_descend(hip.h.h))
+        for o in oracles:
+            o.debug_descend()
+        compare_internal(hip, oracles, range(lv % 3, n_env, 3), "forced descent %d" % (lv + 1))
+    # (the hook is a test-only entry without Reactions: the oracle's mirrors -- screen, status and the history of "the level in the mirror status" --
+    #  stay where they were until real Redraw / StatusUpdated reactions arrive, so the deep part compares the engines' internal state only: tiles
+    #  with their visibility / drawn / visited bits, doors, gold, monsters, player, all RNG words)
+    for t, k in enumerate(keys):
+        hip.step(k)
+        for i, o in enumerate(oracles):
+            o.step_autoreset(int(k[i]))
+        if (t + 1) % 5 == 0:
+            compare_internal(hip, oracles, range(n_env), "deep t=%d" % (t + 1))
+    hip.sync()
+    compare_internal(hip, oracles, range(n_env), "deep end")
+    hip.h.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", type=int, default=40)
+    ap.add_argument("--envs", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--minutes", type=float, default=0.0, help="keep drawing configs until this much time has passed (overrides --configs)")
+    args = ap.parse_args()
+    from parity_util import lockstep
+    from rogue_gym_python import _rogue_gym as inner
+
+    L = inner.load_library()
+    rng = np.random.RandomState(args.seed)
+    t0 = time.time()
+    done = skipped = failed = 0
+    while (time.time() - t0 < args.minutes * 60) if args.minutes > 0 else (done < args.configs):
+        cfg = random_config(rng)
+        text = json.dumps(cfg)
+        buf = (inner.C.c_char * 65536)()
+        if L.rg_config_canonical(text.encode(), buf, len(buf)):  # refused (e.g. min_room_size does not fit): not a parity case
+            skipped += 1
+            if skipped > 50 * (done + 1):
+                raise SystemExit("the generator produces almost only invalid configs")
+            continue
+        done += 1
+        tag = "%dx%d rooms %dx%d" % (cfg["width"], cfg["height"], cfg["dungeon"]["room_num_x"], cfg["dungeon"]["room_num_y"])
+        t1 = time.time()
+        try:
+            run_one(cfg, args.envs, args.steps, rng, inner, lockstep)
+            print("ok   #%d %-26s %.1f s" % (done, tag, time.time() - t1), flush=True)
+        except Exception as e:  # noqa: BLE001
+            failed += 1
+            msg = str(e).splitlines()[0][:300] if str(e) else type(e).__name__
+            print("FAIL #%d %-26s %s\n     %s" % (done, tag, msg, text), flush=True)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "fuzz_failures.jsonl"), "a") as f:
+                f.write(json.dumps({"config": cfg, "error": str(e)[:2000], "fuzz_seed": args.seed, "index": done}) + "\n")
+    print("fuzz: %d configs, %d failed, %d invalid draws skipped, %.0f s" % (done, failed, skipped, time.time() - t0))
+    return 1 if failed else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
