@@ -81,7 +81,19 @@ def run_one(cfg, n_env, steps, rng, inner, lockstep):
     keys = [table[rng.randint(0, len(table), n_env)] for _ in range(steps)]
     seeds = [int(v) for v in rng.randint(0, 1 << 30, n_env)]
     if rng.rand() < 0.7:
-        lockstep(cfg, seeds, keys, max_steps=max_steps, check_every=1, internal_every=max(10, steps // 6))
+        hip, oracles = lockstep(cfg, seeds, keys, max_steps=max_steps, check_every=1, internal_every=max(10, steps // 6))
+        # ... and the observation encoders on the final states: gray and one-hot symbol image with a random status-flag set, with / without history
+        flag, with_hist = int(rng.choice([0, 1, 0x1FF, 0b010000011, int(rng.randint(0, 512))])), bool(rng.rand() < 0.5)
+        g = hip.obs(0, flag, with_hist)
+        sy = hip.obs(1, flag, with_hist)
+        for i, o in enumerate(oracles):
+            assert np.array_equal(g[i], o.gray_image(flag, with_hist)), "gray image env %d flag %x hist %d" % (i, flag, with_hist)
+            try:
+                exp = o.symbol_image(flag, with_hist)
+            except RuntimeError:  # a 'Z' glyph on the screen: an error in the reference too (symbol.rs:51-71)
+                continue
+            assert np.array_equal(sy[i], exp), "symbol image env %d flag %x hist %d" % (i, flag, with_hist)
+        hip.h.L.rg_sync(hip.h.h)  # drain a possible tile-error flag
         return
     # deep start: 1 .. 28 forced descents on both engines (the descent path of k_step on its own), every level compared, then lock-step play there
     # -- the monster tables, dark rooms, mazes and hidden cells of levels the random policy never reaches, on this config's geometry
