@@ -140,6 +140,33 @@ def run_one(cfg, n_env, steps, rng, inner, lockstep):
     hip.h.close()
 
 
+def run_mixed(cfgs, n_env, steps, rng):
+    """Several random configs (different sizes, room grids, monster tables, packs) interleaved behind ONE handle through the reference-named value-object
+    API (ParallelGameState.step -> states): every env against its own oracle -- screen, history, status, is_terminal after every step."""
+    from oracle.pyoracle import OracleEnv
+    from rogue_gym_python._rogue_gym import ParallelGameState
+
+    max_steps = int(rng.choice([40, 120, 1000]))
+    order = rng.randint(0, len(cfgs), n_env)
+    per_env = [dict(cfgs[k], seed=int(rng.randint(0, 1 << 30))) for k in order]
+    game = ParallelGameState(max_steps, [json.dumps(c) for c in per_env])
+    oracles = [OracleEnv(c, max_steps=max_steps) for c in per_env]
+    table = np.frombuffer(b"hjklyubnHJKLYUBN>>ss.", np.uint8)
+    st = game.states()
+    for t in range(steps + 1):
+        if t:
+            keys = table[rng.randint(0, len(table), n_env)]
+            st = game.step(keys.tobytes())
+            for i, o in enumerate(oracles):
+                o.step_autoreset(int(keys[i]))
+        for i, o in enumerate(oracles):
+            assert np.array_equal(st.screen[i], o.screen()), "mixed t=%d env %d (config %d) screen" % (t, i, order[i])
+            assert np.array_equal(st.hist[i], o.hist()), "mixed t=%d env %d (config %d) hist" % (t, i, order[i])
+            assert [int(v) & 0xFFFFFFFF for v in st.status[i]] == [int(v) for v in o.status_arr()], "mixed t=%d env %d (config %d) status" % (t, i, order[i])
+            assert bool(st.is_terminal[i]) == o.flags()["is_terminal"], "mixed t=%d env %d (config %d) is_terminal" % (t, i, order[i])
+    game.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", type=int, default=40)
@@ -155,6 +182,7 @@ def main():
     rng = np.random.RandomState(args.seed)
     t0 = time.time()
     done = skipped = failed = 0
+    recent = []
     while (time.time() - t0 < args.minutes * 60) if args.minutes > 0 else (done < args.configs):
         cfg = random_config(rng)
         text = json.dumps(cfg)
@@ -168,7 +196,15 @@ def main():
         tag = "%dx%d rooms %dx%d" % (cfg["width"], cfg["height"], cfg["dungeon"]["room_num_x"], cfg["dungeon"]["room_num_y"])
         t1 = time.time()
         try:
-            run_one(cfg, args.envs, args.steps, rng, inner, lockstep)
+            if rng.rand() < 0.12:  # this config and 1..3 earlier ones behind one handle
+                group = [cfg] + [recent[int(rng.randint(0, len(recent)))] for _ in range(int(rng.randint(1, 4)))] if recent else [cfg]
+                tag = "mixed x%d, first %s" % (len(group), tag)
+                text = json.dumps(group)
+                run_mixed(group, args.envs, min(args.steps, 120), rng)
+            else:
+                run_one(cfg, args.envs, args.steps, rng, inner, lockstep)
+            recent.append(cfg)
+            del recent[:-8]
             print("ok   #%d %-26s %.1f s" % (done, tag, time.time() - t1), flush=True)
         except Exception as e:  # noqa: BLE001
             failed += 1
