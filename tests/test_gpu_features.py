@@ -778,3 +778,15 @@ def test_lockstep_chasers_partial_maps(goldens):
             compare_internal(hip, oracles, range(n), "t=%d" % t)
         deepest = max(deepest, max(int(o.status_arr()[0]) for o in oracles))
     assert deepest >= 3, deepest
+
+
+@pytest.mark.timeout(300)
+def test_quickstart_example_runs():
+    """examples/quickstart.py: the three entry points (RogueEnv, ParallelRogueEnv, HipVecRogueEnv) as a user would call them."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "quickstart.py")], cwd=root, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RogueEnv: obs (19, 16, 32)" in r.stdout and "ParallelRogueEnv: 1024 envs" in r.stdout and "M env-steps/s" in r.stdout, r.stdout[-1500:]
