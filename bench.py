@@ -220,7 +220,7 @@ def main():
     ap.add_argument("--preroll-steps", type=int, default=1500, help="untimed steps of the MEASURED batch before the warm-up: reach the steady-state episode mix "
                     "the metric is defined on (the first --steps of them are timed and reported as preroll.cold_start); 0 = off.  1.5 x max_steps: "
                     "not on a multiple of max_steps, where the survivors of the synchronised first episodes all reset at once")
-    ap.add_argument("--time-every", type=int, default=7, help="time every N-th launch of each kernel with a HIP-event pair (every 5th when steps < 64, every one when < 16); odd on purpose: "
+    ap.add_argument("--time-every", type=int, default=7, help="time every N-th launch of each kernel with a HIP-event pair (every 3rd when steps < 64, every one when < 16); odd on purpose: "
                     "the background generator runs beside every second k_step, an even stride would sample one kind only")
     ap.add_argument("--gather-steps", type=int, default=50, help="extra steps timed WITH the observation all-gather (N>1)")
     args = ap.parse_args()
@@ -311,8 +311,9 @@ def main():
     for _ in range(W):
         hz.step()
     # HIP-event pairs around a launch cost stream time (~3-4 us per record): every launch when there are very few, every 2nd for short runs
-    # (4 samples per kernel for the driver's 20 steps: an event pair costs ~2 us of stream time), every --time-every-th for long ones
-    every = 1 if K < 16 else (5 if K < 64 else args.time_every)
+    # (7 samples per kernel for the driver's 20 steps -- k_step is bimodal, 67 us without and 82 us with the background generator beside it, so fewer
+    # samples make the reported average jump; an event pair costs ~2 us of stream time), every --time-every-th for long ones
+    every = 1 if K < 16 else (3 if K < 64 else args.time_every)
     hz.timing(every)  # HIP-event pairs on the launch stream around every `every`-th launch of each kernel
     env.counters(reset=True)
     barrier()
