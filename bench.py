@@ -516,6 +516,36 @@ def main():
                 except Exception as e:
                     extra[name] = {"error": str(e)}
             out["extra_workloads"] = extra
+            # The same workload with ROGUE_GYM_HIP_KEEP_SPARES=1 (opt-in, off by default and off for `value`): GameConfig::build is a pure function of
+            # config and seed, so an env with a FIXED seed resets to the same level-1 state every episode and its pre-built spare need not be consumed and
+            # generated again.  `value` regenerates every consumed spare, as the reference rebuilds every RunTime; this is the rate without that work.
+            try:
+                os.environ["ROGUE_GYM_HIP_KEEP_SPARES"] = "1"
+                try:
+                    x = Harness(torch, "mini", 0, 0, local_rank)
+                finally:
+                    del os.environ["ROGUE_GYM_HIP_KEEP_SPARES"]
+                for _ in range(1500 + 50):
+                    x.step()
+                x.timing(7)
+                x.env.counters(reset=True)
+                torch.cuda.synchronize()
+                x0 = time.perf_counter()
+                for _ in range(600):
+                    x.step()
+                torch.cuda.synchronize()
+                xdt = time.perf_counter() - x0
+                pk = x.read_timing()
+                cn = x.env.counters(reset=True)
+                x.env.check_errors()
+                out["fixed_seed_spares_kept"] = {"value": x.n * 600 / xdt, "unit": "env-steps/s", "steps": 600, "preroll": 1500, "warmup": 50, "ms_per_step": xdt / 600 * 1e3,
+                                                 "per_kernel": pk, "rates_per_s": {k: v / xdt for k, v in cn.items()},
+                                                 "note": "opt-in ROGUE_GYM_HIP_KEEP_SPARES=1: resets of fixed-seed envs copy an immutable pre-built level-1 state (bit-identical "
+                                                         "results, tests/test_gpu_features.py::test_kept_spares_*); NOT the headline, which regenerates every consumed spare"}
+                x.close()
+                del x
+            except Exception as e:
+                out["fixed_seed_spares_kept"] = {"error": str(e)}
         if not args.no_cpu_baseline and WORKLOADS[args.workload][2] == "gray":
             out["cpu_baseline"] = cpu_baseline(golden_config(WORKLOADS[args.workload][0]), WORKLOADS[args.workload][5])
     if rank == 0:

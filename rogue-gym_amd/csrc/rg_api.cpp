@@ -40,6 +40,7 @@ struct rg_handle {
     uint64_t step_count = 0;
     hipStream_t side = nullptr;  // stream of the background generator (LOW priority: the step kernel's blocks are placed first, k_regen takes what is left; rg_step_prefix)
     hipEvent_t ev_step = nullptr;
+    int regen_idle_after = -1;   // ROGUE_GYM_HIP_KEEP_SPARES with fixed seeds only: > 0 = that many more k_regen launches (after creation / rg_seed), 0 = none needed, -1 = off
     bool regen_pending = false;  // a k_regen launch is due and hangs behind the next observation pass (rg_step_prefix)
     int device = 0;
     hipStream_t stream = nullptr;
@@ -220,6 +221,7 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
     if (ok && h->cfg.n_enemies > 0 && h->cfg.width > 32 && h->cfg.width <= 96 && hw <= 4096)
         ok = dev_alloc(h, &S.dc_walk, n * RG_DIST_SLOTS * h->cfg.height * ((h->cfg.width + 31) / 32));
     S.full_bfs = getenv("ROGUE_GYM_HIP_FULL_BFS") != nullptr;
+    S.keep_spares = getenv("ROGUE_GYM_HIP_KEEP_SPARES") != nullptr;
     S.err_any = h->d_err;
     if (ok && !h->range_lo.empty()) {
         ok = dev_alloc(h, &S.range_lo, 2 * n) && dev_alloc(h, &S.range_span, 2 * n) &&
@@ -270,6 +272,9 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
         e = hipGetLastError();
         if (e == hipSuccess && !getenv("ROGUE_GYM_HIP_ASYNC_FIRST_SPARES")) e = hipStreamSynchronize(h->side);  // (knob: the round-1 behaviour, for A/B evidence)
         if (e != hipSuccess) { g_create_err = std::string("k_regen: ") + hipGetErrorString(e); free_all(h); delete h; return 1; }
+        bool all_fixed = true;
+        for (uint8_t m : h->reseed) all_fixed = all_fixed && m == 0;
+        if (h->S.keep_spares && all_fixed) h->regen_idle_after = 1;  // kept spares are never consumed: one more launch (if the first one ran in the background), then none
     }
     *out = h;
     return 0;
@@ -452,6 +457,7 @@ int rg_seed(rg_t *h, const uint64_t *seed_lo, const uint64_t *seed_hi, int n) {
         // A k_regen in flight may be about to publish one of them, so the side stream is drained first; the main stream is not.
         HIPCHK(h, hipStreamSynchronize(h->side));
         HIPCHK(h, hipMemsetAsync(h->S.sp_ready, 0, (size_t)n * 4, h->stream));
+        if (h->regen_idle_after >= 0) h->regen_idle_after = 2;  // rebuild the dropped spares, then idle again
     }
     return upload_seeds(h, (size_t)n);  // only the touched prefix travels; the seeds of `seed: None` envs are derived on the device and never read back
 }
@@ -519,6 +525,7 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
     h->step_count++;
     static const bool after_obs = getenv("ROGUE_GYM_HIP_REGEN_AFTER_STEP") == nullptr;  // (A/B knob: the launch behind k_step itself)
     bool regen = h->spares && (regen_every <= 1 || h->step_count % (uint64_t)regen_every == 0);
+    if (regen && h->regen_idle_after >= 0) { if (h->regen_idle_after == 0) regen = false; else h->regen_idle_after--; }
     if (after_obs && h->spares) {
         const bool overdue = h->regen_pending;  // no observation pass since it became due: launch it behind this step after all
         h->regen_pending = regen && !overdue;

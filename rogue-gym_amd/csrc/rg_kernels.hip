@@ -2243,7 +2243,9 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
         }
     }
     __syncthreads();  // every lane's reads of the spares are complete (vmcnt drained) ...
-    if (taken) __hip_atomic_store(&S.sp_ready[e], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // ... before k_regen may refill them
+    // ... before k_regen may refill them.  (ROGUE_GYM_HIP_KEEP_SPARES: an env with a fixed seed rebuilds the SAME level-1 state at every reset --
+    // GameConfig::build is a pure function of config and seed, core/src/lib.rs:193-228 -- so its spare stays valid and is left in place.)
+    if (taken && !(S.keep_spares && S.reseed[e] == 0)) __hip_atomic_store(&S.sp_ready[e], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One wave's share of a step: lane i plays the key of env `e` (any env index -- the lanes of a wave need not hold consecutive envs), `valid`

@@ -91,6 +91,7 @@ struct RgState {
     // bit s of dc_own = its walkable mask was saved into dc_walk when the level's cells were about to change
     uint16_t *dc_part, *dc_own;  // [n]
     uint32_t *dc_walk;           // [n][RG_DIST_SLOTS][H][(W + 31) / 32] or null
+    int keep_spares;             // ROGUE_GYM_HIP_KEEP_SPARES=1: the spare of a FIXED-seed env is not consumed by a reset (its level-1 state is a pure function of config and seed)
     int full_bfs;                // ROGUE_GYM_HIP_FULL_BFS=1: every map is expanded to the end (the A side of tests/test_gpu_features.py::test_partial_dist_maps_*)
     // optional in-kernel phase profile (development aid): [2][32] u64 = {max cycles, sum cycles} per phase, NULL = off
     unsigned long long *prof;

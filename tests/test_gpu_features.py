@@ -790,3 +790,47 @@ def test_quickstart_example_runs():
     r = subprocess.run([sys.executable, os.path.join(root, "examples", "quickstart.py")], cwd=root, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "RogueEnv: obs (19, 16, 32)" in r.stdout and "ParallelRogueEnv: 1024 envs" in r.stdout and "M env-steps/s" in r.stdout, r.stdout[-1500:]
+
+
+def test_kept_spares_give_identical_episodes(goldens):
+    """ROGUE_GYM_HIP_KEEP_SPARES=1: the spare level-1 state of an env with a FIXED seed is left in place by a reset (GameConfig::build is a pure
+    function of config and seed, core/src/lib.rs:193-228) instead of being consumed and generated again.  Same envs and keys through a handle with
+    and one without the knob, short episodes (many resets): mirrors after every step, internal state of sampled envs; the kept side takes a spare
+    at every reset and generates none inline after the first build.  Envs with `seed: None` keep consuming theirs."""
+    import os
+    from rogue_gym_python import _rogue_gym as inner
+
+    cfg = goldens["configs"]["mini"]
+    n, steps = 4096, 400
+    cfgs = [json.dumps(dict(cfg, seed=50000 + i)) for i in range(n)]
+    plain = inner._Handle(cfgs, 30, auto_reset=True)
+    os.environ["ROGUE_GYM_HIP_KEEP_SPARES"] = "1"
+    try:
+        kept = inner._Handle(cfgs, 30, auto_reset=True)
+        fresh = inner._Handle([json.dumps({k: v for k, v in cfg.items() if k != "seed"})] * 256, 30, auto_reset=True)  # seed: None -> consumed as ever
+    finally:
+        del os.environ["ROGUE_GYM_HIP_KEEP_SPARES"]
+    rng = np.random.RandomState(8)
+    table = np.frombuffer(b"hjklyubn>s.HJKL", np.uint8)
+    starts = {}
+    for t in range(steps):
+        keys = np.ascontiguousarray(table[rng.randint(0, len(table), n)])
+        for h in (plain, kept):
+            h.check(h.L.rg_step(h.h, keys.ctypes.data, 0))
+        fresh.check(fresh.L.rg_step(fresh.h, np.ascontiguousarray(keys[:256]).ctypes.data, 0))
+        fscr, _, _, ffl = fresh.fetch()
+        for i in np.nonzero(ffl & 1)[0]:  # is_terminal: the mirror shows the state after the auto-reset
+            starts.setdefault(int(i), set()).add(hashlib.sha1(fscr[i].tobytes()).hexdigest())
+        for x, y, what in zip(plain.fetch(), kept.fetch(), ("screen", "hist", "status", "flags")):
+            assert np.array_equal(x, y), "t=%d: %s differs" % (t, what)
+        if t % 100 == 99:
+            for i in range(0, n, 111):
+                assert _debug_tuple(plain, i) == _debug_tuple(kept, i), "t=%d env %d" % (t, i)
+    cp, ck, cf = (C.c_uint64 * 8)(), (C.c_uint64 * 8)(), (C.c_uint64 * 8)()
+    for h, c in ((plain, cp), (kept, ck), (fresh, cf)):
+        h.check(h.L.rg_counters(h.h, c, 0))
+    assert ck[0] == cp[0] > 10 * n and ck[4] == ck[0] and ck[3] == ck[1], (list(cp), list(ck))  # every reset took its spare; inline generations = descents only
+    # seed None: every episode starts in a dungeon of its own (ten resets per env here: all different start screens for nearly every env)
+    assert cf[0] > 2000 and len(starts) == 256 and sum(len(v) >= 8 for v in starts.values()) >= 250, (list(cf), sorted(len(v) for v in starts.values())[:10])
+    for h in (plain, kept, fresh):
+        h.close()
