@@ -361,7 +361,7 @@ def main():
         import threading
 
         rec = env._h.L.rg_compact_record_bytes(env._h.h, 0)
-        payload = ("one all-gather per step of %d-byte records (u8 screen [%d,%d] + i32 status [10]) = %.1f MB per rank, expanded to f32 [N,%d,%d,%d] "
+        payload = ("one all-gather per step of %d-byte records (u8 screen [%d,%d] + i32 status [10] + f32 reward + u32 flags) = %.1f MB per rank, expanded to f32 [N,%d,%d,%d] "
                    "on every rank by rg_expand_compact" % (rec, env.height, env.width, rec * n / 1e6, env.channels, env.height, env.width))
         gather = {"unit": "env-steps/s", "payload": payload,
                   "process_groups": {"control": "gloo: barrier + max over ranks (CPU scalars)",

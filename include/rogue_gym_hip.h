@@ -151,10 +151,18 @@ int rg_host_alloc(size_t bytes, void **out);
 void rg_host_free(void *p);
 
 /* Multi-GPU: the ONE per-step collective gathers a compact record per env instead of the f32 observation.
- * rg_pack_compact writes u8 [n_env][rg_compact_record_bytes] = {screen u8[H*W], status i32[10], hist u8[H*W] if with_hist} into out_dev
- * (flushes the pending render first); after the all-gather, the consumer expands any number of records with rg_expand_compact into
- * out_dev = f32 [n][C][H][W] -- PlayerState::{gray,symbol}_image[_with_hist] (python/src/lib.rs:72-111; symbol.rs:51-71) from the packed
- * bytes.  H*W must be divisible by 4. */
+ * rg_pack_compact writes u8 [n_env][rg_compact_record_bytes] = {screen u8[H*W], status i32[10], reward f32, flags u32, hist u8[H*W] if
+ * with_hist} into out_dev (flushes the pending render first) -- everything ThreadConductor::step returns per env in one reply, state AND
+ * terminal flag (python/src/thread_impls.rs:61-81; parallel.py:59-64 derives reward and done from it): `reward` is the step's gold delta,
+ * `flags` the public RG_FLAG_* bits (TERMINAL = done, DEAD, message bits 8..14, error bits; the mirror bookkeeping bits are masked out).
+ * After the all-gather, the consumer expands any number of records with rg_expand_compact into out_dev = f32 [n][C][H][W] --
+ * PlayerState::{gray,symbol}_image[_with_hist] (python/src/lib.rs:72-111; symbol.rs:51-71) from the packed bytes -- and reads reward / flags
+ * at RG_COMPACT_REWARD_OFFSET(H*W) / RG_COMPACT_FLAGS_OFFSET(H*W) of every record.  H*W must be divisible by 4. */
+#define RG_COMPACT_FIXED_BYTES 48                       /* status i32[10] + reward f32 + flags u32 */
+#define RG_COMPACT_STATUS_OFFSET(hw) (hw)
+#define RG_COMPACT_REWARD_OFFSET(hw) ((hw) + 40)
+#define RG_COMPACT_FLAGS_OFFSET(hw) ((hw) + 44)
+#define RG_COMPACT_HIST_OFFSET(hw) ((hw) + RG_COMPACT_FIXED_BYTES)
 int rg_compact_record_bytes(const rg_t *h, int with_hist);
 int rg_pack_compact(rg_t *h, int with_hist, uint8_t *out_dev);
 /* The collective itself ("exactly one per step: ncclAllGather (RCCL over xGMI) of the obs slice, in place into rank-ordered

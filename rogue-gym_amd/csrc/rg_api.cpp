@@ -3,7 +3,6 @@
 // fallback: without a HIP device every entry point that needs one fails loudly.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +14,18 @@
 
 #include "../../include/rogue_gym_hip.h"
 #include "rg_state.h"
+
+// The few RCCL declarations this file needs, spelled out: librccl is bound with dlopen at run time, so building the single-GPU library must not
+// need the RCCL development headers either.  (ABI of nccl.h / rccl.h 2.x: ncclUniqueId = 128 opaque bytes passed by value, ncclComm_t an opaque
+// pointer, ncclSuccess = 0, ncclUint8 = 1.)
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+}
+static const ncclResult_t ncclSuccess = 0;
+static const ncclDataType_t ncclUint8 = 1;
 
 extern "C" {
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st);
@@ -29,6 +40,7 @@ void rgk_pack(const RgState *S, int with_hist, uint8_t *out, hipStream_t st);
 void rgk_scatter_rows(const void *src, void *dst, const int32_t *ext, int n, int row_bytes, hipStream_t st);
 void rgk_gather_keys(const uint8_t *keys, const int32_t *ext, uint8_t *dst, int n, hipStream_t st);
 int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, int planes_sym, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+int rgk_step_epw(int n);
 }
 
 struct rg_handle {
@@ -218,8 +230,8 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
               dev_alloc(h, &h->d_err, 4) && dev_alloc(h, &h->d_keys, n);
     ok = ok && dev_alloc(h, &S.sp_ready, n) && dev_alloc(h, &h->d_probe, 4);
     // the grid class whose dist maps may be partial (rg_kernels.hip bfs_rows_n32): one saved walkable mask per map
-    if (ok && h->cfg.n_enemies > 0 && h->cfg.width > 32 && h->cfg.width <= 96 && hw <= 4096)
-        ok = dev_alloc(h, &S.dc_walk, n * RG_DIST_SLOTS * h->cfg.height * ((h->cfg.width + 31) / 32));
+    if (ok && h->cfg.n_enemies > 0 && RG_PARTIAL_MAPS(h->cfg.width, h->cfg.height, (int)nr))
+        ok = dev_alloc(h, &S.dc_walk, n * RG_DIST_SLOTS * h->cfg.height * RG_WALK_WORDS(h->cfg.width));
     S.full_bfs = getenv("ROGUE_GYM_HIP_FULL_BFS") != nullptr;
     S.keep_spares = getenv("ROGUE_GYM_HIP_KEEP_SPARES") != nullptr;
     S.err_any = h->d_err;
@@ -286,6 +298,7 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
 #define SUBCHK(h, sh, call) do { if (call) { (h)->err = (sh)->err; return 1; } } while (0)
 
 static void destroy_handle(rg_handle *h);
+static int comm_release(rg_handle *h, bool teardown);
 
 // status / flags / reward / done of every group -> the parent's arrays in env order (44 + 5 bytes per env); after every step and reset, so that
 // device pointers handed out once (rg_reward, rg_done, rg_status ...) stay current
@@ -390,7 +403,7 @@ static void destroy_handle(rg_handle *h) {
     for (rg_handle *sh : h->sub) destroy_handle(sh);
     h->sub.clear();
     (void)hipStreamSynchronize(h->stream);
-    if (h->comm) (void)rg_comm_destroy(h);
+    if (h->comm) (void)comm_release(h, true);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->ev_step) (void)hipEventDestroy(h->ev_step);
     for (int k = 0; k < 4; k++) for (auto &e : h->ev[k]) (void)hipEventDestroy(e);
@@ -532,8 +545,8 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
         regen = overdue;
     }
     hipEvent_t done_ev = nullptr;
+    static const bool no_stair_waves = getenv("ROGUE_GYM_HIP_NO_STAIR_WAVES") != nullptr;
     {   // stair isolation (rg_kernels.hip, k_step): on unless ROGUE_GYM_HIP_NO_STAIR_WAVES is set (the A/B knob of DESIGN.md's measurement)
-        static const bool no_stair_waves = getenv("ROGUE_GYM_HIP_NO_STAIR_WAVES") != nullptr;
         TimedLaunch t(h, 0, true);
         h->S.stair_gen = h->stair_gen++;  // reads the stair set its predecessor produced, produces the next one
         done_ev = t.stop_ev() ? t.stop_ev() : ((regen && !marker_event) ? h->ev_step : nullptr);
@@ -762,7 +775,7 @@ int rg_host_alloc(size_t bytes, void **out) {
 }
 void rg_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
-int rg_compact_record_bytes(const rg_t *h, int with_hist) { return h->S.hw + 40 + (with_hist ? h->S.hw : 0); }
+int rg_compact_record_bytes(const rg_t *h, int with_hist) { return h->S.hw + RG_COMPACT_FIXED_BYTES + (with_hist ? h->S.hw : 0); }
 
 int rg_pack_compact(rg_t *h, int with_hist, uint8_t *out_dev) {
     if (refuse_mixed(h, "rg_pack_compact")) return 1;
@@ -786,6 +799,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
 };
@@ -803,6 +817,7 @@ Rccl *rccl() {
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.lib, "ncclCommAbort"));
         if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString) r.err = "librccl lacks an expected symbol";
     });
     return &r;
@@ -834,15 +849,18 @@ int rg_comm_init(rg_t *h, const uint8_t id[128], int rank, int world) {
     return 0;
 }
 
-int rg_comm_destroy(rg_t *h) {
+// teardown (rg_destroy): ncclCommAbort where the library has it -- ncclCommDestroy may block when peer ranks have already exited
+static int comm_release(rg_handle *h, bool teardown) {
     if (!h->comm) return 0;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    ncclResult_t e = rccl()->CommDestroy(h->comm);
+    Rccl *r = rccl();
+    ncclResult_t e = (teardown && r->CommAbort) ? r->CommAbort(h->comm) : r->CommDestroy(h->comm);
     h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0;
-    if (e != ncclSuccess) { h->err = std::string("ncclCommDestroy: ") + rccl()->GetErrorString(e); return 1; }
+    if (e != ncclSuccess) { h->err = std::string("ncclCommDestroy: ") + r->GetErrorString(e); return 1; }
     return 0;
 }
+int rg_comm_destroy(rg_t *h) { return comm_release(h, false); }
 
 int rg_allgather_compact(rg_t *h, int with_hist, uint8_t *out_dev) {
     if (!h->comm) { h->err = "rg_allgather_compact: no communicator (rg_comm_init first)"; return 1; }
@@ -861,8 +879,8 @@ int rg_expand_compact(rg_t *h, const uint8_t *packed_dev, int n, int packed_has_
     HIPCHK(h, hipSetDevice(h->device));
     if (h->S.hw & 3) { h->err = "rg_expand_compact needs H*W divisible by 4"; return 1; }
     if (with_hist && !packed_has_hist) { h->err = "rg_expand_compact: the packed batch carries no history plane"; return 1; }
-    const size_t hw = (size_t)h->S.hw, rec = hw + 40 + (packed_has_hist ? hw : 0);
-    rgk_encode(packed_dev, packed_dev + hw + 40, reinterpret_cast<const int32_t *>(packed_dev + hw), nullptr, h->d_err, n, (int)hw, rec, rec / 4, h->cfg.symbols,
+    const size_t hw = (size_t)h->S.hw, rec = hw + RG_COMPACT_FIXED_BYTES + (packed_has_hist ? hw : 0);
+    rgk_encode(packed_dev, packed_dev + RG_COMPACT_HIST_OFFSET(hw), reinterpret_cast<const int32_t *>(packed_dev + RG_COMPACT_STATUS_OFFSET(hw)), nullptr, h->d_err, n, (int)hw, rec, rec / 4, h->cfg.symbols,
                h->cfg.symbols, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, nullptr, h->stream);
     HIPCHK(h, hipGetLastError());
     return 0;

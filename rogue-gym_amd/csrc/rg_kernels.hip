@@ -1685,7 +1685,7 @@ __device__ __forceinline__ void snapshot_walk_service(const RgState &S, const Rg
     if (want) todo = (uint32_t)S.dc_part[e] & ~(uint32_t)S.dc_own[e];
     uint64_t m = __ballot(todo != 0);
     if (!m) return;
-    const int W = c.width, H = c.height, wpr = (W + 31) >> 5;
+    const int W = c.width, H = c.height, wpr = RG_WALK_WORDS(W);  // = the WN of the step class that reads it back (bfs_rows_n32)
     while (m) {
         const int src = __ffsll((long long)m) - 1;
         m &= m - 1;
@@ -2341,7 +2341,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         const bool regenerated = descends && pass == 0;
         if constexpr (BW == 1 || BW == 2) { if (pass == 0 && S.dc_walk) snapshot_walk_service(S, c, lane, e, descends); }
         if (need_gen) n_inline++;
-        gen_service<GM>(S, c, E, lane, e, need_gen, pass == 1, lds_grid, pf);  // W <= 32: at most 12 rooms; the wider instances carry the 64-room generator
+        gen_service<GM>(S, c, E, lane, e, need_gen, pass == 1, lds_grid, pf);  // k_step_w32 carries the 32-room generator (rgk_step routes by room count too), the wider instances the 64-room one
         (void)regenerated;  // (a descended lane's monster-cache column was refilled by gen_service from the generator's own table)
         pf.mark(2);
         need_gen = false;
@@ -2564,22 +2564,27 @@ void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
     default: hipLaunchKernelGGL(k_build<2>, grid, dim3(WAVE), smem, st, *S, *c);
     }
 }
+// envs per index-order wave of k_step: the register footprint allows one or two step waves per
+// SIMD (1024-2048 on the chip); a batch below 64 x 1024 envs is spread over more, emptier waves (less divergence per wave, no idle SIMDs).  More
+// waves than SIMDs never pays: a wave's cost is the union of its lanes' paths.
+int rgk_step_epw(int n) {
+    static const int epw_env = getenv("ROGUE_GYM_HIP_EPW") ? atoi(getenv("ROGUE_GYM_HIP_EPW")) : 0;
+    int epw = WAVE;
+    while (epw > 16 && (n + epw - 1) / epw < 1024) epw >>= 1;
+    if (epw_env >= 16 && epw_env <= 64) epw = epw_env;  // (>= 16: S.stats has one row per block of the largest grid, STAIR_BLOCKS + ceil(n / 16); rg_api.cpp)
+    return epw;
+}
 void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw, c->room_num_x * c->room_num_y);  // the generator's staging grid + tables (inline descents, spare misses), shared with ...
     const bool n32 = c->width <= 96 && hw <= 4096;  // BFS rows as 32-bit words in registers (bfs_rows_n32): no LDS planes
-    const size_t bfs_hi = (c->width <= 32 || n32) ? 0 : (size_t)10 * ((c->width + 63) / 64) * WAVE * 8;  // ... the BFS high distance planes
+    const size_t bfs_hi = n32 ? 0 : (size_t)10 * ((c->width + 63) / 64) * WAVE * 8;  // ... the BFS high distance planes
     if (bfs_hi > smem) smem = bfs_hi;
     smem = (smem + 15) & ~(size_t)15;
     int mc_offset = (int)smem;
     smem += (size_t)c->room_num_x * c->room_num_y * WAVE * 4;  // LDS monster cache
     smem += 25 * WAVE * 2;                                     // ... and the lanes' 5x5 tile windows
-    // envs per wave: the register footprint allows one step wave per SIMD (1024 on the chip); a batch below 64 x 1024 envs is spread over more,
-    // emptier waves (less divergence per wave, no idle SIMDs).  More waves than SIMDs never pays: a wave's cost is the union of its lanes' paths.
-    static const int epw_env = getenv("ROGUE_GYM_HIP_EPW") ? atoi(getenv("ROGUE_GYM_HIP_EPW")) : 0;
-    int epw = WAVE;
-    while (epw > 16 && (S->n + epw - 1) / epw < 1024) epw >>= 1;
-    if (epw_env >= 16 && epw_env <= 64) epw = epw_env;  // (>= 16: S.stats has one row per block of the largest grid, STAIR_BLOCKS + ceil(n / 16); rg_api.cpp)
+    const int epw = rgk_step_epw(S->n);
     // parity >= 0: stair isolation with the list the last render / observation pass wrote into set `parity`
     const int nb = (S->n + epw - 1) / epw;
     const dim3 grid(parity >= 0 ? STAIR_BLOCKS + nb : nb), block(WAVE);
@@ -2588,11 +2593,16 @@ void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const 
                                else hipLaunchKernelGGL(K, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity); } while (0)
     if (gen_mode_of(c) == 2) {
         // the LDS monster table of a > 64-room dungeon (256 B per room and wave) goes beyond the 64 KB a kernel gets by default: raise the kernel's limit once
-        static size_t raised = 0;
-        if (smem > raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_huge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); raised = smem; }
+        // (the attribute is per DEVICE: a process may hold handles on several; a failure stays in hipGetLastError, which rg_step_prefix checks right after)
+        static size_t raised[64] = {0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || smem > raised[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_huge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess && dev >= 0 && dev < 64) raised[dev] = smem;
+        }
         RG_LAUNCH_STEP(k_step_huge);
-    } else if (c->width <= 32) RG_LAUNCH_STEP(k_step_w32);
-    else if (n32 && c->width <= 64) RG_LAUNCH_STEP(k_step<1>);
+    } else if (c->width <= 32 && gen_mode_of(c) == 0) RG_LAUNCH_STEP(k_step_w32);   // (its generator instance holds 32-bit room sets)
+    else if (n32 && c->width <= 64) RG_LAUNCH_STEP(k_step<1>);                        // ... a 32-column grid with 33..64 rooms (e.g. 32x48 with 8x5) steps here
     else if (n32) RG_LAUNCH_STEP(k_step<2>);
     else if (c->width <= 128) RG_LAUNCH_STEP(k_step<3>);
     else RG_LAUNCH_STEP(k_step<4>);

@@ -376,17 +376,23 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
     }
 }
 
-// one 4-byte word of the compact record per thread (hw % 4 == 0: every record section is word-aligned)
-__global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status, int n, int hw,
-                                              int with_hist, uint32_t *__restrict__ out) {
-    const int qs = hw >> 2, qr = qs + 10 + (with_hist ? qs : 0);
+// one 4-byte word of the compact record per thread (hw % 4 == 0: every record section is word-aligned).  Record = {screen u8[hw], status i32[10],
+// reward f32, flags u32 (the public bits: terminal, dead, message flags, error bits -- not the mirror bookkeeping), hist u8[hw] if with_hist}:
+// everything ThreadConductor::step hands back per env in one reply (state AND terminal flag, python/src/thread_impls.rs:61-81; parallel.py:59-64
+// derives reward and done from exactly that), so the one collective of the sharded path carries the learner's whole step
+#define RG_PUBLIC_FLAGS (RG_FLAG_TERMINAL | RG_FLAG_DEAD | RG_FLAG_MSG_MASK | RG_FLAG_ERR_MASK)
+__global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ screen, const uint8_t *__restrict__ hist, const int32_t *__restrict__ status,
+                                              const float *__restrict__ reward, const uint32_t *__restrict__ flags, int n, int hw, int with_hist, uint32_t *__restrict__ out) {
+    const int qs = hw >> 2, qr = qs + 12 + (with_hist ? qs : 0);
     const size_t total = (size_t)n * qr;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
         const int e = (int)(g / qr), i = (int)(g - (size_t)e * qr);
         uint32_t v;
         if (i < qs) v = reinterpret_cast<const uint32_t *>(screen + (size_t)e * hw)[i];
         else if (i < qs + 10) v = (uint32_t)status[(size_t)e * 10 + (i - qs)];
-        else v = reinterpret_cast<const uint32_t *>(hist + (size_t)e * hw)[i - qs - 10];
+        else if (i == qs + 10) v = __float_as_uint(reward[e]);
+        else if (i == qs + 11) v = flags[e] & RG_PUBLIC_FLAGS;
+        else v = reinterpret_cast<const uint32_t *>(hist + (size_t)e * hw)[i - qs - 12];
         out[g] = v;
     }
 }
@@ -488,15 +494,15 @@ void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *statu
         hipLaunchKernelGGL(k_encode_scalar, dim3(blocks), dim3(256), 0, st, screen, hist, status, flags, err_any, n, hw, rs, rst, symbols, planes_sym, sflag, with_hist, kind, out, ext);
     }
 }
-// compact observation record of every env: {screen u8[hw], status i32[10], hist u8[hw] (optional)}, back to back -- the payload of the ONE
+// compact record of every env: {screen u8[hw], status i32[10], reward f32, flags u32, hist u8[hw] (optional)}, back to back -- the payload of the ONE
 // all-gather per step of the multi-GPU path; expanded on the consumer by rgk_encode with rs = record size
 void rgk_pack(const RgState *S, int with_hist, uint8_t *out, hipStream_t st) {
     const int hw = S->hw;
-    const size_t rec = (size_t)hw + 40 + (with_hist ? hw : 0);
+    const size_t rec = (size_t)hw + RG_COMPACT_FIXED_BYTES + (with_hist ? hw : 0);
     const size_t total = (size_t)S->n * (rec / 4);
     int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, st, S->screen, S->hist, S->status, S->n, hw, with_hist, reinterpret_cast<uint32_t *>(out));
+    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, st, S->screen, S->hist, S->status, S->reward, S->flags, S->n, hw, with_hist, reinterpret_cast<uint32_t *>(out));
 }
 // handle with several config groups: rows of a group's array -> the handle's array at the group's env indices (row_words 4-byte words per env)
 void rgk_scatter_rows(const void *src, void *dst, const int32_t *ext, int n, int row_bytes, hipStream_t st) {

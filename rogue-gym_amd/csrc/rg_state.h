@@ -45,6 +45,10 @@ enum { RK_NORMAL = 0, RK_MAZE = 1, RK_EMPTY = 2 };
 // Every connect_2rooms call joins a pair of grid-adjacent rooms that was not joined before (dig_passges excludes joined pairs, passages.rs:33-66),
 // so a level has at most rnx*(rny-1) + rny*(rnx-1) < 2 * rooms corridors whatever max_extra_edges says.
 #define RG_MAX_EDGES (2 * RG_MAX_ROOMS)   // (the tables are allocated per config: 2 x its rooms)
+// words per grid row of a saved walkable mask (dc_walk) = the row words of the step class that builds partial maps (rg_kernels.hip bfs_rows_n32<2|3>)
+#define RG_WALK_WORDS(w) ((w) <= 64 ? 2 : 3)
+// ... and which configs step in that class: rows of <= 96 columns with H * W <= 4096, except the 32-column grids of <= 32 rooms (k_step_w32: whole maps)
+#define RG_PARTIAL_MAPS(w, h, rooms) ((w) <= 96 && (w) * (h) <= 4096 && (rooms) <= 64 && !((w) <= 32 && (rooms) <= 32))
 
 struct RgState {
     int32_t n;          // environments on this device
@@ -90,7 +94,7 @@ struct RgState {
     // partial maps (grids of 33..96 columns, rg_kernels.hip bfs_rows_n32): bit s of dc_part = slot s holds a map that was not expanded to the end;
     // bit s of dc_own = its walkable mask was saved into dc_walk when the level's cells were about to change
     uint16_t *dc_part, *dc_own;  // [n]
-    uint32_t *dc_walk;           // [n][RG_DIST_SLOTS][H][(W + 31) / 32] or null
+    uint32_t *dc_walk;           // [n][RG_DIST_SLOTS][H][RG_WALK_WORDS(W)] or null
     int keep_spares;             // ROGUE_GYM_HIP_KEEP_SPARES=1: the spare of a FIXED-seed env is not consumed by a reset (its level-1 state is a pure function of config and seed)
     int full_bfs;                // ROGUE_GYM_HIP_FULL_BFS=1: every map is expanded to the end (the A side of tests/test_gpu_features.py::test_partial_dist_maps_*)
     // optional in-kernel phase profile (development aid): [2][32] u64 = {max cycles, sum cycles} per phase, NULL = off

@@ -167,7 +167,7 @@ class HipVecRogueEnv:
     def all_gather_obs(self, compact: bool = True):
         """Whole-job observation batch f32 [world * num_envs, C, H, W] on every rank, env order = rank order -- the same type whatever the
         world size (world 1: this rank's own `obs`).  compact=True (default): ONE RCCL all-gather over xGMI of the packed records
-        (552 B per mini env instead of 2 KB .. 330 KB of f32), expanded on the consumer GPU by the HIP encode kernels -- through the
+        (560 B per mini env instead of 2 KB .. 330 KB of f32), expanded on the consumer GPU by the HIP encode kernels -- through the
         handle's own communicator when init_comm() was called (the C-ABI path), else through torch.distributed;
         compact=False gathers the f32 observation itself (xGMI-bound for the one-hot image)."""
         import torch.distributed as dist
@@ -189,6 +189,24 @@ class HipVecRogueEnv:
         with_hist = bool(self.image_setting.includes_hist)
         gathered = all_gather_packed(self.packed_records(with_hist), group=group)
         return self.expand_records(gathered, packed_has_hist=with_hist)
+
+    def all_gather_step(self):
+        """(obs, reward, done, flags) of the WHOLE job on every rank from the ONE collective of the step: obs f32 [world * num_envs, C, H, W],
+        reward f32 [N], done bool [N], flags i32 [N] (public RG_FLAG_* bits), env order = rank order.  ThreadConductor::step returns state and
+        terminal flag of every env in one reply (python/src/thread_impls.rs:61-81) and parallel.py:59-64 derives reward and done from it; here the
+        compact record carries them next to the screen, so a learner that wants the all-gathered batch needs no second collective."""
+        import torch.distributed as dist
+        from .sharding import all_gather_packed, unpack_step
+
+        with_hist = bool(self.image_setting.includes_hist)
+        if getattr(self, "_comm", None) is not None:
+            packed = self.all_gather_records(with_hist)
+        else:
+            packed = self.packed_records(with_hist)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(getattr(self, "process_group", None)) > 1:
+                packed = all_gather_packed(packed, group=getattr(self, "process_group", None))
+        reward, done, flags = unpack_step(packed, self.height, self.width, with_hist)
+        return self.expand_records(packed, packed_has_hist=with_hist), reward, done, flags
 
     def all_gather_compact(self, with_hist: bool = False):
         """The gathered records themselves, as views: (screen u8 [N,H,W], status i32 [N,10], hist u8 [N,H,W] or None)."""

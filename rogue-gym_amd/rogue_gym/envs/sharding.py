@@ -1,6 +1,7 @@
 """Env sharding across ranks: rank r owns the contiguous block of env indices
-[r*N/P, (r+1)*N/P); the only exchange is ONE optional all-gather per step of the compact observation records
-(u8 screen + i32 status (+ u8 history) per env, packed by rg_pack_compact), expanded to f32 images on the consumer GPU by the HIP
+[r*N/P, (r+1)*N/P); the only exchange is ONE optional all-gather per step of the compact records
+(u8 screen + i32 status + f32 reward + u32 flags (+ u8 history) per env, packed by rg_pack_compact) -- everything ThreadConductor::step returns
+per env in one reply, state and terminal flag (python/src/thread_impls.rs:61-81) -- expanded to f32 images on the consumer GPU by the HIP
 encode kernels (rg_expand_compact)."""
 from typing import Tuple
 
@@ -11,10 +12,14 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return (n_total * rank) // world, (n_total * (rank + 1)) // world
 
 
+FIXED_BYTES = 48        # status i32[10] + reward f32 + flags u32 (RG_COMPACT_FIXED_BYTES)
+FLAG_TERMINAL = 0x1     # RG_FLAG_TERMINAL: the last key ended the episode (PlayerState.is_terminal)
+
+
 def record_layout(height: int, width: int, with_hist: bool = False):
-    """Byte offsets inside one compact record: (screen, status, hist or None, record size)."""
+    """Byte offsets inside one compact record: (screen, status, hist or None, record size); reward / flags sit at status + 40 / + 44."""
     hw = height * width
-    return 0, hw, (hw + 40 if with_hist else None), hw + 40 + (hw if with_hist else 0)
+    return 0, hw, (hw + FIXED_BYTES if with_hist else None), hw + FIXED_BYTES + (hw if with_hist else 0)
 
 
 def all_gather_packed(packed, group=None):
@@ -40,3 +45,17 @@ def unpack_records(packed, height: int, width: int, with_hist: bool = False):
     status = flat[:, o_st:o_st + 40].contiguous().view(torch.int32).reshape(n, 10)
     hist = flat[:, o_hist:o_hist + height * width].reshape(n, height, width) if with_hist else None
     return screen, status, hist
+
+
+def unpack_step(packed, height: int, width: int, with_hist: bool = False):
+    """The step half of a gathered batch of records: (reward f32 [N], done bool [N], flags i32 [N]) -- what parallel.py:59-64 derives from the
+    states ParallelGameState::step returns, for the WHOLE job on every rank.  flags: the public RG_FLAG_* bits (terminal, dead, message bits
+    8..14, error bits)."""
+    import torch
+
+    _, o_st, _, rec = record_layout(height, width, with_hist)
+    n = packed.shape[0]
+    tail = packed.reshape(n, rec)[:, o_st + 40:o_st + 48].contiguous()
+    reward = tail[:, 0:4].contiguous().view(torch.float32).reshape(n)
+    flags = tail[:, 4:8].contiguous().view(torch.int32).reshape(n)
+    return reward, (flags & FLAG_TERMINAL) != 0, flags

@@ -311,6 +311,7 @@ class _Handle:
 
 
 _LAZY_MIN_BYTES = 1 << 20   # batches with at least this many screen bytes keep their screens on the device until they are looked at
+_LAZY_MAX_BYTES = 1 << 30   # device bytes all not-yet-read snapshots of a handle may pin together (65 536 mini envs: 8 batches); older ones move to the host
 _IMAGE_BATCH_LIMIT = 1 << 28  # bytes: above this a batch does not cache whole-batch images (one-hot images of large batches are GBs)
 
 
@@ -347,6 +348,17 @@ class StateBatch:
             handle.check(handle.L.rg_fetch_states(handle.h, None, None, self.status.ctypes.data, self.flags.ctypes.data))  # (synchronises the stream)
             key, lazy = id(self), handle.lazy
             lazy[key] = weakref.ref(self, lambda _r, key=key, lazy=lazy: lazy.pop(key, None))
+            # Every lazy batch pins 2 * n * H * W bytes of HBM until it is collected or looked at: a caller that keeps the states of a whole rollout
+            # (128 steps of 65 536 mini envs = 17 GB) must not exhaust the device silently.  Beyond _LAZY_MAX_BYTES the OLDEST batches get their host
+            # copies now (what every batch cost before the lazy path existed) and hand their device buffer back.
+            live = [b for b in (r() for r in list(lazy.values())) if b is not None and b._snap is not None]
+            total = sum(b._snap.nbytes for b in live)
+            for b in live:
+                if total <= _LAZY_MAX_BYTES:
+                    break
+                if b is not self:
+                    total -= b._snap.nbytes
+                    b._materialise()
         self._epoch = handle.epoch
         self._items = {}
         self._images = {}

@@ -21,6 +21,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _step(e, key):
+    """One auto-resetting step of an oracle env -> (reward, done) the way parallel.py:59-64 derives them from the returned state: the positive
+    gold delta and the terminal flag."""
+    g0 = int(e.status_arr()[1])
+    e.step_autoreset(key)
+    return float(max(0, int(e.status_arr()[1]) - g0)), e.flags()["is_terminal"]
+
+
 def _worker(rank, world, port, n_total, steps, q):
     import sys
     sys.path.insert(0, ROOT)
@@ -29,28 +37,32 @@ def _worker(rank, world, port, n_total, steps, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle.pyoracle import OracleEnv
-    from rogue_gym.envs.sharding import all_gather_packed, record_layout, shard_range, unpack_records
+    from rogue_gym.envs.sharding import all_gather_packed, record_layout, shard_range, unpack_records, unpack_step
 
     cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_goldens.json")))["configs"]["mini"]
     first, last = shard_range(n_total, rank, world)
     envs = [OracleEnv(cfg, seed=i, max_steps=20) for i in range(first, last)]
     acts = np.frombuffer(b".hjklnbuy>s", np.uint8)
     rng = np.random.RandomState(0)
+    last = [(0.0, False)] * len(envs)
     for _ in range(steps):
         keys = acts[rng.randint(0, 11, n_total)]  # same global action tensor on every rank
         for j, e in enumerate(envs):
-            e.step_autoreset(int(keys[first + j]))
-    # the record rg_pack_compact writes per env: screen bytes, status i32[10], history bytes
+            last[j] = _step(e, int(keys[first + j]))
+    # the record rg_pack_compact writes per env: screen bytes, status i32[10], reward f32, flags u32, history bytes
     o_scr, o_st, o_hist, rec = record_layout(16, 32, with_hist=True)
     packed = np.zeros((len(envs), rec), np.uint8)
     for j, e in enumerate(envs):
         packed[j, o_scr:o_st] = e.screen().reshape(-1)
         packed[j, o_st:o_st + 40] = e.status_arr().astype(np.int32).view(np.uint8)
+        packed[j, o_st + 40:o_st + 44] = np.array([last[j][0]], np.float32).view(np.uint8)
+        packed[j, o_st + 44:o_st + 48] = np.array([1 if last[j][1] else 0], np.uint32).view(np.uint8)
         packed[j, o_hist:] = e.hist().reshape(-1)
     gathered = all_gather_packed(torch.from_numpy(packed))  # ONE collective
     scr, st, hist = unpack_records(gathered, 16, 32, with_hist=True)
+    rew, done, _flags = unpack_step(gathered, 16, 32, with_hist=True)
     if rank == 0:
-        q.put((scr.numpy(), st.numpy(), hist.numpy()))
+        q.put((scr.numpy(), st.numpy(), hist.numpy(), rew.numpy(), done.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,7 +90,7 @@ def test_world2_gloo_gather_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    scr, st, hist = q.get(timeout=100)
+    scr, st, hist, rew, done = q.get(timeout=100)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -86,11 +98,14 @@ def test_world2_gloo_gather_matches_single_process():
     envs = [OracleEnv(cfg, seed=i, max_steps=20) for i in range(n_total)]
     acts = np.frombuffer(b".hjklnbuy>s", np.uint8)
     rng = np.random.RandomState(0)
+    last = [(0.0, False)] * n_total
     for _ in range(steps):
         keys = acts[rng.randint(0, 11, n_total)]
         for i, e in enumerate(envs):
-            e.step_autoreset(int(keys[i]))
+            last[i] = _step(e, int(keys[i]))
     for i, e in enumerate(envs):
         assert np.array_equal(scr[i], e.screen())
         assert np.array_equal(st[i], e.status_arr().astype(np.int32))
         assert np.array_equal(hist[i], e.hist())
+        # the step half of the ONE collective: reward and done of every env of the job (thread_impls.rs:61-81, parallel.py:59-64)
+        assert rew[i] == np.float32(last[i][0]) and bool(done[i]) == bool(last[i][1]), i

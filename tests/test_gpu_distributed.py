@@ -44,10 +44,12 @@ def _worker(rank, world, port, name, kind, n_total, steps, q):
     full = env.all_gather_obs(compact=True)     # ONE collective + HIP expand
     raw = env.all_gather_obs(compact=False)     # the f32 gather of the literal config text
     scr, status, hist = env.all_gather_compact(with_hist=True)
+    obs2, rew, done, flags = env.all_gather_step()  # the whole step of the whole job from the same ONE collective
     torch.cuda.synchronize()
     env.check_errors()
     if rank == 0:
-        q.put((full.cpu().numpy(), bool(torch.equal(full, raw)), scr.cpu().numpy(), status.cpu().numpy()))
+        q.put((full.cpu().numpy(), bool(torch.equal(full, raw)) and bool(torch.equal(full, obs2)), scr.cpu().numpy(), status.cpu().numpy(),
+               rew.cpu().numpy(), done.cpu().numpy(), flags.cpu().numpy()))
     dist.barrier()
     env.close()
     dist.destroy_process_group()
@@ -67,7 +69,7 @@ def test_world2_hip_shards_gather_to_the_single_process_batch(name, kind, n_tota
     procs = [ctx.Process(target=_worker, args=(r, world, port, name, kind, n_total, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    full, same, scr, status = q.get(timeout=240)
+    full, same, scr, status, rew, done, flags = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -81,6 +83,10 @@ def test_world2_hip_shards_gather_to_the_single_process_batch(name, kind, n_tota
     torch.cuda.synchronize()
     assert np.array_equal(full, obs.cpu().numpy())
     assert np.array_equal(scr, env.screen.cpu().numpy()) and np.array_equal(status, env.status.cpu().numpy())
+    # reward / done / message flags of every env of the job arrived with the records (thread_impls.rs:61-81; parallel.py:59-64)
+    assert np.array_equal(rew, env.reward.cpu().numpy()) and np.array_equal(done, env.done.cpu().numpy())
+    public = 0x1 | 0x2 | 0x7f00 | 0xff0000
+    assert np.array_equal(flags, env.flags.cpu().numpy() & public) and rew.max() > 0 and done.any()
     env.close()
 
 

@@ -214,19 +214,22 @@ def test_room_grids_beyond_32_rooms(goldens):
     Three generator instances: 32-bit room sets (<= 32 rooms), 64-bit (<= 64, corridor records beyond the 64th in LDS), six words + the room table
     in LDS (<= 384).  Lock step with the oracle, then deeper levels straight from the generator."""
     rng = np.random.RandomState(9)
-    cases = ((10, 4, 4, 24, 5, 100), (8, 8, 4, 16, 60, 100), (8, 4, 4, 24, 5, 60),       # 40 rooms; 64 with > 64 corridor records; exactly 32
-             (11, 6, 4, 12, 5, 60), (13, 5, 4, 12, 20, 60), (32, 8, 4, 8, 40, 50), (40, 9, 3, 8, 5, 50))   # 66, 65, 256, 360 rooms
-    for rx, ry, mr, n, extra, steps in cases:
-        cfg = {"width": 160, "height": 48, "dungeon": {"style": "rogue", "room_num_x": rx, "room_num_y": ry, "min_room_size": {"x": mr, "y": mr},
-                                                       "max_extra_edges": extra}}
+    cases = ((160, 10, 4, 4, 24, 5, 100), (160, 8, 8, 4, 16, 60, 100), (160, 8, 4, 4, 24, 5, 60),       # 40 rooms; 64 with > 64 corridor records; exactly 32
+             (160, 11, 6, 4, 12, 5, 60), (160, 13, 5, 4, 12, 20, 60), (160, 32, 8, 4, 8, 40, 50), (160, 40, 9, 3, 8, 5, 50),   # 66, 65, 256, 360 rooms
+             # 32 COLUMNS with more than 32 rooms (ADVICE r3): the capped W <= 32 step kernel carries the 32-room generator only, so these step in the
+             # next width class (64-bit room sets; partial dist maps over 2-word rows)
+             (32, 8, 5, 3, 24, 10, 120), (32, 8, 8, 3, 16, 40, 120))
+    for width, rx, ry, mr, n, extra, steps in cases:
+        cfg = {"width": width, "height": 48, "dungeon": {"style": "rogue", "room_num_x": rx, "room_num_y": ry, "min_room_size": {"x": mr, "y": mr},
+                                                         "max_extra_edges": extra}}
         keys = [ALL_KEYS[rng.randint(0, len(ALL_KEYS), n)] for _ in range(steps)]
         hip, oracles = lockstep(cfg, list(range(100 * rx, 100 * rx + n)), keys, max_steps=45, check_every=3, internal_every=20)
         # ... and the observation tensors of such a grid (the fused kernel holds 64 rooms: beyond that the unfused render + encode runs)
         img = hip.obs(0, 0x1FF, True)
         for i in (0, n - 1):
             assert np.array_equal(img[i], oracles[i].gray_image(0x1FF, True)), (rx, ry, i)
-    for rx, ry, mr in ((10, 4, 4), (13, 5, 4), (32, 8, 4)):   # deeper levels: dark rooms, mazes, locked doors, a monster in most rooms
-        cfg = {"width": 160, "height": 48, "dungeon": {"style": "rogue", "room_num_x": rx, "room_num_y": ry, "min_room_size": {"x": mr, "y": mr}}}
+    for width, rx, ry, mr in ((160, 10, 4, 4), (160, 13, 5, 4), (160, 32, 8, 4), (32, 8, 5, 3)):   # deeper levels: dark rooms, mazes, locked doors, a monster in most rooms
+        cfg = {"width": width, "height": 48, "dungeon": {"style": "rogue", "room_num_x": rx, "room_num_y": ry, "min_room_size": {"x": mr, "y": mr}}}
         seeds = list(range(12))
         hip = HipBatch(cfg, seeds)
         oracles = make_oracles(cfg, seeds)

@@ -32,6 +32,10 @@ def random_config(rng):
     ry = int(rng.randint(1, max(2, min(7, h // 5) + 1)))
     if rng.rand() < 0.08:  # many small rooms: the 64-room and 384-room generator instances
         rx, ry = max(rx, w // int(rng.randint(4, 9))), max(ry, h // int(rng.randint(5, 8)))
+    narrow_many = rng.rand() < 0.04  # 32 columns with 33..64 rooms: steps outside the capped W <= 32 kernel
+    if narrow_many:
+        w, h, rx = 32, int(rng.randint(30, 49)), 8
+        ry = h // int(rng.randint(5, 7))
     rooms = rx * ry
     d = {"style": "rogue", "room_num_x": rx, "room_num_y": ry,
          "dark_level": int(rng.choice([1, 2, 3, 5, 10, 1000])), "maze_rate_inv": int(rng.choice([1, 2, 4, 15, 1000])),
@@ -41,6 +45,8 @@ def random_config(rng):
          "door_unlock_rate_inv": int(rng.choice([1, 2, 5])), "passage_unlock_rate_inv": int(rng.choice([1, 3, 5]))}
     if rng.rand() < 0.3:
         d["amulet_level"] = int(rng.randint(1, 6))
+    if narrow_many:
+        d["min_room_size"] = {"x": 3, "y": 3}
     cfg = {"width": w, "height": h, "dungeon": d, "hide_dungeon": bool(rng.rand() < 0.7)}
     if rng.rand() < 0.7:
         cfg["item"] = {"armor": {}, "weapon": {},
