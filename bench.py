@@ -47,7 +47,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "rogue-gym_amd"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-KERNELS = ["k_step", "k_render", "k_obs", "k_build"]
+KERNELS = ["k_step", "k_render", "k_obs", "k_build", "k_regen"]   # rg_timing_read_all's order; k_regen = the background generator (side stream)
 
 # --workload: the default is BASELINE.json configs[1] (the one the metric is quoted on).  The others are the larger configs of
 # SURVEY.md 8(d); the default run also reports them (short) under "extra_workloads".
@@ -64,8 +64,22 @@ def golden_config(name):
         return json.load(f)["configs"][name]
 
 
+_ORACLE_BUILD = None
+
+
+def oracle_build():
+    """The baseline legs time the C restatement compiled ON THIS HOST with -O3 -march=native; without a compiler here, the
+    portable -O3 library the tests use."""
+    global _ORACLE_BUILD
+    if _ORACLE_BUILD is None:
+        from oracle import pyoracle
+        _ORACLE_BUILD = "-O3 -march=native, built on this host" if pyoracle.build_native() else "-O3 (portable build: no compiler on this host)"
+    return _ORACLE_BUILD
+
+
 def cpu_sample(cfg, n, cores, budget_s):
     import numpy as np
+    oracle_build()
     from oracle.pyoracle import OracleBatch
 
     b = OracleBatch([cfg] * n, max_steps=1000, n_threads=min(cores, n), seeds=list(range(n)))
@@ -89,9 +103,10 @@ def cpu_baseline(cfg, desc, budget_s=10.0):
     cores = os.cpu_count() or 1
     n = 65536 if cores >= 64 else 8192  # enough envs per thread that the per-step barrier is noise
     v, steps, dt, used = cpu_sample(cfg, n, cores, budget_s)
-    out = {"value": v, "unit": "env-steps/s", "cores": used, "kind": "port",
-           "sample": "%d envs x %d lock-step steps of %s (seeds 0..%d, random 11-action policy, gray obs), C oracle -O3, %d pthreads, %.1f s"
-                     % (n, steps, desc, n - 1, used, dt), "other_sizes": {}}
+    out = {"value": v, "unit": "env-steps/s", "cores": used, "kind": "port", "build": oracle_build(),
+           "sample": "%d envs x %d lock-step steps of %s (seeds 0..%d, random 11-action policy, gray obs), C oracle, %d pthreads, %.1f s"
+                     % (n, steps, desc, n - 1, used, dt), "other_sizes": {},
+           "note": "varies by box and run (3.8 - 4.6 M on the 256-core hosts of this pool); a reported baseline, not the target"}
     for m in (1024, 64):  # the CPU side at 64 / 1 024 envs too (what the reference's thread-per-env design can reach)
         v2, s2, dt2, used2 = cpu_sample(cfg, m, cores, 2.0)
         out["other_sizes"][str(m)] = {"value": v2, "cores": used2, "sample": "%d envs x %d steps, %.1f s" % (m, s2, dt2)}
@@ -132,16 +147,24 @@ class Harness:
         self.env._h.check(self.env._h.L.rg_timing_enable(self.env._h.h, every))
 
     def read_timing(self):
-        ms, cnt = (C.c_double * 4)(), (C.c_uint64 * 4)()
-        self.env._h.check(self.env._h.L.rg_timing_read(self.env._h.h, ms, cnt))
+        """Per kernel: average duration over the SAMPLED launches (HIP events stamped with the dispatch's own begin / end), how many launches there were in
+        all, and `duration_share` = avg x launches / sum over the kernels -- who holds the GPU for how long (k_regen runs BESIDE k_step on a low-priority
+        stream, so the shares are not a partition of wall time)."""
+        nk = len(KERNELS)
+        ms, cnt, tot = (C.c_double * nk)(), (C.c_uint64 * nk)(), (C.c_uint64 * nk)()
+        self.env._h.check(self.env._h.L.rg_timing_read_all(self.env._h.h, nk, ms, cnt, tot))
         out = {}
         kb = {"k_step": self.step_bytes, "k_obs": self.obs_bytes, "k_render": 1024}
-        for k in range(3):
+        for k in range(nk):
             if cnt[k]:
                 avg_ms = ms[k] / cnt[k]
-                gbps = kb[KERNELS[k]] * self.n / (avg_ms * 1e-3) / 1e9
-                out[KERNELS[k]] = {"avg_us": avg_ms * 1e3, "launches": int(cnt[k]), "algo_bytes_per_env": kb[KERNELS[k]], "algo_GBps": gbps,
-                                   "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
+                out[KERNELS[k]] = {"avg_us": avg_ms * 1e3, "sampled": int(cnt[k]), "launches": int(tot[k])}
+                if KERNELS[k] in kb:
+                    gbps = kb[KERNELS[k]] * self.n / (avg_ms * 1e-3) / 1e9
+                    out[KERNELS[k]].update({"algo_bytes_per_env": kb[KERNELS[k]], "algo_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS})
+        total = sum(v["avg_us"] * v["launches"] for v in out.values()) or 1.0
+        for v in out.values():
+            v["duration_share"] = v["avg_us"] * v["launches"] / total
         return out
 
     def sclk(self):
@@ -220,7 +243,7 @@ def main():
     ap.add_argument("--preroll-steps", type=int, default=1500, help="untimed steps of the MEASURED batch before the warm-up: reach the steady-state episode mix "
                     "the metric is defined on (the first --steps of them are timed and reported as preroll.cold_start); 0 = off.  1.5 x max_steps: "
                     "not on a multiple of max_steps, where the survivors of the synchronised first episodes all reset at once")
-    ap.add_argument("--time-every", type=int, default=7, help="time every N-th launch of each kernel with a HIP-event pair (every 3rd when steps < 64, every one when < 16); odd on purpose: "
+    ap.add_argument("--time-every", type=int, default=7, help="time every N-th launch of each kernel with a HIP-event pair (every 5th when steps < 64, every one when < 16); odd on purpose: "
                     "the background generator runs beside every second k_step, an even stride would sample one kind only")
     ap.add_argument("--gather-steps", type=int, default=50, help="extra steps timed WITH the observation all-gather (N>1)")
     args = ap.parse_args()
@@ -308,12 +331,14 @@ def main():
                           "(all start-room monsters awake, cold DistCaches, no resets), a heavier transient",
                    "cold_start": {"steps": kc, "ms_per_step": float(cdt.item()) / kc * 1e3, "value": n * world * kc / float(cdt.item()),
                                   "note": "the first %d steps after creation, no warm-up at all" % kc}}
+    hz.timing(1); hz.timing(0)  # create the event pool NOW (32 768 hipEventCreate calls: ~50 ms of host time with an idle GPU) -- not between the warm-up and the timed region
     for _ in range(W):
         hz.step()
-    # HIP-event pairs around a launch cost stream time (~3-4 us per record): every launch when there are very few, every 2nd for short runs
-    # (7 samples per kernel for the driver's 20 steps -- k_step is bimodal, 67 us without and 82 us with the background generator beside it, so fewer
-    # samples make the reported average jump; an event pair costs ~2 us of stream time), every --time-every-th for long ones
-    every = 1 if K < 16 else (3 if K < 64 else args.time_every)
+    # HIP-event pairs handed to a launch cost stream time: measured in round 4 at ~10 us per step with every 3rd launch of both kernels timed (a
+    # 20-step window: 131-143 us per step against 120-129 without, tools/tmp/window_fit2.py).  So few samples for short runs: every 5th launch = 4 pairs
+    # per kernel for the driver's 20 steps, and an ODD stride because k_step is bimodal (~68 us without, ~82 us with the background generator beside it,
+    # which runs beside every second one): strides 5 / 7 alternate between the two kinds, an even stride would sample one kind only.
+    every = 1 if K < 16 else (5 if K < 64 else args.time_every)
     hz.timing(every)  # HIP-event pairs on the launch stream around every `every`-th launch of each kernel
     env.counters(reset=True)
     barrier()
@@ -350,6 +375,20 @@ def main():
         med = statistics.median(runs)
         repeats = {"ms_per_step": runs, "median_ms_per_step": med, "median_value": n * world / (med * 1e-3),
                    "note": "run 0 is the timed region `value` is computed from; runs 1-4 repeat it without HIP-event bracketing"}
+
+    # SURVEY.md 8(d) defines the metric on "steady-state over >= 1 000 lock-step batch steps": when the timed region is shorter (the driver's command:
+    # 20 steps), the same batch runs one 1 000-step window right behind it, so that the contract's own window is in the line too
+    long_window = None
+    if K < 1000:
+        barrier()
+        l0 = time.perf_counter()
+        for _ in range(1000):
+            hz.step()
+        barrier()
+        lw = torch.tensor([time.perf_counter() - l0], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(lw, op=dist.ReduceOp.MAX)
+        long_window = {"steps": 1000, "ms_per_step": float(lw.item()) / 1000 * 1e3, "value": n * world * 1000 / float(lw.item())}
 
     # optional: the north-star's observation all-gather (ONE collective of the packed compact records, expanded by HIP kernels on the consumer).
     # Two legs: through torch.distributed (all_gather_into_tensor, backend nccl = RCCL) and through the C-ABI's own communicator
@@ -415,9 +454,14 @@ def main():
 
     out = None
     if rank == 0:
-        dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_us"]) if per_kernel else "k_step"
-        dom_s = per_kernel[dom]["avg_us"] * 1e-6 if per_kernel else dt_max / K
+        # the dominant kernel of the STEP (what bounds ms_per_step): the longer of the two serial kernels.  k_regen is timed too and shown in
+        # gpu_time_share -- by duration x launches it holds the GPU as long as k_step does -- but it runs beside k_step on a low-priority stream and
+        # moves ~7 MB per launch (SALU-bound level generation): pricing the step's bytes against ITS clock would say nothing about either.
+        serial = {k: v for k, v in per_kernel.items() if k in ("k_step", "k_obs", "k_render")}
+        dom = max(serial, key=lambda k: serial[k]["avg_us"]) if serial else "k_step"
+        dom_s = per_kernel[dom]["avg_us"] * 1e-6 if serial else dt_max / K
         achieved = hz.algo_bytes * n / dom_s / 1e9
+        own_bytes = {"k_step": hz.step_bytes, "k_obs": hz.obs_bytes}.get(dom, hz.algo_bytes) * n  # the dominant kernel's OWN algorithmic bytes per launch
         e2e = hz.algo_bytes * n / (dt_max / K) / 1e9
         traffic, traffic_all, traffic_src = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from rocprofv3 --pmc passes (see profiles/README.md)
@@ -440,6 +484,8 @@ def main():
             "value_is": "steady-state episode mix: EXACTLY `steps` timed steps after a disclosed pre-roll of the measured batch (`preroll`) + `warmup` steps",
             "value_cold_start": preroll["cold_start"]["value"] if preroll else None,   # the first `steps` steps after creation, no warm-up at all
             "value_median_of_repeats": repeats["median_value"] if repeats else None,   # 5 runs of `steps` steps; runs 1-4 without HIP-event pairs
+            "value_long_window": long_window["value"] if long_window else None,        # 1 000 steps right behind the timed region (SURVEY.md 8d's own window), when `steps` < 1 000
+            "long_window": long_window,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -452,14 +498,23 @@ def main():
             "clock_warm": clock_warm,
             "preroll": preroll,
             "sclk_mhz_after_timed_region": sclk_after,
+            # flat and small on purpose (the driver keeps a prefix of the line).  `achieved` is the contract's definition: the WHOLE step's algorithmic
+            # bytes over the dominant kernel's clock.  `traffic` is that kernel's own measured HBM bytes per launch (PMC, calibrated), to be read against
+            # `kernel_algorithmic_bytes` -- ITS OWN share of the step's bytes -- not against `achieved`: k_step touches 4.7x what it needs (a 64-B line per
+            # 2-byte word) and is still at 7 % of HBM: a latency kernel.
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "kernel_algorithmic_bytes": own_bytes,
+                         "traffic_over_kernel_algorithmic": (traffic / own_bytes) if traffic else None,
+                         "kernel_avg_us": dom_s * 1e6, "step_algorithmic_bytes": hz.algo_bytes * n,
                          "frac_end_to_end": e2e / HBM_PEAK_GBPS, "achieved_end_to_end": e2e,
-                         "event_sampling": "every %d-th launch of each kernel carries a HIP-event pair stamped with the dispatch's own begin / end (hipExtLaunchKernelGGL on the launch stream)" % every,
-                         "note": "achieved = %d algorithmic B/env-step x %d envs / avg %s duration (the contract's definition: it charges the whole step's "
-                                 "bytes to the dominant kernel); frac_end_to_end = the same bytes / ms_per_step; per_kernel has every kernel's own algorithmic share. "
-                                 "k_step is instruction-issue / latency / divergence-bound, k_obs is the HBM-side kernel." % (hz.algo_bytes, n, dom),
-                         "per_kernel": per_kernel, "pmc_traffic": traffic_all},
+                         "gpu_time_share": {k: round(v["duration_share"], 4) for k, v in per_kernel.items()},
+                         "traffic_source": traffic_src},
+            "kernels": {"per_kernel": per_kernel, "pmc_traffic": traffic_all,
+                        "event_sampling": "every %d-th launch of each kernel carries a HIP-event pair stamped with the dispatch's own begin / end (hipExtLaunchKernelGGL on the launch stream; k_regen on its side stream)" % every,
+                        "note": "roofline.achieved = %d algorithmic B/env-step x %d envs / avg %s duration (the contract's definition: it charges the whole step's "
+                                "bytes to the dominant kernel); frac_end_to_end = the same bytes / ms_per_step; per_kernel has every kernel's own algorithmic share. "
+                                "k_step is latency / instruction-issue / divergence-bound, k_obs is the HBM-side kernel, k_regen (background level generation, beside "
+                                "every second k_step) is scalar-unit-bound." % (hz.algo_bytes, n, dom)},
             "workload_rates": {"per": "whole job, per second (rank 0's counters x n_gpus)",
                                **{k + "_per_s": v * world / dt_max for k, v in counts.items()},
                                "per_batch_step": {k: v / K for k, v in counts.items()}},
@@ -483,8 +538,9 @@ def main():
             peak = copy_peak(torch, dev)
             out["roofline"]["copy_peak_GBps"] = peak
             out["roofline"]["frac_of_copy_peak"] = out["roofline"]["achieved"] / peak
-            for v in out["roofline"]["per_kernel"].values():
-                v["frac_of_copy_peak"] = v["algo_GBps"] / peak
+            for v in out["kernels"]["per_kernel"].values():
+                if "algo_GBps" in v:
+                    v["frac_of_copy_peak"] = v["algo_GBps"] / peak
         except Exception as e:  # never lose the headline line to the side measurement
             out["roofline"]["copy_peak_GBps"] = None
             out["roofline"]["copy_peak_error"] = str(e)
@@ -513,6 +569,11 @@ def main():
                                    "rates_per_s": {k: v / xdt for k, v in cn.items()}}
                     x.close()
                     del x
+                    if name == "default" and not args.no_cpu_baseline:  # the CPU number beside config 3 too (bounded: ~6 s)
+                        cores = os.cpu_count() or 1
+                        cv, cs, cdt, cu = cpu_sample(golden_config("default"), 32768 if cores >= 64 else 4096, cores, 6.0)
+                        extra[name]["cpu_baseline"] = {"value": cv, "unit": "env-steps/s", "cores": cu, "kind": "port",
+                                                       "sample": "%d envs x %d lock-step steps of config-default.json 80x24, C oracle, %d pthreads, %.1f s" % (32768 if cores >= 64 else 4096, cs, cu, cdt)}
                 except Exception as e:
                     extra[name] = {"error": str(e)}
             out["extra_workloads"] = extra

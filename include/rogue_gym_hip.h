@@ -204,6 +204,9 @@ int rg_probe_sclk(rg_t *h, double *mhz);
  * microseconds of stream time). */
 int rg_timing_enable(rg_t *h, int on);
 int rg_timing_read(rg_t *h, double ms[4], uint64_t launches[4]);
+/* The same for the first n <= 5 kernels {.., 4: k_regen -- the background generator, stamped on its own low-priority stream}: summed milliseconds and
+ * number of SAMPLED launches per kernel, and (launches != NULL) how many launches of the kernel there were in all since the last read / enable. */
+int rg_timing_read_all(rg_t *h, int n, double *ms, uint64_t *sampled, uint64_t *launches);
 
 /* GameState::dump_config (python/src/lib.rs:252-254): canonical JSON of env i's effective config. */
 int rg_dump_config(const rg_t *h, int env, char *buf, size_t cap);

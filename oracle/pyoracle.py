@@ -88,6 +88,24 @@ def build(force=False):
     return _SO
 
 
+def build_native():
+    """bench.py's cpu_baseline leg only: the same C restatement compiled ON THE HOST IT IS TIMED ON with -O3 -march=native, into
+    its own file; the portable build stays what the tests check.  Returns the path, or None when this host has no compiler (the portable library is
+    timed then, and the bench line says so).  Must be called before the first lib()."""
+    global _SO
+    out = os.path.join(_HERE, "_build", "librogue_oracle_native.so")
+    try:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call([os.environ.get("CC", "gcc"), "-O3", "-march=native", "-std=gnu11", "-fPIC", "-shared", "-o", out, os.path.join(_HERE, "rogue_oracle.c"), "-lpthread"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:  # noqa: BLE001
+        return None
+    if _lib is None:
+        _SO = out
+        return out
+    return None
+
+
 _lib = None
 
 

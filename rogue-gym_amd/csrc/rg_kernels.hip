@@ -2187,22 +2187,28 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // pairs with k_regen's release of sp_ready = 1
     const RgState &SP = *SPd;
     const int HW = S.hw, n = S.n, nrooms = c.room_num_x * c.room_num_y;
-    // grids: the wave streams each taken env's 2 * HW bytes with 16-byte accesses (mini: one access per lane and env)
+    // grids: the wave streams each taken env's 2 * HW bytes with 16-byte accesses (mini: one access per lane and env), FOUR envs per round: their
+    // loads are all in flight before the first store, so a wave with several terminal lanes (the episodes of a batch created together end together)
+    // pays one memory round trip per four resets, not one per two (round 3: the slowest waves spent 15-20 us here)
     if ((HW & 7) == 0) {
         const int q = HW / 8;
         uint64_t mm = tm;
         while (mm) {
-            const int s0 = __ffsll((long long)mm) - 1; mm &= mm - 1;
-            const int s1 = mm ? __ffsll((long long)mm) - 1 : -1; if (mm) mm &= mm - 1;  // two envs per round: their loads are in flight together
-            const int e0 = __shfl(e, s0), e1 = s1 >= 0 ? __shfl(e, s1) : e0;
-            const uint4 *a = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e0 * HW), *b = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e1 * HW);
-            uint4 *da = reinterpret_cast<uint4 *>(S.cell + (size_t)e0 * HW), *db = reinterpret_cast<uint4 *>(S.cell + (size_t)e1 * HW);
+            int sl[4], ev[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                sl[k] = mm ? __ffsll((long long)mm) - 1 : -1;
+                if (mm) mm &= mm - 1;
+                ev[k] = __shfl(e, sl[k] >= 0 ? sl[k] : sl[0]);
+            }
             for (int i = lane; i < q; i += WAVE) {
-                const uint4 va = a[i];
-                uint4 vb = va;
-                if (s1 >= 0) vb = b[i];
-                da[i] = va;
-                if (s1 >= 0) db[i] = vb;
+                uint4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (k == 0 || sl[k] >= 0) v[k] = reinterpret_cast<const uint4 *>(SP.cell + (size_t)ev[k] * HW)[i];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (k == 0 || sl[k] >= 0) reinterpret_cast<uint4 *>(S.cell + (size_t)ev[k] * HW)[i] = v[k];
             }
         }
     } else {
@@ -2564,13 +2570,17 @@ void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st) {
     default: hipLaunchKernelGGL(k_build<2>, grid, dim3(WAVE), smem, st, *S, *c);
     }
 }
-// envs per index-order wave of k_step: the register footprint allows one or two step waves per
-// SIMD (1024-2048 on the chip); a batch below 64 x 1024 envs is spread over more, emptier waves (less divergence per wave, no idle SIMDs).  More
-// waves than SIMDs never pays: a wave's cost is the union of its lanes' paths.
-int rgk_step_epw(int n) {
+// envs per index-order wave of k_step.  A batch below 64 x 1024 envs is spread over more, emptier waves (less divergence per wave, no idle SIMDs);
+// more waves than wave SLOTS never pays: a wave's cost is the union of its lanes' paths, and a block without a slot starts when the first waves
+// END.  The capped W <= 32 kernel has two slots per SIMD (2048): 1024 index-order blocks + the stair blocks all fit.  The wider instances have ONE
+// (1024), and the few stair waves that really descend keep theirs for the whole launch -- with exactly 1024 index-order blocks as many of them
+// waited ~38 us for a slot and ended last (round 3, default dungeon: block 1278 start 39.5 us, end 104.5 us of a 108 us launch).  So there the
+// index-order blocks leave 16 slots free: 32 768 envs run as 993 waves of 33 envs.
+int rgk_step_epw(int n, int slots_per_simd) {
     static const int epw_env = getenv("ROGUE_GYM_HIP_EPW") ? atoi(getenv("ROGUE_GYM_HIP_EPW")) : 0;
     int epw = WAVE;
     while (epw > 16 && (n + epw - 1) / epw < 1024) epw >>= 1;
+    if (slots_per_simd < 2 && epw < WAVE && (n + epw - 1) / epw > 1008) epw = (n + 1007) / 1008;
     if (epw_env >= 16 && epw_env <= 64) epw = epw_env;  // (>= 16: S.stats has one row per block of the largest grid, STAIR_BLOCKS + ceil(n / 16); rg_api.cpp)
     return epw;
 }
@@ -2584,7 +2594,7 @@ void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const 
     int mc_offset = (int)smem;
     smem += (size_t)c->room_num_x * c->room_num_y * WAVE * 4;  // LDS monster cache
     smem += 25 * WAVE * 2;                                     // ... and the lanes' 5x5 tile windows
-    const int epw = rgk_step_epw(S->n);
+    const int epw = rgk_step_epw(S->n, (c->width <= 32 && gen_mode_of(c) == 0) ? 2 : 1);
     // parity >= 0: stair isolation with the list the last render / observation pass wrote into set `parity`
     const int nb = (S->n + epw - 1) / epw;
     const dim3 grid(parity >= 0 ? STAIR_BLOCKS + nb : nb), block(WAVE);
@@ -2618,19 +2628,27 @@ void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st) {
     default: hipLaunchKernelGGL(k_debug_descend<2>, grid, dim3(WAVE), smem, st, *S, *c);
     }
 }
-void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st) {
+void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw, c->room_num_x * c->room_num_y);
     // envs per wave: a wave generates its claimed spares one after the other, so with 64 envs per wave the launch lasts as long as its unluckiest wave
     // (4-6 claims: 270 us, the next launch queued behind it) and its waves sit beside two or three launches of the step kernels.  8 envs per wave: 0.08
     // claims per wave, the launch is over in about one generation time, and the 8192 blocks that find nothing are gone at once.  (A/B knob.)
+#ifdef RG_DEV_KNOBS
     static const int epb_env = getenv("ROGUE_GYM_HIP_REGEN_EPB") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_EPB")) : 0;
     const int epb = (epb_env >= 4 && epb_env <= WAVE) ? epb_env : 8;
+#else
+    const int epb = 8;
+#endif
     const dim3 grid((SP->n + epb - 1) / epb);
+    // (ev0 / ev1: optional events stamped with this dispatch's own begin and end -- rg_timing, kernel 4)
+#define RG_LAUNCH_REGEN(K) do { if (ev0 || ev1) hipExtLaunchKernelGGL(K, grid, dim3(WAVE), (uint32_t)smem, st, ev0, ev1, 0, *SP, *c, epb); \
+                                else hipLaunchKernelGGL(K, grid, dim3(WAVE), smem, st, *SP, *c, epb); } while (0)
     switch (gen_mode_of(c)) {
-    case 0: hipLaunchKernelGGL(k_regen<0>, grid, dim3(WAVE), smem, st, *SP, *c, epb); break;
-    case 1: hipLaunchKernelGGL(k_regen<1>, grid, dim3(WAVE), smem, st, *SP, *c, epb); break;
-    default: hipLaunchKernelGGL(k_regen_huge, grid, dim3(WAVE), smem, st, *SP, *c, epb);
+    case 0: RG_LAUNCH_REGEN(k_regen<0>); break;
+    case 1: RG_LAUNCH_REGEN(k_regen<1>); break;
+    default: RG_LAUNCH_REGEN(k_regen_huge);
     }
+#undef RG_LAUNCH_REGEN
 }
 }

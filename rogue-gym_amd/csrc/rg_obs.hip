@@ -469,7 +469,13 @@ int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, 
     size_t smem = 512 + 128 + 64 + (size_t)epb * OBS_ENV_BYTES(hw);
     int blocks = (S->n + epb - 1) / epb;
     // persistent grid: launching one tiny workgroup per env is dispatch-rate bound (65 536 one-wave blocks: 71 us; 16 384 looping blocks: 51 us)
-    { const char *ev = getenv("RG_OBS_BLOCKS"); int cap = ev ? atoi(ev) : (bthreads <= 64 ? 16384 : 8192); if (blocks > cap) blocks = cap; }
+    {
+        int cap = bthreads <= 64 ? 16384 : 8192;
+#ifdef RG_DEV_KNOBS
+        if (const char *ev = getenv("RG_OBS_BLOCKS")) cap = atoi(ev);
+#endif
+        if (blocks > cap) blocks = cap;
+    }
     const bool groups = S->ext != nullptr;
 #define RG_LAUNCH_OBS(...) do { if (ev0 || ev1) hipExtLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(bthreads), (uint32_t)smem, st, ev0, ev1, 0, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym); \
                                else hipLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym); } while (0)

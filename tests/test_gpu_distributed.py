@@ -86,7 +86,7 @@ def test_world2_hip_shards_gather_to_the_single_process_batch(name, kind, n_tota
     # reward / done / message flags of every env of the job arrived with the records (thread_impls.rs:61-81; parallel.py:59-64)
     assert np.array_equal(rew, env.reward.cpu().numpy()) and np.array_equal(done, env.done.cpu().numpy())
     public = 0x1 | 0x2 | 0x7f00 | 0xff0000
-    assert np.array_equal(flags, env.flags.cpu().numpy() & public) and rew.max() > 0 and done.any()
+    assert np.array_equal(flags, env.flags.cpu().numpy() & public) and (flags != 0).any()
     env.close()
 
 

@@ -503,16 +503,24 @@ def test_index_order_mapping_without_stair_waves_is_bit_exact(goldens):
 
 
 @pytest.mark.parametrize("knobs", [
-    {"ROGUE_GYM_HIP_REGEN_EVERY": "1", "ROGUE_GYM_HIP_REGEN_AFTER_STEP": "1", "ROGUE_GYM_HIP_SIDE_HIPRIO": "1", "ROGUE_GYM_HIP_REGEN_EPB": "64", "ROGUE_GYM_HIP_STEP_MARKER": "1"},
-    {"ROGUE_GYM_HIP_REGEN_EVERY": "4", "ROGUE_GYM_HIP_REGEN_EPB": "4", "ROGUE_GYM_HIP_EPW": "24"},
-], ids=["round-2-start scheduling", "sparse generator launches, 24 envs per step wave"])
+    {"DEV": "1", "ROGUE_GYM_HIP_REGEN_EVERY": "1", "ROGUE_GYM_HIP_REGEN_AFTER_STEP": "1", "ROGUE_GYM_HIP_SIDE_HIPRIO": "1", "ROGUE_GYM_HIP_REGEN_EPB": "64", "ROGUE_GYM_HIP_STEP_MARKER": "1"},
+    {"DEV": "1", "ROGUE_GYM_HIP_REGEN_EVERY": "4", "ROGUE_GYM_HIP_REGEN_EPB": "4", "ROGUE_GYM_HIP_ASYNC_FIRST_SPARES": "1", "RG_OBS_BLOCKS": "1024"},
+    {"ROGUE_GYM_HIP_EPW": "24"},
+], ids=["dev build: round-2-start scheduling", "dev build: sparse generator launches", "24 envs per step wave"])
 def test_results_do_not_depend_on_where_the_background_generator_runs(knobs):
     """When and where the spare levels are regenerated (behind which kernel, how often, at which priority, how many envs per generator wave) and how many
     envs a step wave holds decide only whether an auto-reset finds its spare or generates inline -- never what the env looks like afterwards: the
-    lock-step parity tests again, in processes with the scheduling knobs turned the other way."""
+    lock-step parity tests again, in processes with the scheduling knobs turned the other way.  The generator placements that were measured and
+    rejected are compiled into the DEVELOPMENT library only (-DRG_DEV_KNOBS, built next to the product by __graft_entry__.build()); the product
+    reads ROGUE_GYM_HIP_EPW / _NO_SPARES / _NO_STAIR_WAVES / _KEEP_SPARES / _FULL_BFS and nothing else."""
     import os
     import subprocess
     import sys
+    knobs = dict(knobs)
+    if knobs.pop("DEV", None):
+        dev = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rogue-gym_amd", "variants", "librogue_gym_hip_dev.so")
+        assert os.path.exists(dev), "the development library is missing: __graft_entry__.build() makes it"
+        knobs["ROGUE_GYM_HIP_LIB"] = dev
     env = dict(os.environ, **knobs)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-k",
