@@ -2187,28 +2187,23 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // pairs with k_regen's release of sp_ready = 1
     const RgState &SP = *SPd;
     const int HW = S.hw, n = S.n, nrooms = c.room_num_x * c.room_num_y;
-    // grids: the wave streams each taken env's 2 * HW bytes with 16-byte accesses (mini: one access per lane and env), FOUR envs per round: their
-    // loads are all in flight before the first store, so a wave with several terminal lanes (the episodes of a batch created together end together)
-    // pays one memory round trip per four resets, not one per two (round 3: the slowest waves spent 15-20 us here)
+    // grids: the wave streams each taken env's 2 * HW bytes with 16-byte accesses (mini: one access per lane and env).  (Four envs per round instead of
+    // two -- one round trip per four resets -- was measured neutral in round 4 and cost the capped kernel 80 bytes of scratch: not kept.)
     if ((HW & 7) == 0) {
         const int q = HW / 8;
         uint64_t mm = tm;
         while (mm) {
-            int sl[4], ev[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                sl[k] = mm ? __ffsll((long long)mm) - 1 : -1;
-                if (mm) mm &= mm - 1;
-                ev[k] = __shfl(e, sl[k] >= 0 ? sl[k] : sl[0]);
-            }
+            const int s0 = __ffsll((long long)mm) - 1; mm &= mm - 1;
+            const int s1 = mm ? __ffsll((long long)mm) - 1 : -1; if (mm) mm &= mm - 1;  // two envs per round: their loads are in flight together
+            const int e0 = __shfl(e, s0), e1 = s1 >= 0 ? __shfl(e, s1) : e0;
+            const uint4 *a = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e0 * HW), *b = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e1 * HW);
+            uint4 *da = reinterpret_cast<uint4 *>(S.cell + (size_t)e0 * HW), *db = reinterpret_cast<uint4 *>(S.cell + (size_t)e1 * HW);
             for (int i = lane; i < q; i += WAVE) {
-                uint4 v[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (k == 0 || sl[k] >= 0) v[k] = reinterpret_cast<const uint4 *>(SP.cell + (size_t)ev[k] * HW)[i];
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (k == 0 || sl[k] >= 0) reinterpret_cast<uint4 *>(S.cell + (size_t)ev[k] * HW)[i] = v[k];
+                const uint4 va = a[i];
+                uint4 vb = va;
+                if (s1 >= 0) vb = b[i];
+                da[i] = va;
+                if (s1 >= 0) db[i] = vb;
             }
         }
     } else {

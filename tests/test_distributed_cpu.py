@@ -109,3 +109,34 @@ def test_world2_gloo_gather_matches_single_process():
         assert np.array_equal(hist[i], e.hist())
         # the step half of the ONE collective: reward and done of every env of the job (thread_impls.rs:61-81, parallel.py:59-64)
         assert rew[i] == np.float32(last[i][0]) and bool(done[i]) == bool(last[i][1]), i
+
+
+@pytest.mark.timeout(60)
+def test_spawn_ranks_kills_the_survivors_when_one_rank_dies(tmp_path, monkeypatch):
+    """bench.py's own launcher (`python bench.py --gpus N` without torchrun): when one rank exits with an error the others -- blocked in a barrier that
+    will never complete -- are killed and the worst exit code is returned, instead of the driver's command hanging."""
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+
+    script = tmp_path / "fake_rank.py"
+    script.write_text("import os, sys, time\n"
+                      "open(os.path.join(os.path.dirname(__file__), 'pid%s' % os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+                      "assert os.environ['WORLD_SIZE'] == '4' and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+                      "if os.environ['RANK'] == '2':\n    time.sleep(0.5); sys.exit(7)\n"
+                      "time.sleep(600)\n")
+    monkeypatch.setattr(bench, "__file__", str(script))
+    monkeypatch.setattr(sys, "argv", [str(script)])
+    t0 = time.time()
+    rc = bench.spawn_ranks(4)
+    assert rc == 7 and time.time() - t0 < 30
+    time.sleep(0.3)
+    for r in range(4):
+        pid = int((tmp_path / ("pid%d" % r)).read_text())
+        try:
+            os.kill(pid, 0)
+            alive = open("/proc/%d/stat" % pid).read().split()[2] != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, "rank %d (pid %d) survived" % (r, pid)

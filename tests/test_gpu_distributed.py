@@ -110,6 +110,23 @@ def test_bench_two_ranks_on_one_device():
         f.write(line + "\n")
 
 
+@pytest.mark.timeout(900)
+def test_bench_eight_ranks_on_one_device():
+    """The driver's `python bench.py --gpus 8` is the first run of an 8-process rendezvous: bench.py starts its own 8 ranks
+    (ThreadConductor owns its workers the same way, python/src/thread_impls.rs:14-34), gloo control plane on 127.0.0.1, every rank steps its shard, the
+    gather legs run, rank 0 prints the one line -- here with all eight ranks on GPU 0 (ROGUE_GYM_BENCH_ONE_DEVICE), small shards."""
+    env = dict(os.environ, ROGUE_GYM_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "10", "--warmup", "2", "--envs-per-gpu", "2048", "--gather-steps", "4",
+           "--clock-warm-s", "0", "--preroll-steps", "20", "--no-repeats"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=840)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["steps"] == 10 and out["value"] > 0
+    assert out["config"]["envs_per_gpu"] == 2048 and out["allgather"]["value"] > 0, out.get("allgather")
+
+
 @pytest.mark.timeout(600)
 def test_bench_under_torchrun_still_works():
     """... and the launcher form of the contract (`python -m torch.distributed.run ... bench.py --gpus N`): ranks from the environment."""
