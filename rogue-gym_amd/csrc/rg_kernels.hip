@@ -1762,7 +1762,8 @@ __device__ __forceinline__ bool level_up(const RgConfig &c, Env &E, uint32_t exp
 // actions::player_attack + fight::player_attack (actions.rs:140-166, fight.rs:6-39):
 // the wielded weapon's dice / hit_plus / dam_plus (or bare hands 1d4; the default pack wields a mace 2d4 +1,+1) come resolved from the config
 // (rg_items.cpp); strength 16 => +0 / +0 (fight.rs:89-109); the monster is always `running` by the time of the roll
-__device__ __forceinline__ void player_attack(const RgState &S, const RgConfig &c, Env &E, int slot, uint32_t &react) {
+// (hp / exp_gain: the monster's mon_hp / mon_exp words, loaded by the caller together with everything else the player's move may need)
+__device__ __forceinline__ void player_attack(const RgState &S, const RgConfig &c, Env &E, int slot, uint32_t &react, int hp, uint32_t exp_gain) {
     int idx = slot * E.n + E.e;
     uint32_t w = mon_rd<true>(S, E, slot);
     E.quiet = 0;
@@ -1774,11 +1775,10 @@ __device__ __forceinline__ void player_attack(const RgState &S, const RgConfig &
         int dmg = c.wpn_dam_plus;  // Dice::random (character/mod.rs:229-234): `times` rolls of 1..=max as i64, + dam_plus (fight.rs:66)
         for (int t = 0; t < c.wpn_times; t++) dmg += (int)range64(E.re, 1, (uint64_t)c.wpn_max + 1);
         react |= MSG_HIT_TO;
-        int hp = S.mon_hp[idx];
         if (hp <= dmg) {  // Enemy::get_damage (enemies.rs:205-213)
             mon_wr<true>(S, E, slot, 0);
             E.mon_alive--; E.mon_active--;
-            if (level_up(c, E, S.mon_exp[idx])) react |= R_STATUS;
+            if (level_up(c, E, exp_gain)) react |= R_STATUS;
             react |= MSG_KILLED | R_REDRAW;
         } else S.mon_hp[idx] = dmg - hp;  // reference quirk: stores damage - cur
     } else react |= MSG_MISS_TO;
@@ -1801,6 +1801,7 @@ struct Win {
 // The window lives in LDS, not in registers: 25 VGPRs held from the first load to the last line of the turn (the stair test of the tail reads it)
 // were a tenth of the kernel's register budget, and a run-time index into registers is a 25-deep select chain where LDS takes an address.
 #define WIN_K(i, j) (((j) + 2) * 5 + (i) + 2)
+#define WIN_SLOTS 25
 #define WV(w, k) ((uint32_t)(w).v[(k) * WAVE])
 #define WSET(w, k, val) ((w).v[(k) * WAVE] = (uint16_t)(val))
 
@@ -1866,25 +1867,34 @@ struct FillReq { uint32_t leave, enter; };  // packed half-open rects, 0 = none:
 // actions::move_player + get_item (actions.rs:168-231).  Returns `done` (true = a MoveUntil run stops here).
 // The window is centred on the player's position before the move.
 __device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c, Env &E, Win &w, int d, uint32_t &react, FillReq &fr) {
-    const int nrooms = c.room_num_x * c.room_num_y;
+    const int nrooms = c.room_num_x * c.room_num_y, n = E.n, e = E.e;
     const int dx = dir_dx(d), dy = dir_dy(d);
+    // The lanes of a wave take different branches here -- an attack (monster hp / exp), a step through a door (room meta + rect of the room left
+    // and of the room entered), a step onto gold (the gold table) -- and a wave runs its branches one after the other.  Inside each branch everything
+    // it may need is requested TOGETHER: hp with exp, meta with rect, the whole gold table at once -- one round trip per branch where rounds 1-3 had
+    // dependent chains (hp -> exp; meta -> rect, twice; gold slot after gold slot -> amount: up to ten round trips for the union of a wave's cases).
+    // (Hoisting all of it in front of the branches -- one round trip for the whole move -- spilled the capped W <= 32 kernel: measured, not kept.)
     if (!win_can_move(w, dx, dy)) return true;  // Notify(CantMove): no mirror effect
     const int nx = E.px + dx, ny = E.py + dy;
-    int ms = mon_find(S, E, nrooms, POS(nx, ny));
-    if (ms >= 0) { player_attack(S, c, E, ms, react); return true; }
+    const int ms = mon_find(S, E, nrooms, POS(nx, ny));
+    if (ms >= 0) {
+        const int a_hp = S.mon_hp[ms * n + e];
+        const uint32_t a_exp = S.mon_exp[ms * n + e];
+        player_attack(S, c, E, ms, react, a_hp, a_exp);
+        return true;
+    }
+    const int nk = WIN_K(dx, dy);
+    const int rid_o = (WV(w, WIN_K(0, 0)) & C_DOOR) ? room_id_of(c, E.px, E.py) : -1;   // Floor::leaves_room's room
     // ---- Floor::player_out at the old cell (field-of-view, floor.rs:201-312) ----
-    if (WV(w, WIN_K(0, 0)) & C_DOOR) {  // Floor::leaves_room (floor.rs:249-261)
-        int rid = room_id_of(c, E.px, E.py);
-        if (rid >= 0) {
-            uint8_t meta = S.room_meta[rid * E.n + E.e];
-            if ((meta & RM_VISITED) && (meta & RM_DARK)) {
-                int x0, y0, x1, y1;
-                if ((meta & RM_KIND_MASK) == RK_EMPTY) assigned_area(c, rid, x0, y0, x1, y1);
-                else unpack_rect(S.room_rect[rid * E.n + E.e], x0, y0, x1, y1);
-                if (x1 - x0 > 2 && y1 - y0 > 2) {
-                    fr.leave = pack_rect(x0 + 1, y0 + 1, x1 - 1, y1 - 1);
-                    win_rect(w, x0 + 1, y0 + 1, x1 - 1, y1 - 1, C_VISIBLE, 0);
-                }
+    if (rid_o >= 0) {  // Floor::leaves_room (floor.rs:249-261)
+        const uint32_t meta_o = S.room_meta[rid_o * n + e], rect_o = S.room_rect[rid_o * n + e];
+        if ((meta_o & RM_VISITED) && (meta_o & RM_DARK)) {
+            int x0, y0, x1, y1;
+            if ((meta_o & RM_KIND_MASK) == RK_EMPTY) assigned_area(c, rid_o, x0, y0, x1, y1);
+            else unpack_rect(rect_o, x0, y0, x1, y1);
+            if (x1 - x0 > 2 && y1 - y0 > 2) {
+                fr.leave = pack_rect(x0 + 1, y0 + 1, x1 - 1, y1 - 1);
+                win_rect(w, x0 + 1, y0 + 1, x1 - 1, y1 - 1, C_VISIBLE, 0);
             }
         }
     }
@@ -1899,22 +1909,21 @@ __device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c,
             }
         }
     // ---- Floor::player_in at the new cell ----
-    const int nk = WIN_K(dx, dy);
     uint32_t here = win_get(w, nk);
     if (here & C_DOOR) {
-        int rid = room_id_of(c, nx, ny);
-        if (rid >= 0) {
-            uint8_t meta = S.room_meta[rid * E.n + E.e];
-            if (!(meta & RM_VISITED)) {  // Floor::enters_room (floor.rs:231-247)
-                S.room_meta[rid * E.n + E.e] = meta | RM_VISITED;
-                if ((meta & RM_KIND_MASK) == RK_NORMAL && !(meta & RM_DARK)) {
+        const int rid_n = room_id_of(c, nx, ny);
+        if (rid_n >= 0) {
+            const uint32_t meta_n = S.room_meta[rid_n * n + e], rect_n = S.room_rect[rid_n * n + e];
+            if (!(meta_n & RM_VISITED)) {  // Floor::enters_room (floor.rs:231-247)
+                S.room_meta[rid_n * n + e] = (uint8_t)(meta_n | RM_VISITED);
+                if ((meta_n & RM_KIND_MASK) == RK_NORMAL && !(meta_n & RM_DARK)) {
                     int x0, y0, x1, y1;
-                    unpack_rect(S.room_rect[rid * E.n + E.e], x0, y0, x1, y1);
+                    unpack_rect(rect_n, x0, y0, x1, y1);
                     fr.enter = pack_rect(x0, y0, x1, y1);
                     win_rect(w, x0, y0, x1, y1, 0, C_DRAWN | C_VISIBLE);
                 }
             }
-            activate_room<true>(S, c, E, rid);
+            activate_room<true>(S, c, E, rid_n);
         }
         here = win_get(w, nk);
     }
@@ -1937,9 +1946,17 @@ __device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c,
     const uint32_t v = win_get(w, nk);
     if ((v & C_GOLD) && c.can_pickup) {  // ItemBox::entry -> Merge into the pack's gold, or its first free slot (itembox.rs:30-40); a full pack without
                                          // a Gold item makes get_item return None and the gold stays on the floor (actions.rs:206-231)
-        for (int s = 0; s < nrooms; s++) {
-            uint32_t g = S.gold_pos[s * E.n + E.e];
-            if (g == (POS(nx, ny) | 0x10000u)) { E.gold += S.gold_amt[s * E.n + E.e]; S.gold_pos[s * E.n + E.e] = 0; }
+        const uint32_t want = POS(nx, ny) | 0x10000u;
+        for (int s0 = 0; s0 < nrooms; s0 += 4) {  // the gold table, four slots (positions and amounts) per round: the mini dungeon's whole table at once
+            uint32_t p4[4], a4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int sl = s0 + k < nrooms ? s0 + k : s0;
+                p4[k] = S.gold_pos[sl * n + e]; a4[k] = S.gold_amt[sl * n + e];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (s0 + k < nrooms && p4[k] == want) { E.gold += a4[k]; S.gold_pos[(s0 + k) * n + e] = 0; }
         }
         win_set(w, nk, v & ~C_GOLD);
         react |= R_STATUS;
@@ -2282,7 +2299,16 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         gold_before = S.status[(size_t)e * 10 + 1];
         if (e < S.n_keys) key = keys[e];  // (an env beyond the key prefix has no key: key = 0, never '>')
         load_env(S, E, e);
-        for (int s = 0; s < nrooms_k; s++) E.mc[s * WAVE] = S.mon_w0[s * S.n + e];
+        // the monster words, four slots per round into registers first: written as `E.mc[s * WAVE] = S.mon_w0[..]` in a loop the compiler emitted one
+        // load -> wait -> LDS store per slot, i.e. nrooms SERIAL round trips in every wave (found in the ISA, round 4)
+        for (int s0 = 0; s0 < nrooms_k; s0 += 4) {
+            uint32_t m4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) m4[k] = S.mon_w0[(size_t)(s0 + k < nrooms_k ? s0 + k : s0) * S.n + e];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (s0 + k < nrooms_k) E.mc[(s0 + k) * WAVE] = m4[k];
+        }
     }
     // An env is played by a stair wave iff its player stands on the stairs AND this key is '>' (the only way into a level generation); both
     // kinds of wave decide from the same two values -- the key and the env's byte of the stair set this launch READS, which nothing writes while
@@ -2438,8 +2464,9 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     }
     pf.mark(6);
     if (S.stats) {
-        // per-BLOCK rows, plain read-modify-write by the block's own lane 0 (launches of one handle are stream-ordered): no atomics.  (One
-        // atomicAdd per wave and counter on a shared 64-byte line -- 7 000 same-line atomics per launch -- cost the kernel 20 us, measured.)
+        // per-BLOCK rows (one atomicAdd per wave and counter on a SHARED 64-byte line -- 7 000 same-line atomics per launch -- cost the kernel 20 us,
+        // measured in round 2).  On the block's own line a no-return atomic is a fire-and-forget add; the plain `+=` of rounds 2-3 was a load the
+        // wave had to wait for before it could store and end (round 4).
         const uint32_t cnt[8] = {(uint32_t)__popcll(__ballot(live && terminal && c.auto_reset)), (uint32_t)__popcll(__ballot(descends)),
                                  wave_sum(n_bfs), wave_sum(n_inline), wave_sum(n_taken), (uint32_t)__popcll(__ballot(live && (react & R_REDRAW))),
                                  (uint32_t)__popcll(__ballot(live)), (BW == 1 || BW == 2) ? wave_sum(n_cont) : 0u};
@@ -2447,7 +2474,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             uint32_t mine = 0;
 #pragma unroll
             for (int k = 0; k < 8; k++) mine = lane == k ? cnt[k] : mine;
-            if (mine) S.stats[(size_t)blockIdx.x * 8 + lane] += mine;
+            if (mine) atomicAdd(&S.stats[(size_t)blockIdx.x * 8 + lane], (unsigned long long)mine);  // (no return value: nothing waits for it)
         }
     }
     if (valid && err) {
@@ -2474,7 +2501,10 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         S.steps[e] = steps;
         S.flags[e] = flags;
         S.done[e] = terminal ? 1 : 0;
-        int gold_after = S.status[(size_t)e * 10 + 1];
+        // reward = the gold delta of the status mirror (parallel.py:59-64).  The mirror's gold is E.gold wherever this key rewrote the status (a status
+        // reaction, or the post-reset status), else what it was: known in registers -- reading it back from memory was a dependent round trip
+        // (store -> load -> store, ~2 us) at the very end of every wave
+        const int gold_after = ((terminal && c.auto_reset) || (react & R_STATUS)) ? (int)E.gold : gold_before;
         S.reward[e] = (float)(gold_after - gold_before > 0 ? gold_after - gold_before : 0);
     }
     // the stair set for the NEXT k_step: where does this env's player stand now?  A level generated in this turn reported it (place_player), a taken
@@ -2588,7 +2618,7 @@ void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const 
     smem = (smem + 15) & ~(size_t)15;
     int mc_offset = (int)smem;
     smem += (size_t)c->room_num_x * c->room_num_y * WAVE * 4;  // LDS monster cache
-    smem += 25 * WAVE * 2;                                     // ... and the lanes' 5x5 tile windows
+    smem += WIN_SLOTS * WAVE * 2;                              // ... and the lanes' 5x5 tile windows 
     const int epw = rgk_step_epw(S->n, (c->width <= 32 && gen_mode_of(c) == 0) ? 2 : 1);
     // parity >= 0: stair isolation with the list the last render / observation pass wrote into set `parity`
     const int nb = (S->n + epw - 1) / epw;
