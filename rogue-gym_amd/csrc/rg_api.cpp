@@ -31,7 +31,7 @@ extern "C" {
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st);
 void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 void rgk_probe_clock(unsigned long long *out, int spin, hipStream_t st);
-void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st);
 void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st);
 void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, size_t rs, size_t rst,
@@ -54,6 +54,7 @@ struct rg_handle {
     hipEvent_t ev_step = nullptr;
     int regen_idle_after = -1;   // ROGUE_GYM_HIP_KEEP_SPARES with fixed seeds only: > 0 = that many more k_regen launches (after creation / rg_seed), 0 = none needed, -1 = off
     bool regen_pending = false;  // a k_regen launch is due and hangs behind the next observation pass (rg_step_prefix)
+    int regen_bulk = 0;          // that many of the next k_regen launches rebuild EVERY consumed spare they find (after rg_seed dropped them all), not one per wave
     hipEvent_t regen_ev = nullptr;  // ... that pass has been launched: its completion event; the k_regen launch itself is enqueued right behind the NEXT k_step
     int device = 0;
     hipStream_t stream = nullptr;
@@ -290,10 +291,11 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
     if (h->spares) {
         // first spares.  rg_create waits for them: left in the background, this one-off generation of EVERY env's spare (~2 ms at 65 536 envs)
         // competes with the first few hundred steps for issue slots (the driver's 20-step bench ran k_step at 141 us instead of ~100 us).
-        rgk_regen(&h->SP, &h->cfg, h->side, nullptr, nullptr);
+        rgk_regen(&h->SP, &h->cfg, 1, h->side, nullptr, nullptr);  // (bulk: every spare)
         e = hipGetLastError();
         if (e == hipSuccess && !RG_DEV_ENV("ROGUE_GYM_HIP_ASYNC_FIRST_SPARES")) e = hipStreamSynchronize(h->side);  // (dev knob: the round-1 behaviour)
         if (e != hipSuccess) { g_create_err = std::string("k_regen: ") + hipGetErrorString(e); free_all(h); delete h; return 1; }
+        h->regen_bulk = 1;  // (the first steady-state launch too: whatever the creation launch left, e.g. when it ran in the background)
         bool all_fixed = true;
         for (uint8_t m : h->reseed) all_fixed = all_fixed && m == 0;
         if (h->S.keep_spares && all_fixed) h->regen_idle_after = 1;  // kept spares are never consumed: one more launch (if the first one ran in the background), then none
@@ -481,6 +483,7 @@ int rg_seed(rg_t *h, const uint64_t *seed_lo, const uint64_t *seed_hi, int n) {
         HIPCHK(h, hipStreamSynchronize(h->side));
         HIPCHK(h, hipMemsetAsync(h->S.sp_ready, 0, (size_t)n * 4, h->stream));
         if (h->regen_idle_after >= 0) h->regen_idle_after = 2;  // rebuild the dropped spares, then idle again
+        h->regen_bulk = 2;
     }
     return upload_seeds(h, (size_t)n);  // only the touched prefix travels; the seeds of `seed: None` envs are derived on the device and never read back
 }
@@ -529,21 +532,14 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
         dk = h->d_keys;
     }
     h->S.n_keys = n_keys;
-    // The consumed spares are refilled on the side stream (k_regen), purely stream-ordered (the host runs far ahead of the GPU, so polling an event here
-    // would be meaningless).  WHERE that work lands decides what it costs: ~335 level generations per 65 536-env step are ~10 000 wave-us, and beside the
-    // observation pass (a bandwidth kernel that lives on 7 waves per SIMD) or as a high-priority burst between the two kernels they cost the step
-    // 10-28 us; beside k_step -- latency-bound, a third of the chip's register file idle -- about 7.  So: a launch is due behind every SECOND step (a
-    // launch costs the main stream a few us whatever it finds; behind every third / fourth step its waves carry so many generations that they
-    // serialise and spares run out), it is hung behind the NEXT OBSERVATION PASS (the side stream waits for that kernel's own completion signal, handed
-    // to the launch as hipExtLaunchKernelGGL's stop event -- an event recorded behind it would be one more packet on the main stream), so it starts
-    // with the following k_step; the side stream has LOW priority, so the step kernel's blocks are placed first; and a k_regen wave looks at 8 envs, not
-    // 64 (rgk_regen), so nearly every wave generates at most one level and the launch is over in one generation time instead of 270 us.  Per step, same
-    // box: 143.4 us (every step, behind k_step, high priority, 64 envs per wave) -> 135.3 (every second) -> 125.8 (all four); k_obs 54 -> 46 us,
-    // k_step 77 -> 75 us, inline generations (spare not ready) 1.3 -> 0.3 per step.  A spare is wanted one episode after it was consumed, so the
-    // latency added here is free.  If no observation pass follows a step, the launch goes behind the next step instead.  (Measured and not kept: no stream
-    // dependency at all -- 1 % faster on the mini workload, starves the spares of the default one; an event recorded on the side stream behind every
-    // k_regen, which nothing waited for: +4 us per launch.)
-    static const int regen_every = RG_DEV_ENV("ROGUE_GYM_HIP_REGEN_EVERY") ? atoi(RG_DEV_ENV("ROGUE_GYM_HIP_REGEN_EVERY")) : 2;
+    // The consumed spares are refilled on the side stream (k_regen), purely stream-ordered (the host runs far ahead of the GPU: polling an event here would
+    // be meaningless).  WHERE that work lands decides what it costs: ~450 level generations per 65 536-env step are ~12 000 wave-us of scalar-unit work.
+    // The current form (round 4; the earlier placements and their numbers are in DESIGN_HISTORY.md): a launch behind EVERY step, hung behind the
+    // observation pass that follows the step (the side stream waits for that kernel's own completion signal) and enqueued right behind the NEXT k_step's
+    // launch -- so it runs beside k_step, the latency-bound kernel, not beside the bandwidth-bound pass; low stream priority, so k_step's blocks are
+    // placed first; eight envs per generator wave and at most ONE generation per wave and launch (rgk_regen), so the launch is over in about one
+    // generation time.  If no observation pass follows a step, the launch goes behind the next step instead.
+    static const int regen_every = RG_DEV_ENV("ROGUE_GYM_HIP_REGEN_EVERY") ? atoi(RG_DEV_ENV("ROGUE_GYM_HIP_REGEN_EVERY")) : 1;
     static const bool marker_event = RG_DEV_ENV("ROGUE_GYM_HIP_STEP_MARKER") != nullptr;
     static const bool after_obs = RG_DEV_ENV("ROGUE_GYM_HIP_REGEN_AFTER_STEP") == nullptr;
     h->step_count++;
@@ -570,14 +566,14 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
         // pass (the synchronize used to wait ~100 us for it, alone on the chip), and none is drained in front of the next window's first k_step -- it
         // arrives with that k_step and runs beside it, as designed.  Round 3 measured the two edges at ~150 us per window = 5 % of a 20-step one.
         HIPCHK(h, hipStreamWaitEvent(h->side, h->regen_ev, 0));
-        { TimedLaunch t(h, 4, true); rgk_regen(&h->SP, &h->cfg, h->side, t.start_ev(), t.stop_ev()); }
+        { TimedLaunch t(h, 4, true); rgk_regen(&h->SP, &h->cfg, h->regen_bulk > 0 ? 1 : 0, h->side, t.start_ev(), t.stop_ev()); if (h->regen_bulk > 0) h->regen_bulk--; }
         HIPCHK(h, hipGetLastError());
         h->regen_ev = nullptr;
     }
     if (regen) {
         if (!done_ev) { HIPCHK(h, hipEventRecord(h->ev_step, h->stream)); done_ev = h->ev_step; }
         HIPCHK(h, hipStreamWaitEvent(h->side, done_ev, 0));
-        { TimedLaunch t(h, 4, true); rgk_regen(&h->SP, &h->cfg, h->side, t.start_ev(), t.stop_ev()); }
+        { TimedLaunch t(h, 4, true); rgk_regen(&h->SP, &h->cfg, h->regen_bulk > 0 ? 1 : 0, h->side, t.start_ev(), t.stop_ev()); if (h->regen_bulk > 0) h->regen_bulk--; }
         HIPCHK(h, hipGetLastError());
     }
     h->render_pending = true;

@@ -1165,13 +1165,20 @@ __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
 #define RG_REGEN_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))  // <= 128 registers: two generator waves beside a step wave on a SIMD (tests/test_kernel_resources.py)
 #endif
 template <int GM>
-__device__ __forceinline__ void regen_body(const RgState &SP, const RgConfig &c, int epb) {
+__device__ __forceinline__ void regen_body(const RgState &SP, const RgConfig &c, int epb, int max_claims) {
     const int lane = threadIdx.x;
     const int e = blockIdx.x * epb + lane;
     const bool valid = lane < epb && e < SP.n;
+    // ONE spare per wave and launch: a wave generates its claims one after the other (28 us each, more beside a step wave), so the few waves that found
+    // two or three consumed spares decided how long the launch lasted -- 120-160 us, i.e. through k_step AND the observation pass behind it and into the
+    // next step (round 4: k_obs 47.5 -> 52 us with a launch beside every step).  The other consumed spares of the wave's eight envs wait for the next
+    // launch, one step later; a spare is wanted an episode after it was consumed.
+    const bool want = valid && __hip_atomic_load(&SP.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+    const uint64_t wm = __ballot(want);
+    if (!wm) return;
     bool claim = false;
-    if (valid && __hip_atomic_load(&SP.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
-        claim = atomicCAS(&SP.sp_ready[e], 0u, 2u) == 0u;
+    if (max_claims <= 1) { if (lane == __ffsll((long long)wm) - 1) claim = atomicCAS(&SP.sp_ready[e], 0u, 2u) == 0u; }
+    else if (want) claim = atomicCAS(&SP.sp_ready[e], 0u, 2u) == 0u;
     if (!__any(claim)) return;
     Env E;
     E.e = valid ? e : 0; E.n = SP.n; E.cell = E.gcell = SP.cell + (size_t)E.e * SP.hw; E.err = 0; E.mc = nullptr;
@@ -1184,9 +1191,9 @@ __device__ __forceinline__ void regen_body(const RgState &SP, const RgConfig &c,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (claim) __hip_atomic_store(&SP.sp_ready[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <int GM> __global__ void __launch_bounds__(WAVE) RG_REGEN_ATTR k_regen(RgState SP, RgConfig c, int epb) { regen_body<GM>(SP, c, epb); }
+template <int GM> __global__ void __launch_bounds__(WAVE) RG_REGEN_ATTR k_regen(RgState SP, RgConfig c, int epb, int max_claims) { regen_body<GM>(SP, c, epb, max_claims); }
 // (the 384-room instance does not fit the 128-register cap without scratch; its configs run at one step wave per SIMD anyway)
-__global__ void __launch_bounds__(WAVE) k_regen_huge(RgState SP, RgConfig c, int epb) { regen_body<2>(SP, c, epb); }
+__global__ void __launch_bounds__(WAVE) k_regen_huge(RgState SP, RgConfig c, int epb, int max_claims) { regen_body<2>(SP, c, epb, max_claims); }
 
 // ---------------------------------------------------------------------------------------------
 // wave-cooperative bit-parallel BFS (Floor::make_dist_map, floor.rs:395-416)
@@ -2204,23 +2211,33 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // pairs with k_regen's release of sp_ready = 1
     const RgState &SP = *SPd;
     const int HW = S.hw, n = S.n, nrooms = c.room_num_x * c.room_num_y;
-    // grids: the wave streams each taken env's 2 * HW bytes with 16-byte accesses (mini: one access per lane and env).  (Four envs per round instead of
-    // two -- one round trip per four resets -- was measured neutral in round 4 and cost the capped kernel 80 bytes of scratch: not kept.)
+    // grids: the wave streams each taken env's 2 * HW bytes with 16-byte accesses (mini: one access per lane and env), FOUR envs per round: all their
+    // loads are in flight before the first store, so a wave with several terminal lanes (the episodes of a batch created together end together) pays one
+    // memory round trip per four resets.  (Round 3's slowest waves spent 15-20 us here, two envs per round.  Spelled out without arrays: the array form
+    // put the capped kernel's copies into scratch memory.)
     if ((HW & 7) == 0) {
         const int q = HW / 8;
         uint64_t mm = tm;
         while (mm) {
             const int s0 = __ffsll((long long)mm) - 1; mm &= mm - 1;
-            const int s1 = mm ? __ffsll((long long)mm) - 1 : -1; if (mm) mm &= mm - 1;  // two envs per round: their loads are in flight together
-            const int e0 = __shfl(e, s0), e1 = s1 >= 0 ? __shfl(e, s1) : e0;
-            const uint4 *a = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e0 * HW), *b = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e1 * HW);
-            uint4 *da = reinterpret_cast<uint4 *>(S.cell + (size_t)e0 * HW), *db = reinterpret_cast<uint4 *>(S.cell + (size_t)e1 * HW);
+            const int s1 = mm ? __ffsll((long long)mm) - 1 : -1; if (mm) mm &= mm - 1;
+            const int s2 = mm ? __ffsll((long long)mm) - 1 : -1; if (mm) mm &= mm - 1;
+            const int s3 = mm ? __ffsll((long long)mm) - 1 : -1; if (mm) mm &= mm - 1;
+            const int e0 = __shfl(e, s0), e1 = __shfl(e, s1 >= 0 ? s1 : s0), e2 = __shfl(e, s2 >= 0 ? s2 : s0), e3 = __shfl(e, s3 >= 0 ? s3 : s0);
+            const uint4 *a0 = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e0 * HW), *a1 = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e1 * HW);
+            const uint4 *a2 = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e2 * HW), *a3 = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e3 * HW);
+            uint4 *d0 = reinterpret_cast<uint4 *>(S.cell + (size_t)e0 * HW), *d1 = reinterpret_cast<uint4 *>(S.cell + (size_t)e1 * HW);
+            uint4 *d2 = reinterpret_cast<uint4 *>(S.cell + (size_t)e2 * HW), *d3 = reinterpret_cast<uint4 *>(S.cell + (size_t)e3 * HW);
             for (int i = lane; i < q; i += WAVE) {
-                const uint4 va = a[i];
-                uint4 vb = va;
-                if (s1 >= 0) vb = b[i];
-                da[i] = va;
-                if (s1 >= 0) db[i] = vb;
+                const uint4 v0 = a0[i];
+                uint4 v1 = v0, v2 = v0, v3 = v0;
+                if (s1 >= 0) v1 = a1[i];
+                if (s2 >= 0) v2 = a2[i];
+                if (s3 >= 0) v3 = a3[i];
+                d0[i] = v0;
+                if (s1 >= 0) d1[i] = v1;
+                if (s2 >= 0) d2[i] = v2;
+                if (s3 >= 0) d3[i] = v3;
             }
         }
     } else {
@@ -2653,22 +2670,25 @@ void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st) {
     default: hipLaunchKernelGGL(k_debug_descend<2>, grid, dim3(WAVE), smem, st, *S, *c);
     }
 }
-void rgk_regen(const RgState *SP, const RgConfig *c, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw, c->room_num_x * c->room_num_y);
     // envs per wave: a wave generates its claimed spares one after the other, so with 64 envs per wave the launch lasts as long as its unluckiest wave
     // (4-6 claims: 270 us, the next launch queued behind it) and its waves sit beside two or three launches of the step kernels.  8 envs per wave: 0.08
     // claims per wave, the launch is over in about one generation time, and the 8192 blocks that find nothing are gone at once.  (A/B knob.)
+    // (bulk: every consumed spare the wave finds, not one -- the launches that build ALL spares: creation, after rg_seed)
 #ifdef RG_DEV_KNOBS
     static const int epb_env = getenv("ROGUE_GYM_HIP_REGEN_EPB") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_EPB")) : 0;
     const int epb = (epb_env >= 4 && epb_env <= WAVE) ? epb_env : 8;
+    static const int claims_env = getenv("ROGUE_GYM_HIP_REGEN_CLAIMS") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_CLAIMS")) : 1;
+    const int max_claims = bulk ? WAVE : claims_env;
 #else
-    const int epb = 8;
+    const int epb = 8, max_claims = bulk ? WAVE : 1;
 #endif
     const dim3 grid((SP->n + epb - 1) / epb);
     // (ev0 / ev1: optional events stamped with this dispatch's own begin and end -- rg_timing, kernel 4)
-#define RG_LAUNCH_REGEN(K) do { if (ev0 || ev1) hipExtLaunchKernelGGL(K, grid, dim3(WAVE), (uint32_t)smem, st, ev0, ev1, 0, *SP, *c, epb); \
-                                else hipLaunchKernelGGL(K, grid, dim3(WAVE), smem, st, *SP, *c, epb); } while (0)
+#define RG_LAUNCH_REGEN(K) do { if (ev0 || ev1) hipExtLaunchKernelGGL(K, grid, dim3(WAVE), (uint32_t)smem, st, ev0, ev1, 0, *SP, *c, epb, max_claims); \
+                                else hipLaunchKernelGGL(K, grid, dim3(WAVE), smem, st, *SP, *c, epb, max_claims); } while (0)
     switch (gen_mode_of(c)) {
     case 0: RG_LAUNCH_REGEN(k_regen<0>); break;
     case 1: RG_LAUNCH_REGEN(k_regen<1>); break;
