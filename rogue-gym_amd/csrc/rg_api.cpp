@@ -31,7 +31,7 @@ extern "C" {
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st);
 void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 void rgk_probe_clock(unsigned long long *out, int spin, hipStream_t st);
-void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, const uint32_t *mark, uint32_t target, uint32_t *err_any, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st);
 void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st);
 void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, size_t rs, size_t rst,
@@ -51,11 +51,8 @@ struct rg_handle {
     bool spares = false;
     uint64_t step_count = 0;
     hipStream_t side = nullptr;  // stream of the background generator (LOW priority: the step kernel's blocks are placed first, k_regen takes what is left; rg_step_prefix)
-    hipEvent_t ev_step = nullptr;
     int regen_idle_after = -1;   // ROGUE_GYM_HIP_KEEP_SPARES with fixed seeds only: > 0 = that many more k_regen launches (after creation / rg_seed), 0 = none needed, -1 = off
-    bool regen_pending = false;  // a k_regen launch is due and hangs behind the next observation pass (rg_step_prefix)
     int regen_bulk = 0;          // that many of the next k_regen launches rebuild EVERY consumed spare they find (after rg_seed dropped them all), not one per wave
-    hipEvent_t regen_ev = nullptr;  // ... that pass has been launched: its completion event; the k_regen launch itself is enqueued right behind the NEXT k_step
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
@@ -239,7 +236,7 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
               dev_alloc(h, &S.dc_map, h->cfg.n_enemies > 0 ? n * RG_DIST_SLOTS * hw : 16) && dev_alloc(h, &S.dc_key, RG_DIST_SLOTS * n) &&
               dev_alloc(h, &S.dc_head, n) && dev_alloc(h, &S.dc_len, n) && dev_alloc(h, &S.dc_part, n) && dev_alloc(h, &S.dc_own, n) && dev_alloc(h, &S.status, n * 10) &&
               dev_alloc(h, &h->d_err, 4) && dev_alloc(h, &h->d_keys, n);
-    ok = ok && dev_alloc(h, &S.sp_ready, n) && dev_alloc(h, &h->d_probe, 4);
+    ok = ok && dev_alloc(h, &S.sp_ready, n) && dev_alloc(h, &h->d_probe, 4) && dev_alloc(h, &S.launch_mark, 4);
     // the grid class whose dist maps may be partial (rg_kernels.hip bfs_rows_n32): one saved walkable mask per map
     if (ok && h->cfg.n_enemies > 0 && RG_PARTIAL_MAPS(h->cfg.width, h->cfg.height, (int)nr))
         ok = dev_alloc(h, &S.dc_walk, n * RG_DIST_SLOTS * h->cfg.height * RG_WALK_WORDS(h->cfg.width));
@@ -272,8 +269,7 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
              dev_alloc(h, &P.on_stairs, n);
         P.prof = nullptr;
         int lo = 0, hi = 0;
-        if (ok && (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, RG_DEV_ENV("ROGUE_GYM_HIP_SIDE_HIPRIO") ? hi : lo) != hipSuccess ||
-                   hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming) != hipSuccess)) {
+        if (ok && (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, RG_DEV_ENV("ROGUE_GYM_HIP_SIDE_HIPRIO") ? hi : lo) != hipSuccess)) {
             h->err = "failed to create the background generation stream"; ok = false;
         }
     }
@@ -291,7 +287,7 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
     if (h->spares) {
         // first spares.  rg_create waits for them: left in the background, this one-off generation of EVERY env's spare (~2 ms at 65 536 envs)
         // competes with the first few hundred steps for issue slots (the driver's 20-step bench ran k_step at 141 us instead of ~100 us).
-        rgk_regen(&h->SP, &h->cfg, 1, h->side, nullptr, nullptr);  // (bulk: every spare)
+        rgk_regen(&h->SP, &h->cfg, 1, nullptr, 0, h->d_err, h->side, nullptr, nullptr);  // (bulk: every spare; no gate)
         e = hipGetLastError();
         if (e == hipSuccess && !RG_DEV_ENV("ROGUE_GYM_HIP_ASYNC_FIRST_SPARES")) e = hipStreamSynchronize(h->side);  // (dev knob: the round-1 behaviour)
         if (e != hipSuccess) { g_create_err = std::string("k_regen: ") + hipGetErrorString(e); free_all(h); delete h; return 1; }
@@ -417,7 +413,6 @@ static void destroy_handle(rg_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->comm) (void)comm_release(h, true);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
-    if (h->ev_step) (void)hipEventDestroy(h->ev_step);
     for (int k = 0; k < RG_TIMED_KERNELS; k++) for (auto &e : h->ev[k]) (void)hipEventDestroy(e);
     if (h->obs_scratch) (void)hipFree(h->obs_scratch);
     free_all(h);
@@ -532,50 +527,30 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
         dk = h->d_keys;
     }
     h->S.n_keys = n_keys;
-    // The consumed spares are refilled on the side stream (k_regen), purely stream-ordered (the host runs far ahead of the GPU: polling an event here would
-    // be meaningless).  WHERE that work lands decides what it costs: ~450 level generations per 65 536-env step are ~12 000 wave-us of scalar-unit work.
-    // The current form (round 4; the earlier placements and their numbers are in DESIGN_HISTORY.md): a launch behind EVERY step, hung behind the
-    // observation pass that follows the step (the side stream waits for that kernel's own completion signal) and enqueued right behind the NEXT k_step's
-    // launch -- so it runs beside k_step, the latency-bound kernel, not beside the bandwidth-bound pass; low stream priority, so k_step's blocks are
-    // placed first; eight envs per generator wave and at most ONE generation per wave and launch (rgk_regen), so the launch is over in about one
-    // generation time.  If no observation pass follows a step, the launch goes behind the next step instead.
+    // The consumed spares are refilled on the side stream (k_regen).  WHERE that work lands decides what it costs: ~450 level generations per 65 536-env
+    // step are ~12 000 wave-us of scalar-unit work.  The current form (round 4; the earlier placements and their numbers are in DESIGN_HISTORY.md): a
+    // launch with EVERY step, enqueued right behind the k_step launch and let in by a one-wave GATE kernel once that k_step has started (its block 0
+    // publishes the launch number) -- so the generator runs beside k_step, the latency-bound kernel, never in front of it and not beside the bandwidth-
+    // bound observation pass; low stream priority, so k_step's blocks are placed first; eight envs per generator wave and at most ONE generation per
+    // wave and launch (rgk_regen), so the launch is over in about one generation time.  No event and no packet of this is on the handle's stream: the
+    // round-2/3 form hung the launch on the observation pass's completion event, and an event handed to a launch costs that stream a few us each time.
     static const int regen_every = RG_DEV_ENV("ROGUE_GYM_HIP_REGEN_EVERY") ? atoi(RG_DEV_ENV("ROGUE_GYM_HIP_REGEN_EVERY")) : 1;
-    static const bool marker_event = RG_DEV_ENV("ROGUE_GYM_HIP_STEP_MARKER") != nullptr;
-    static const bool after_obs = RG_DEV_ENV("ROGUE_GYM_HIP_REGEN_AFTER_STEP") == nullptr;
     h->step_count++;
     bool regen = h->spares && (regen_every <= 1 || h->step_count % (uint64_t)regen_every == 0);
     if (regen && h->regen_idle_after >= 0) { if (h->regen_idle_after == 0) regen = false; else h->regen_idle_after--; }
-    if (after_obs && h->spares) {
-        const bool overdue = h->regen_pending;  // no observation pass since it became due: launch it behind this step after all
-        h->regen_pending = regen && !overdue;
-        regen = overdue;
-    }
-    hipEvent_t done_ev = nullptr;
     static const bool no_stair_waves = getenv("ROGUE_GYM_HIP_NO_STAIR_WAVES") != nullptr;
     {   // stair isolation (rg_kernels.hip, k_step): on unless ROGUE_GYM_HIP_NO_STAIR_WAVES is set (the A/B knob of DESIGN.md's measurement)
         TimedLaunch t(h, 0, true);
         h->S.stair_gen = h->stair_gen++;  // reads the stair set its predecessor produced, produces the next one
-        done_ev = t.stop_ev() ? t.stop_ev() : ((regen && !marker_event) ? h->ev_step : nullptr);
-        rgk_step(&h->S, h->d_SP, &h->cfg, dk, h->spares ? 1 : 0, no_stair_waves ? -1 : 0, h->stream, t.start_ev(), done_ev);
+        rgk_step(&h->S, h->d_SP, &h->cfg, dk, h->spares ? 1 : 0, no_stair_waves ? -1 : 0, h->stream, t.start_ev(), t.stop_ev());
     }
     HIPCHK(h, hipGetLastError());
-    if (h->regen_ev) {
-        // The k_regen that hangs behind the last observation pass: enqueued HERE, right behind this k_step's launch, not with that pass.  On the GPU
-        // nothing changes while the host runs ahead (the side stream waits for the pass's completion event either way, and k_step's blocks are placed
-        // first).  What changes is a window that ends with a device-wide synchronize: no generator launch is left in flight behind the window's last
-        // pass (the synchronize used to wait ~100 us for it, alone on the chip), and none is drained in front of the next window's first k_step -- it
-        // arrives with that k_step and runs beside it, as designed.  Round 3 measured the two edges at ~150 us per window = 5 % of a 20-step one.
-        HIPCHK(h, hipStreamWaitEvent(h->side, h->regen_ev, 0));
-        { TimedLaunch t(h, 4, true); rgk_regen(&h->SP, &h->cfg, h->regen_bulk > 0 ? 1 : 0, h->side, t.start_ev(), t.stop_ev()); if (h->regen_bulk > 0) h->regen_bulk--; }
-        HIPCHK(h, hipGetLastError());
-        h->regen_ev = nullptr;
-    }
     if (regen) {
-        if (!done_ev) { HIPCHK(h, hipEventRecord(h->ev_step, h->stream)); done_ev = h->ev_step; }
-        HIPCHK(h, hipStreamWaitEvent(h->side, done_ev, 0));
-        { TimedLaunch t(h, 4, true); rgk_regen(&h->SP, &h->cfg, h->regen_bulk > 0 ? 1 : 0, h->side, t.start_ev(), t.stop_ev()); if (h->regen_bulk > 0) h->regen_bulk--; }
-        HIPCHK(h, hipGetLastError());
+        TimedLaunch t(h, 4, true);
+        rgk_regen(&h->SP, &h->cfg, h->regen_bulk > 0 ? 1 : 0, h->S.launch_mark, (uint32_t)h->S.stair_gen + 1u, h->d_err, h->side, t.start_ev(), t.stop_ev());
+        if (h->regen_bulk > 0) h->regen_bulk--;
     }
+    HIPCHK(h, hipGetLastError());
     h->render_pending = true;
     return 0;
 }
@@ -632,13 +607,8 @@ static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, fl
     }
     {   // steady state: one fused pass refreshes the mirrors of Redraw envs and encodes every env
         TimedLaunch t(h, 2, true);
-        hipEvent_t done_ev = t.stop_ev() ? t.stop_ev() : (h->regen_pending ? h->ev_step : nullptr);
-        if (rgk_obs(&h->S, &h->cfg, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->d_err, h->planes_sym, h->stream, t.start_ev(), done_ev)) {
+        if (rgk_obs(&h->S, &h->cfg, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->d_err, h->planes_sym, h->stream, t.start_ev(), t.stop_ev())) {
             HIPCHK(h, hipGetLastError());
-            if (h->regen_pending) {  // the due k_regen starts when this pass ends, i.e. beside the next k_step: rg_step_prefix enqueues it behind that launch
-                h->regen_pending = false;
-                h->regen_ev = done_ev;
-            }
             h->render_pending = false;
             return 0;
         }

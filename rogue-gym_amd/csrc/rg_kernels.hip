@@ -1191,6 +1191,18 @@ __device__ __forceinline__ void regen_body(const RgState &SP, const RgConfig &c,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (claim) __hip_atomic_store(&SP.sp_ready[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The gate in front of a k_regen launch, alone on the generator's stream: ONE wave that waits until the k_step launched beside it has started
+// (launch_mark reached `target`).  k_regen follows in stream order, so it runs beside that k_step -- not in front of it, where its waves would take
+// the slots of k_step's blocks, and with no event on the handle's stream.  The wait is bounded (~20 ms): a k_step that never starts must not hang
+// rg_sync / rg_destroy, which drain this stream.
+__global__ void __launch_bounds__(WAVE) k_regen_gate(const uint32_t *__restrict__ mark, uint32_t target, uint32_t *__restrict__ err_any) {
+    int spins = 0;
+    while ((int32_t)(__hip_atomic_load(mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1 << 17)) break;
+    }
+    (void)err_any;
+}
 template <int GM> __global__ void __launch_bounds__(WAVE) RG_REGEN_ATTR k_regen(RgState SP, RgConfig c, int epb, int max_claims) { regen_body<GM>(SP, c, epb, max_claims); }
 // (the 384-room instance does not fit the 128-register cap without scratch; its configs run at one step wave per SIMD anyway)
 __global__ void __launch_bounds__(WAVE) k_regen_huge(RgState SP, RgConfig c, int epb, int max_claims) { regen_body<2>(SP, c, epb, max_claims); }
@@ -2554,7 +2566,10 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
 #define RG_STEP_BLOCK_BODY(BWV, GMV) \
     __builtin_amdgcn_s_setprio(3); \
     const int lane = threadIdx.x; \
-    if (blockIdx.x == 0 && lane == 0) stair_recycle(S); \
+    if (blockIdx.x == 0 && lane == 0) { \
+        stair_recycle(S); \
+        __hip_atomic_store(S.launch_mark, (uint32_t)S.stair_gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  /* this launch has started: k_regen_gate */ \
+    } \
     const bool stair = parity >= 0 && (int)blockIdx.x < STAIR_BLOCKS; \
     const int32_t *list = S.stair_list + (size_t)(S.stair_gen & 1) * S.n; \
     const int items = stair ? (int)S.stair_cnt[S.stair_gen % 3] : S.n; \
@@ -2670,7 +2685,8 @@ void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st) {
     default: hipLaunchKernelGGL(k_debug_descend<2>, grid, dim3(WAVE), smem, st, *S, *c);
     }
 }
-void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, const uint32_t *mark, uint32_t target, uint32_t *err_any, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    if (mark) hipLaunchKernelGGL(k_regen_gate, dim3(1), dim3(WAVE), 0, st, mark, target, err_any);
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw, c->room_num_x * c->room_num_y);
     // envs per wave: a wave generates its claimed spares one after the other, so with 64 envs per wave the launch lasts as long as its unluckiest wave

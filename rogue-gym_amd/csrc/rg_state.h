@@ -119,6 +119,7 @@ struct RgState {
     int32_t *stair_list;   // [2][n]
     uint32_t *stair_cnt;   // [8]: [0..2] the rotating entry counts, [4..6] k_step's take counters for entries beyond its first STAIR_BLOCKS
     int32_t stair_gen;     // producers launched so far (set by the host before every producer launch)
+    uint32_t *launch_mark; // [1] stair_gen + 1 of the newest k_step that has STARTED (block 0 publishes it): what the generator's gate kernel waits for
     uint8_t *on_stairs;    // [n] spare view only: the pre-generated state's player stands on the stairs
     // handle with per-env configs that differ in more than the seed: this RgState is one config GROUP, and env e of the group is env ext[e] of the
     // handle (observation tensors are written at the handle's index); NULL = the group is the whole handle
