@@ -953,7 +953,16 @@ __device__ __forceinline__ void env_to_lane(Env &E, const Env &U) {  // the gene
 }
 static_assert(sizeof(Rng) == 16, "Rng is 4 words");
 
-template <int GM>
+// A store another kernel will read while this one is still running (the spare state k_regen hands to k_step): WT = write-through (`sc1`: a relaxed
+// agent-scope atomic store of <= 8 bytes), so that the hand-off needs no release fence.  A release at agent scope is buffer_wbl2 -- the write-back
+// of the XCD's WHOLE L2, which the k_step running beside the generator keeps full of dirty lines: 450 of them per step made a 28 us generation
+// last up to 100 us and cost the step ~10 us (round 4; MI355X_MICROARCH.md: "16-B sc1 stores + drained flag").
+template <bool WT, typename T> __device__ __forceinline__ void st_pub(T *p, T v) {
+    if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+template <int GM, bool WT = false>
 __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c, Env &E, int lane, int e, bool need, bool is_build,
                                             uint16_t *lds_grid, Prof &pf) {
     const int HW = c.width * c.height, nrooms = c.room_num_x * c.room_num_y;
@@ -1000,20 +1009,26 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
         // tables: one room slot per lane (and round, with more rooms than lanes); grid: 16 bytes per lane
         for (int r = lane; r < nrooms; r += WAVE) {
             const size_t g = (size_t)r * real_n + real_e;
-            S.room_rect[g] = T->room_rect[r]; S.room_meta[g] = T->room_meta[r];
-            S.mon_w0[g] = T->mon_w0[r]; S.mon_hp[g] = T->mon_hp[r]; S.mon_exp[g] = T->mon_exp[r];
-            S.gold_pos[g] = T->gold_pos[r]; S.gold_amt[g] = T->gold_amt[r];
+            st_pub<WT>(&S.room_rect[g], T->room_rect[r]); st_pub<WT>(&S.room_meta[g], T->room_meta[r]);
+            st_pub<WT>(&S.mon_w0[g], T->mon_w0[r]); st_pub<WT>(&S.mon_hp[g], T->mon_hp[r]); st_pub<WT>(&S.mon_exp[g], T->mon_exp[r]);
+            st_pub<WT>(&S.gold_pos[g], T->gold_pos[r]); st_pub<WT>(&S.gold_amt[g], T->gold_amt[r]);
             if (GM < 2) break;
         }
         {
             uint16_t *dst = S.cell + (size_t)real_e * HW;
             const uint16_t *srcp = reinterpret_cast<const uint16_t *>(slot);
             if ((HW & 7) == 0) {
-                uint4 *d4 = reinterpret_cast<uint4 *>(dst);
-                const uint4 *s4 = reinterpret_cast<const uint4 *>(srcp);
-                for (int i = lane; i < HW / 8; i += WAVE) d4[i] = s4[i];
+                if constexpr (WT) {  // (8 bytes per store: the widest relaxed atomic store)
+                    unsigned long long *d8 = reinterpret_cast<unsigned long long *>(dst);
+                    const unsigned long long *s8 = reinterpret_cast<const unsigned long long *>(srcp);
+                    for (int i = lane; i < HW / 4; i += WAVE) st_pub<true>(&d8[i], s8[i]);
+                } else {
+                    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+                    const uint4 *s4 = reinterpret_cast<const uint4 *>(srcp);
+                    for (int i = lane; i < HW / 8; i += WAVE) d4[i] = s4[i];
+                }
             } else
-                for (int i = lane; i < HW; i += WAVE) dst[i] = srcp[i];
+                for (int i = lane; i < HW; i += WAVE) st_pub<WT>(&dst[i], srcp[i]);
         }
         if (pf.p) pf.rec(20, __builtin_amdgcn_s_memtime() - tg0);
         pf.mark(16);
@@ -1046,15 +1061,16 @@ __device__ __forceinline__ void load_env(const RgState &S, Env &E, int e) {
     uint32_t mc = S.mon_cnt[e];
     E.mon_alive = mc & 0xff; E.mon_active = (mc >> 8) & 0xff;
 }
+template <bool WT = false>
 __device__ __forceinline__ void store_env(const RgState &S, const Env &E) {
     int n = S.n, e = E.e;
-    S.rng[0 * n + e] = E.rd.x; S.rng[1 * n + e] = E.rd.y; S.rng[2 * n + e] = E.rd.z; S.rng[3 * n + e] = E.rd.w;
-    S.rng[4 * n + e] = E.ri.x; S.rng[5 * n + e] = E.ri.y; S.rng[6 * n + e] = E.ri.z; S.rng[7 * n + e] = E.ri.w;
-    S.rng[8 * n + e] = E.re.x; S.rng[9 * n + e] = E.re.y; S.rng[10 * n + e] = E.re.z; S.rng[11 * n + e] = E.re.w;
-    S.p_pos[e] = (uint16_t)POS(E.px, E.py);
-    S.p_hp[e] = E.hp; S.p_hpmax[e] = E.hpmax; S.p_lvl[e] = E.plvl;
-    S.p_exp[e] = E.exp; S.food[e] = E.food; S.quiet[e] = E.quiet; S.pack_gold[e] = E.gold; S.dlevel[e] = E.dlevel;
-    S.mon_cnt[e] = E.mon_alive | (E.mon_active << 8);
+    const uint32_t r[12] = {E.rd.x, E.rd.y, E.rd.z, E.rd.w, E.ri.x, E.ri.y, E.ri.z, E.ri.w, E.re.x, E.re.y, E.re.z, E.re.w};
+#pragma unroll
+    for (int k = 0; k < 12; k++) st_pub<WT>(&S.rng[k * n + e], r[k]);
+    st_pub<WT>(&S.p_pos[e], (uint16_t)POS(E.px, E.py));
+    st_pub<WT>(&S.p_hp[e], (int32_t)E.hp); st_pub<WT>(&S.p_hpmax[e], (int32_t)E.hpmax); st_pub<WT>(&S.p_lvl[e], (int32_t)E.plvl);
+    st_pub<WT>(&S.p_exp[e], E.exp); st_pub<WT>(&S.food[e], E.food); st_pub<WT>(&S.quiet[e], E.quiet); st_pub<WT>(&S.pack_gold[e], E.gold); st_pub<WT>(&S.dlevel[e], E.dlevel);
+    st_pub<WT>(&S.mon_cnt[e], E.mon_alive | (E.mon_active << 8));
 }
 
 // The stair set a producer launch writes for the k_step after it (rg_state.h): every env it owns gets its byte, marked envs are appended to the
@@ -1184,10 +1200,11 @@ __device__ __forceinline__ void regen_body(const RgState &SP, const RgConfig &c,
     E.e = valid ? e : 0; E.n = SP.n; E.cell = E.gcell = SP.cell + (size_t)E.e * SP.hw; E.err = 0; E.mc = nullptr;
     Prof pf; pf.start(nullptr);
     E.on_stairs = 0;
-    gen_service<GM>(SP, c, E, lane, e, claim, true, reinterpret_cast<uint16_t *>(g_smem), pf);
-    if (claim) { store_env(SP, E); SP.on_stairs[e] = (uint8_t)E.on_stairs; }
+    // everything k_step will take over is written THROUGH (st_pub<true>): the hand-off is "sc1 payload, every writing wave drained, then the flag" --
+    // no release fence (see st_pub); the consumer's side is take_spares' agent-scope acquire
+    gen_service<GM, true>(SP, c, E, lane, e, claim, true, reinterpret_cast<uint16_t *>(g_smem), pf);
+    if (claim) { store_env<true>(SP, E); st_pub<true>(&SP.on_stairs[e], (uint8_t)E.on_stairs); }
     if (claim && E.err) atomicOr(SP.err_any, E.err);  // (the flag word belongs to the concurrently running k_step)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (claim) __hip_atomic_store(&SP.sp_ready[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -2292,7 +2309,10 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
     __syncthreads();  // every lane's reads of the spares are complete (vmcnt drained) ...
     // ... before k_regen may refill them.  (ROGUE_GYM_HIP_KEEP_SPARES: an env with a fixed seed rebuilds the SAME level-1 state at every reset --
     // GameConfig::build is a pure function of config and seed, core/src/lib.rs:193-228 -- so its spare stays valid and is left in place.)
-    if (taken && !(S.keep_spares && S.reseed[e] == 0)) __hip_atomic_store(&S.sp_ready[e], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // (a RELAXED store: what must precede it is that the spare has been READ, which the barrier above guarantees (it drains vmcnt) -- nothing this wave
+    // wrote has to be visible to k_regen.  The release store of rounds 2-3 was a buffer_wbl2, the write-back of the XCD's whole L2, in a third of the
+    // waves of every launch.)
+    if (taken && !(S.keep_spares && S.reseed[e] == 0)) __hip_atomic_store(&S.sp_ready[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One wave's share of a step: lane i plays the key of env `e` (any env index -- the lanes of a wave need not hold consecutive envs), `valid`
