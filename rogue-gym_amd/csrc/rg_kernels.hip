@@ -2237,7 +2237,7 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
 __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__restrict__ SPd, const RgConfig &c, int lane, int e, bool taken, bool &on_stairs) {
     const uint64_t tm = __ballot(taken);
     if (!tm) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // pairs with k_regen's release of sp_ready = 1
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // pairs with k_regen's hand-off (sc1 payload, drained, then sp_ready = 1); measured free (round 4)
     const RgState &SP = *SPd;
     const int HW = S.hw, n = S.n, nrooms = c.room_num_x * c.room_num_y;
     // grids: the wave streams each taken env's 2 * HW bytes with 16-byte accesses (mini: one access per lane and env), FOUR envs per round: all their
