@@ -101,7 +101,9 @@ struct TimedLaunch {  // times one kernel launch with an event pair when timing 
     rg_handle *h; int k; bool on, ext_;
     TimedLaunch(rg_handle *h_, int k_, bool ext = false) : h(h_), k(k_), on(false), ext_(ext) {
         // sampled: an event pair costs a few us of stream time, so only every `timing_stride`-th launch of a kernel is timed
-        if (h->timing && (h->timing_seq[k]++ % h->timing_stride) == 0 && h->ev_used[k] + 2 <= h->ev[k].size()) {
+        // (the sampled launch of every stride is its MIDDLE one, not its first: the first launch behind a synchronize runs on an idle, cold chip -- ~110 us
+        // for a 65 us k_step -- and with 4 samples in the driver's 20-step window that one outlier made the reported average 80 us)
+        if (h->timing && (h->timing_seq[k]++ % h->timing_stride) == h->timing_stride / 2 && h->ev_used[k] + 2 <= h->ev[k].size()) {
             on = true;
             if (!ext_) (void)hipEventRecord(h->ev[k][h->ev_used[k]], h->stream);
         }
