@@ -180,17 +180,6 @@ __device__ __forceinline__ int mon_find(const RgState &S, const Env &E, int nroo
     }
     return found;
 }
-// skip() of EnemyHandler::move_actives (enemies.rs:386-387) seen from monster `self`: a cell is blocked by any
-// asleep monster or any active monster that already moved this turn; `self` is in neither map while it moves
-__device__ __forceinline__ bool blocked_for(const RgState &S, const Env &E, int nrooms, uint32_t pos, int self) {
-    bool blk = false;
-    for (int s = 0; s < nrooms; s++) {
-        uint32_t w = mon_rd<true>(S, E, s);
-        uint32_t fl = w >> 24;
-        if (s != self && (fl & MF_ALIVE) && !(fl & MF_PENDING) && (w & 0xffff) == pos) blk = true;
-    }
-    return blk;
-}
 __device__ __forceinline__ uint32_t lev_add_of(const RgConfig &c, uint32_t level) { return c.amulet_level < level ? level - c.amulet_level : 0; }
 
 // EnemyHandler::activate_area (enemies.rs:342-362): wake MEAN sleepers inside room `rid`'s assigned area
@@ -2158,10 +2147,21 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
         if (!((walk >> 3) & (walk >> 0) & 1u)) cm &= ~(1u << 5);  // RightUp: Right, Up
         if (!((walk >> 2) & (walk >> 1) & 1u)) cm &= ~(1u << 6);  // LeftDown: Left, Down
         if (!((walk >> 3) & (walk >> 1) & 1u)) cm &= ~(1u << 7);  // RightDown: Right, Down
+        // skip() of EnemyHandler::move_actives (enemies.rs:386-387) for the nine cells around this monster, ONCE: bit d = the cell in direction d holds an asleep monster
+        // or an active one that has already moved (the monster itself is in neither map while it moves).  The table does not change while this monster decides, and asking it cell by
+        // cell was nine passes over the wave's LDS monster table per monster.
+        uint32_t occ = 0;
+        for (int s = 0; s < nrooms; s++) {
+            const uint32_t o = mon_rd<true>(S, E, s);
+            const uint32_t fl = o >> 24;
+            const int ddx = POS_X(o) - cx, ddy = POS_Y(o) - cy;
+            if (s != slot && (fl & MF_ALIVE) && !(fl & MF_PENDING) && ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1)
+                occ |= 1u << (uint32_t)((0x716382504ull >> (4 * ((ddy + 1) * 3 + ddx + 1))) & 15ull);  // (dx, dy) -> direction index (kDXc / kDYc order)
+        }
         if (random) {  // Dungeon::move_enemy_randomly
             int d = (int)((wt >> (24 + MF_DIR_SHIFT)) & 7u);
             uint32_t np = POS(cx + dir_dx(d), cy + dir_dy(d));
-            if (!blocked_for(S, E, nrooms, np, slot) && ((cm >> d) & 1u)) {
+            if (!((occ >> d) & 1u) && ((cm >> d) & 1u)) {
                 if (np == ppos) reach = true; else fin = np;
             }
         } else {  // Dungeon::move_enemy: greedy step on the (possibly stale) dist map, 9 directions incl. Stay
@@ -2169,7 +2169,7 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
 #pragma unroll
             for (int d = 0; d < 9; d++) {
                 const uint32_t np = POS(cx + kDXc[d], cy + kDYc[d]);
-                if (reach || blocked_for(S, E, nrooms, np, slot)) continue;
+                if (reach || ((occ >> d) & 1u)) continue;
                 const uint32_t nd = dv[d];
                 if (nd == 0 && ((cm >> d) & 1u)) { reach = true; continue; }
                 if (nd != DIST_INF && nd > 0 && (!found || nd < best)) { best = nd; bp = np; found = true; }
