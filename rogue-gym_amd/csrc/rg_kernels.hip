@@ -1953,18 +1953,15 @@ __device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c,
         here = win_get(w, nk);
     }
     if (!(here & C_VISITED)) { win_set(w, nk, here | C_VISITED); react |= R_HIST_CHANGED; }
+#pragma nounroll
+    for (int ddy = -1; ddy <= 1; ddy++)
 #pragma unroll
-    for (int j = -2; j <= 2; j++)
-#pragma unroll
-        for (int i = -2; i <= 2; i++) {  // Cell::approached (field.rs:20-26) on the 3x3 around the new cell
-            const int ddx = i - dx, ddy = j - dy;
-            const bool near = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && ((w.inb >> WIN_K(i, j)) & 1u);
-            const uint32_t v = WV(w, WIN_K(i, j));
+        for (int ddx = -1; ddx <= 1; ddx++) {  // Cell::approached (field.rs:20-26) on the 3x3 around the new cell: nine window cells at a run-time offset
+            const int k = WIN_K(dx + ddx, dy + ddy);  // (inside the 5x5 window: |dx + ddx| <= 2)
+            const uint32_t v = win_get(w, k);
             const bool diag = ddx != 0 && ddy != 0;
-            if (near && !(diag && (v & C_SURF_MASK) == S_PASSAGE) && !(v & C_HIDDEN) && (v & (C_DRAWN | C_VISIBLE)) != (C_DRAWN | C_VISIBLE)) {
-                WSET(w, WIN_K(i, j), v | C_DRAWN | C_VISIBLE);
-                w.dirty |= 1u << WIN_K(i, j);
-            }
+            if (((w.inb >> k) & 1u) && !(diag && (v & C_SURF_MASK) == S_PASSAGE) && !(v & C_HIDDEN) && (v & (C_DRAWN | C_VISIBLE)) != (C_DRAWN | C_VISIBLE))
+                win_set(w, k, v | C_DRAWN | C_VISIBLE);
         }
     E.px = nx; E.py = ny;
     react |= R_REDRAW;
