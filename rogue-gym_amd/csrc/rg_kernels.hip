@@ -1695,9 +1695,12 @@ __device__ __forceinline__ bool dist_map_sufficient(const RgState &S, const RgCo
     const uint16_t *dist = S.dc_map + ((size_t)E.e * RG_DIST_SLOTS + slot) * S.hw;
     const int nrooms = c.room_num_x * c.room_num_y;
     bool ok = true;
-    for (int q = 0; q < nrooms; q++) {
-        const uint32_t w = E.mc[q * WAVE];
-        if (((w >> 24) & (MF_PENDING | MF_RANDOM)) == MF_PENDING && dist[POS_Y(w) * c.width + POS_X(w)] == DIST_INF) ok = false;
+    for (int q0 = 0; q0 < nrooms; q0 += 2) {  // two monsters per round: their probes are in flight together (one load -> test per monster was a round trip each)
+        const bool has1 = q0 + 1 < nrooms;
+        const uint32_t wa = E.mc[q0 * WAVE], wb = E.mc[(has1 ? q0 + 1 : q0) * WAVE];
+        const uint32_t da = dist[POS_Y(wa) * c.width + POS_X(wa)], db = dist[POS_Y(wb) * c.width + POS_X(wb)];
+        if (((wa >> 24) & (MF_PENDING | MF_RANDOM)) == MF_PENDING && da == DIST_INF) ok = false;
+        if (has1 && ((wb >> 24) & (MF_PENDING | MF_RANDOM)) == MF_PENDING && db == DIST_INF) ok = false;
     }
     return ok;
 }
@@ -2455,12 +2458,14 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             if (do_turn && E.mon_active > 0) need_map = monsters_prepass(S, c, E);
             pf.mark(30);
             if (need_map) {
+                uint32_t part_bits = 0, own_bits = 0;
+                if constexpr (BW == 1 || BW == 2) { part_bits = S.dc_part[e]; own_bits = S.dc_own[e]; }  // (requested with the ring's keys: one round trip, not three)
                 need_bfs = !dist_cache_lookup(S, E, POS(E.px, E.py), map_slot);
                 if constexpr (BW == 1 || BW == 2) {
                     // a cached PARTIAL map that does not reach one of this turn's chasers is continued (bfs_rows_n32)
-                    if (!need_bfs && ((S.dc_part[e] >> map_slot) & 1u) && !dist_map_sufficient(S, c, E, map_slot)) {
+                    if (!need_bfs && ((part_bits >> map_slot) & 1u) && !dist_map_sufficient(S, c, E, map_slot)) {
                         need_bfs = true;
-                        own_req = (S.dc_own[e] >> map_slot) & 1u;
+                        own_req = (own_bits >> map_slot) & 1u;
                         if (own_req) n_cont++;
                     }
                 }
