@@ -1,6 +1,9 @@
 """GPU parity tests proper: the HIP stepper (through the C-ABI) against the CPU oracle and the
 reference's golden vectors.  Bit-exact for all integer state; float-exact for observations
 (tolerance 0: the encode is one correctly-rounded f32 division per cell)."""
+import ctypes
+import json
+
 import numpy as np
 import pytest
 
@@ -160,6 +163,39 @@ def test_inline_generation_path_without_spares(goldens, monkeypatch):
     monkeypatch.setenv("ROGUE_GYM_HIP_NO_SPARES", "1")
     rng = np.random.RandomState(21)
     lockstep(goldens["configs"]["mini"], list(range(256)), rand_keys(rng, ALL_KEYS, 256, 200), max_steps=60, check_every=1, internal_every=40)
+
+
+def test_spare_hand_off_at_full_batch(goldens):
+    """The hand-off of regenerated spare levels (k_regen on the side stream writes them through to memory behind every k_step launch, the
+    resets of later launches take them) under load: 65 536 envs with 30-step episodes -- about 2 200 resets per step, every one served
+    from a spare written a few launches earlier -- against a handle that generates every reset inline.  Any stale or half-written spare
+    shows up as a differing env."""
+    import os
+
+    from rogue_gym_python import _rogue_gym as inner
+
+    n, steps = 65536, 240
+    cfgs = [json.dumps(dict(goldens["configs"]["mini"], seed=i % 5000)) for i in range(n)]
+    a = inner._Handle(cfgs, 30, auto_reset=True)
+    os.environ["ROGUE_GYM_HIP_NO_SPARES"] = "1"
+    try:
+        b = inner._Handle(cfgs, 30, auto_reset=True)
+    finally:
+        del os.environ["ROGUE_GYM_HIP_NO_SPARES"]
+    rng = np.random.RandomState(3)
+    table = np.frombuffer(b"hjklyubn>s.", np.uint8)
+    for t in range(steps):
+        keys = np.ascontiguousarray(table[rng.randint(0, len(table), n)])
+        for h in (a, b):
+            h.check(h.L.rg_step(h.h, keys.ctypes.data, 0))
+        if t % 4 == 3:
+            for x, y, what in zip(a.fetch(), b.fetch(), ("screen", "hist", "status", "flags")):
+                assert np.array_equal(x, y), (t, what, [i for i in range(n) if not np.array_equal(x[i], y[i])][:8])
+    cnt = (ctypes.c_uint64 * 8)()
+    a.check(a.L.rg_counters(a.h, cnt, 0))
+    assert cnt[4] > 0.9 * cnt[0] > 400000, list(cnt)   # the resets did take spares
+    a.close()
+    b.close()
 
 
 def test_frequent_descents_with_monsters(goldens):
