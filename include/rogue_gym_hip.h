@@ -189,9 +189,13 @@ int rg_history_keys(rg_t *h, int env, int which, uint8_t *keys, size_t cap, uint
 int rg_dump_history(rg_t *h, int env, int which, char *buf, size_t cap, size_t *needed);
 
 /* Workload counters accumulated by rg_step since the last reset of the counters: out[0] auto-resets, [1] descents, [2] dist maps built (BFS),
- * [3] levels generated inline by the step kernel, [4] spare levels taken, [5] Redraw reactions, [6] keys processed, [7] partial dist maps continued over the walkable mask saved with them (a map
+ * [3] levels generated inline by the step kernel (descents, and resets that found no spare), [4] spare levels taken, [5] Redraw reactions, [6] keys processed, [7] partial dist maps continued over the walkable mask saved with them (a map
  * begun before a descent or an opening search, grids of 33..96 columns; counted in [2] as well).  Synchronous. */
 int rg_counters(rg_t *h, uint64_t out[8], int reset);
+/* ... and the counters beyond the first eight (n_out <= 16): [8] descents whose level came from its next-level structure -- the first two thirds of
+ * Dungeon::new_level (rogue/mod.rs:434-481: rooms, passages, gold, stairs) generated ahead of the descent by the background generator, the monsters and
+ * the player's placement inside the turn; counted in [3] as well.  [9..15] reserved (0). */
+int rg_counters_ex(rg_t *h, uint64_t *out, int n_out, int reset);
 /* Effective shader clock right now: a one-wave spin kernel on the handle's stream compares s_memtime (shader-clock ticks) with
  * s_memrealtime (constant 100 MHz).  Synchronous; bench.py's evidence for the clock state of a run. */
 int rg_probe_sclk(rg_t *h, double *mhz);

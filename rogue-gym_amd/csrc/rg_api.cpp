@@ -234,7 +234,7 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
               dev_alloc(h, &S.mon_w0, nr * n) && dev_alloc(h, &S.mon_hp, nr * n) && dev_alloc(h, &S.mon_exp, nr * n) &&
               dev_alloc(h, &S.mon_cnt, n) && dev_alloc(h, &S.gold_pos, nr * n) && dev_alloc(h, &S.gold_amt, nr * n) &&
               dev_alloc(h, &S.edge_a, ne * n) && dev_alloc(h, &S.edge_b, ne * n) &&
-              dev_alloc(h, &S.maze_stack, (size_t)maze_cap * n) && dev_alloc(h, &S.build_ctr, n) && dev_alloc(h, &S.stats, 8 * h->stat_rows) && dev_alloc(h, &S.stair_list, 2 * n) && dev_alloc(h, &S.stair_cnt, 8) && dev_alloc(h, &S.stair_mark, 2 * n) &&
+              dev_alloc(h, &S.maze_stack, (size_t)maze_cap * n) && dev_alloc(h, &S.build_ctr, n) && dev_alloc(h, &S.stats, RG_STAT_COLS * h->stat_rows) && dev_alloc(h, &S.stair_list, 2 * n) && dev_alloc(h, &S.stair_cnt, 8) && dev_alloc(h, &S.stair_mark, 2 * n) &&
               dev_alloc(h, &S.dc_map, h->cfg.n_enemies > 0 ? n * RG_DIST_SLOTS * hw : 16) && dev_alloc(h, &S.dc_key, RG_DIST_SLOTS * n) &&
               dev_alloc(h, &S.dc_head, n) && dev_alloc(h, &S.dc_len, n) && dev_alloc(h, &S.dc_part, n) && dev_alloc(h, &S.dc_own, n) && dev_alloc(h, &S.status, n * 10) &&
               dev_alloc(h, &h->d_err, 4) && dev_alloc(h, &h->d_keys, n);
@@ -258,8 +258,20 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
         if (!ok && h->err.empty()) h->err = "hipMemcpy failed";
         S.init_draws = d;
     }
-    h->SP = S;
     h->spares = auto_reset != 0 && getenv("ROGUE_GYM_HIP_NO_SPARES") == nullptr;
+    // next-level structures (rg_kernels.hip gen_service): generated by the spare pipeline's kernel, for the generator instances with the room table in
+    // registers (<= 64 rooms).  ROGUE_GYM_HIP_NO_NEXT_LEVELS: every descent generates its whole level inline (the A side of the parity / A-B tests)
+    if (ok && h->spares && nr <= 64 && getenv("ROGUE_GYM_HIP_NO_NEXT_LEVELS") == nullptr) {
+        RgNext nx;
+        memset(&nx, 0, sizeof nx);
+        RgNext *d_nx = nullptr;
+        ok = dev_alloc(h, &nx.cell, n * hw) && dev_alloc(h, &nx.room_rect, nr * n) && dev_alloc(h, &nx.room_meta, nr * n) &&
+             dev_alloc(h, &nx.gold_pos, nr * n) && dev_alloc(h, &nx.gold_amt, nr * n) && dev_alloc(h, &nx.level, n) &&
+             dev_alloc(h, &S.nx_rng, 12 * n) && dev_alloc(h, &S.nx_state, n) && dev_alloc(h, &d_nx, 1);
+        ok = ok && hipMemcpy(d_nx, &nx, sizeof nx, hipMemcpyHostToDevice) == hipSuccess;
+        S.nx = d_nx;
+    }
+    h->SP = S;
     if (ok && h->spares) {
         RgState &P = h->SP;
         ok = dev_alloc(h, &P.cell, n * hw) && dev_alloc(h, &P.p_pos, n) && dev_alloc(h, &P.p_hp, n) && dev_alloc(h, &P.p_hpmax, n) && dev_alloc(h, &P.p_lvl, n) &&
@@ -296,7 +308,7 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
         h->regen_bulk = 1;  // (the first steady-state launch too: whatever the creation launch left, e.g. when it ran in the background)
         bool all_fixed = true;
         for (uint8_t m : h->reseed) all_fixed = all_fixed && m == 0;
-        if (h->S.keep_spares && all_fixed) h->regen_idle_after = 1;  // kept spares are never consumed: one more launch (if the first one ran in the background), then none
+        if (h->S.keep_spares && all_fixed && !h->S.nx_state) h->regen_idle_after = 1;  // kept spares are never consumed: one more launch (if the first one ran in the background), then none
     }
     *out = h;
     return 0;
@@ -962,29 +974,31 @@ int rg_dump_history(rg_t *h, int env, int which, char *buf, size_t cap, size_t *
     return 0;
 }
 
-int rg_counters(rg_t *h, uint64_t out[8], int reset) {
+int rg_counters_ex(rg_t *h, uint64_t *out, int n_out, int reset) {
     HIPCHK(h, hipSetDevice(h->device));
+    if (n_out < 0 || n_out > RG_STAT_COLS) { h->err = "rg_counters_ex: at most 16 counters"; return 1; }
     if (!h->sub.empty()) {
-        if (out) for (int k = 0; k < 8; k++) out[k] = 0;
+        if (out) for (int k = 0; k < n_out; k++) out[k] = 0;
         for (rg_handle *sh : h->sub) {
-            uint64_t o[8];
-            SUBCHK(h, sh, rg_counters(sh, o, reset));
-            if (out) for (int k = 0; k < 8; k++) out[k] += o[k];
+            uint64_t o[RG_STAT_COLS];
+            SUBCHK(h, sh, rg_counters_ex(sh, o, n_out, reset));
+            if (out) for (int k = 0; k < n_out; k++) out[k] += o[k];
         }
         return 0;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (!h->S.stats) { if (out) memset(out, 0, 64); return 0; }
+    if (!h->S.stats) { if (out) memset(out, 0, 8 * (size_t)n_out); return 0; }
     if (out) {
-        std::vector<unsigned long long> rows(8 * h->stat_rows);
+        std::vector<unsigned long long> rows(RG_STAT_COLS * h->stat_rows);
         HIPCHK(h, hipMemcpy(rows.data(), h->S.stats, rows.size() * 8, hipMemcpyDeviceToHost));
-        for (int k = 0; k < 8; k++) out[k] = 0;
+        for (int k = 0; k < n_out; k++) out[k] = 0;
         for (size_t r = 0; r < h->stat_rows; r++)
-            for (int k = 0; k < 8; k++) out[k] += rows[r * 8 + k];
+            for (int k = 0; k < n_out; k++) out[k] += rows[r * RG_STAT_COLS + k];
     }
-    if (reset) HIPCHK(h, hipMemset(h->S.stats, 0, 64 * h->stat_rows));
+    if (reset) HIPCHK(h, hipMemset(h->S.stats, 0, 8 * RG_STAT_COLS * h->stat_rows));
     return 0;
 }
+int rg_counters(rg_t *h, uint64_t out[8], int reset) { return rg_counters_ex(h, out, 8, reset); }
 
 int rg_probe_sclk(rg_t *h, double *mhz) {
     HIPCHK(h, hipSetDevice(h->device));

@@ -122,6 +122,7 @@ struct Prof {
 // per-lane environment view
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct Env {
     int e;              // env index
     int n;              // env count (SoA stride)
@@ -134,7 +135,8 @@ struct Env {
     uint32_t mon_alive, mon_active;
     lds_u16 *lc;        // generation: the lane's LDS staging grid through an LDS-typed pointer (ds_read / ds_write instead of flat accesses)
     uint16_t *stk_lds;  // generation: LDS maze stack of the lane's slot (GEN_STACK_LDS entries), else nullptr
-    uint32_t *mc;       // k_step: this lane's column of the wave's LDS monster cache (word s at mc[s * WAVE]); write-through
+    lds_u32 *mc;        // k_step: this lane's column of the wave's LDS monster cache (word s at mc[s * WAVE]); write-through.  (LDS-typed: one register and
+                        // ds_read / ds_write, where the generic pointer of rounds 1-4 was two registers and flat accesses)
     uint32_t err;       // RG_FLAG_ERR_INTERNAL if a capacity guard tripped (each guard carries its proof of unreachability)
     uint32_t on_stairs; // set by place_player: the player was put on the staircase of the level just generated
 #ifdef RG_FINE_PROF
@@ -640,10 +642,14 @@ __device__ __forceinline__ void dig_maze(const RgState &S, const RgConfig &c, En
 }
 
 // Dungeon::new_level_ (rogue/mod.rs:434-481).  Returns the bitmask of non-empty rooms.
+// Dungeon::new_level in two halves.  gen_structure: everything up to the stairs -- it draws on the dungeon stream and (gold) on the item stream only,
+// and the item stream is touched by nothing but level generation, so its outcome is a pure function of (level, dungeon stream, item stream).
+// gen_populate: the monsters (dungeon stream for the cell, enemy stream for everything else) and the reveal.  k_regen runs the first half ahead of a
+// descent ("next-level structures", gen_service), the descent then only runs the second.
 template <int GM>
-__device__ __forceinline__ typename RoomSet<GM>::type gen_level(const RgState &S, const RgConfig &c, Env &E, Prof &pf) {
+__device__ __forceinline__ typename RoomSet<GM>::type gen_structure(const RgState &S, const RgConfig &c, Env &E, Prof &pf) {
     typedef typename RoomSet<GM>::type rmask_t;
-    const int W = c.width, H = c.height, HW = W * H, n = E.n, e = E.e;
+    const int W = c.width, HW = W * c.height, n = E.n, e = E.e;
     const int rnx = c.room_num_x, nrooms = rnx * c.room_num_y;
     lds_u16 *cell = E.lc;
     const uint32_t level = ++E.dlevel;
@@ -816,6 +822,14 @@ __device__ __forceinline__ typename RoomSet<GM>::type gen_level(const RgState &S
         }
     }
     pf.mark(14);
+    return non_empty;
+}
+template <int GM>
+__device__ __forceinline__ void gen_populate(const RgState &S, const RgConfig &c, Env &E, Prof &pf) {
+    const int W = c.width, H = c.height, n = E.n, e = E.e;
+    const int nrooms = c.room_num_x * c.room_num_y;
+    lds_u16 *cell = E.lc;
+    const uint32_t level = E.dlevel;
     // ---- monsters (floor.rs:106-130, enemies.rs:265-320) ----
     if (c.n_enemies > 0) {
         uint32_t mn = level >= 4 ? level - 4 : 0, mx = level + 6;
@@ -858,6 +872,11 @@ __device__ __forceinline__ typename RoomSet<GM>::type gen_level(const RgState &S
     pf.mark(15);
     if (!c.hide_dungeon)
         for (int i = W + (int)threadIdx.x; i < (H - 1) * W; i += WAVE) cell[i] |= C_VISIBLE;  // rows 1..H-2
+}
+template <int GM>
+__device__ __forceinline__ typename RoomSet<GM>::type gen_level(const RgState &S, const RgConfig &c, Env &E, Prof &pf) {
+    const typename RoomSet<GM>::type non_empty = gen_structure<GM>(S, c, E, pf);
+    gen_populate<GM>(S, c, E, pf);
     return non_empty;
 }
 
@@ -951,9 +970,53 @@ template <bool WT, typename T> __device__ __forceinline__ void st_pub(T *p, T v)
     else *p = v;
 }
 
+// Next-level structures.  A descent generates its level inside the turn, and the wave that does is the longest chain of a launch (mini: 33 of 51 us,
+// the default dungeon: 71 of 107 us -- the launch lasts as long as that wave).  Two thirds of that generation (gen_structure) draw only on the dungeon and
+// item streams, which play leaves alone except for a successful search next to a hidden passage / locked door and the moves of an erratic monster
+// (rogue/mod.rs:376-397, floor.rs:349-370): between a level's generation and the descent out of it the dungeon stream was untouched in 89 of 91
+// descents of the random policy (tools/tmp measurements in profiles/r04_experiments.txt).  So when a player comes near the stairs (k_step: a staircase in
+// his 5x5 window) the env ASKS for the structure of the next level; k_regen generates it beside the following step from the env's streams as they are
+// then, and writes it through with the dungeon stream it started from as the KEY; the descent compares the key with its own dungeon stream and, on a
+// match, loads the structure into the generator's LDS slot and runs gen_populate + place_player only.  No match (not asked, not ready, stream moved
+// on): the level is generated inline as before -- the result is the same bits either way, the structure only moves work off the critical wave.
+//
+// load_structure: the generator's state as gen_structure would have left it (grid, room / gold tables, streams, level, non-empty set).
+template <int GM>
+__device__ __forceinline__ typename RoomSet<GM>::type load_structure(const RgState &S, const RgConfig &c, Env &U, int real_e, int real_n, const GenTabs *T) {
+    const int HW = c.width * c.height, nrooms = c.room_num_x * c.room_num_y, lane = threadIdx.x;
+    const RgNext *NX = S.nx;  // (each pointer fetched where it is used: the copy of the struct held eight of them in SGPRs through the whole load)
+    const uint16_t *src = NX->cell + (size_t)real_e * HW;
+    if ((HW & 7) == 0) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        __attribute__((address_space(3))) u32x4 *d4 = (__attribute__((address_space(3))) u32x4 *)U.lc;
+        const u32x4 *s4 = reinterpret_cast<const u32x4 *>(src);
+#pragma nounroll
+        for (int i = lane; i < HW / 8; i += WAVE) d4[i] = s4[i];
+    } else {
+#pragma nounroll
+        for (int i = lane; i < HW; i += WAVE) U.lc[i] = src[i];
+    }
+    uint32_t meta = RK_EMPTY;
+    if (lane < nrooms) {
+        const size_t g = (size_t)lane * real_n + real_e;
+        U.g_rect = NX->room_rect[g]; meta = NX->room_meta[g]; U.g_meta = meta;
+        T->gold_pos[lane] = NX->gold_pos[g]; T->gold_amt[lane] = NX->gold_amt[g]; T->mon_w0[lane] = 0;
+    }
+    const uint32_t *q = S.nx_rng + real_e;
+    U.rd = {uni(q[4 * (size_t)real_n]), uni(q[5 * (size_t)real_n]), uni(q[6 * (size_t)real_n]), uni(q[7 * (size_t)real_n])};
+    U.ri = {uni(q[8 * (size_t)real_n]), uni(q[9 * (size_t)real_n]), uni(q[10 * (size_t)real_n]), uni(q[11 * (size_t)real_n])};
+    U.dlevel++;
+    U.mon_alive = U.mon_active = 0;
+    const uint64_t ne = __ballot(lane < nrooms && (meta & RM_KIND_MASK) != RK_EMPTY);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    return (typename RoomSet<GM>::type)ne;
+}
+
+// from_nx / struct_only: bit i = lane i's level comes from its next-level structure / lane i asks for the structure alone (k_regen)
 template <int GM, bool WT = false>
-__device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c, Env &E, int lane, int e, bool need, bool is_build,
-                                            uint16_t *lds_grid, Prof &pf) {
+__device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c, Env &E, int lane, int e, bool need, bool is_build_in,
+                                            uint16_t *lds_grid, Prof &pf, const uint64_t from_nx = 0, const uint64_t struct_only = 0) {
     const int HW = c.width * c.height, nrooms = c.room_num_x * c.room_num_y;
     uint8_t *slot = reinterpret_cast<uint8_t *>(lds_grid);
     const GenTabs TT = gen_tabs(slot, HW, nrooms), *T = &TT;
@@ -968,6 +1031,7 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
         U.cell = U.gcell = reinterpret_cast<uint16_t *>(slot);
         U.lc = (lds_u16 *)U.cell;
         U.stk_lds = T->stack; U.mc = nullptr;
+        const bool so = GM < 2 && ((struct_only >> src) & 1ull), is_build = is_build_in && !so;
         if (is_build) build_prologue(S, U);
         // table view: column 0 of a 1-env SoA in LDS
         RgState L = S;
@@ -979,7 +1043,48 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
 #ifdef RG_FINE_PROF
         U.pfp = &pf;
 #endif
-        const typename RoomSet<GM>::type non_empty = gen_level<GM>(L, c, U, pf);
+        if constexpr (GM < 2) {
+            if (so) {  // the structure alone, written through to the env's nx_* arrays with the stream it started from (k_regen)
+                const RgNext NX = *S.nx;
+                (void)gen_structure<GM>(L, c, U, pf);
+                if (lane < nrooms) { T->room_rect[lane] = U.g_rect; T->room_meta[lane] = (uint8_t)U.g_meta; }
+                __syncthreads();
+                if (lane < nrooms) {
+                    const size_t g = (size_t)lane * real_n + real_e;
+                    st_pub<true>(&NX.room_rect[g], T->room_rect[lane]); st_pub<true>(&NX.room_meta[g], T->room_meta[lane]);
+                    st_pub<true>(&NX.gold_pos[g], T->gold_pos[lane]); st_pub<true>(&NX.gold_amt[g], T->gold_amt[lane]);
+                }
+                {
+                    uint16_t *dst = NX.cell + (size_t)real_e * HW;
+                    const uint16_t *srcp = reinterpret_cast<const uint16_t *>(slot);
+                    if ((HW & 7) == 0) {
+                        unsigned long long *d8 = reinterpret_cast<unsigned long long *>(dst);
+                        const unsigned long long *s8 = reinterpret_cast<const unsigned long long *>(srcp);
+                        for (int i = lane; i < HW / 4; i += WAVE) st_pub<true>(&d8[i], s8[i]);
+                    } else
+                        for (int i = lane; i < HW; i += WAVE) st_pub<true>(&dst[i], srcp[i]);
+                }
+                if (lane < 8) {  // the streams after it (words 0..3, the dungeon stream it started from, and the level are the request's own: the key)
+                    const uint32_t r[8] = {U.rd.x, U.rd.y, U.rd.z, U.rd.w, U.ri.x, U.ri.y, U.ri.z, U.ri.w};
+                    uint32_t mine = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) mine = lane == k ? r[k] : mine;
+                    st_pub<true>(&S.nx_rng[(size_t)(4 + lane) * real_n + real_e], mine);
+                }
+                __syncthreads();
+                continue;
+            }
+        }
+        typename RoomSet<GM>::type non_empty;
+        bool loaded = false;
+        if constexpr (GM < 2) {
+            if ((from_nx >> src) & 1ull) {
+                non_empty = load_structure<GM>(S, c, U, real_e, real_n, T);
+                gen_populate<GM>(L, c, U, pf);
+                loaded = true;
+            }
+        }
+        if (!loaded) non_empty = gen_level<GM>(L, c, U, pf);
         pf.mark(17);
         if (is_build) build_epilogue(L, c, U);
         place_player<GM>(L, c, U, non_empty);
@@ -1122,6 +1227,7 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     store_env(S, E);
     write_status(S, c, E);
     S.dc_len[e] = 0; S.dc_head[e] = 0; S.dc_part[e] = 0; S.dc_own[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
+    if (S.nx_state) (void)__hip_atomic_fetch_and(&S.nx_state[e], RG_NX_DROP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (as step_wave's new level)
     S.steps[e] = 0;
     S.flags[e] = RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY | E.err;
     if (E.err) atomicOr(S.err_any, E.err);
@@ -1151,6 +1257,7 @@ __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
     if (!valid) return;
     store_env(S, E);
     write_status(S, c, E);
+    if (S.nx_state) (void)__hip_atomic_fetch_and(&S.nx_state[e], RG_NX_DROP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (as step_wave's new level)
     S.flags[e] = (S.flags[e] & (RG_FLAG_TERMINAL | RG_FLAG_DEAD)) | RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY | E.err;
     if (E.err) atomicOr(S.err_any, E.err);
 }
@@ -1179,23 +1286,48 @@ __device__ __forceinline__ void regen_body(const RgState &SP, const RgConfig &c,
     // next step (round 4: k_obs 47.5 -> 52 us with a launch beside every step).  The other consumed spares of the wave's eight envs wait for the next
     // launch, one step later; a spare is wanted an episode after it was consumed.
     const bool want = valid && __hip_atomic_load(&SP.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
-    const uint64_t wm = __ballot(want);
-    if (!wm) return;
-    bool claim = false;
-    if (max_claims <= 1) { if (lane == __ffsll((long long)wm) - 1) claim = atomicCAS(&SP.sp_ready[e], 0u, 2u) == 0u; }
-    else if (want) claim = atomicCAS(&SP.sp_ready[e], 0u, 2u) == 0u;
-    if (!__any(claim)) return;
+    // ... or ONE next-level structure (gen_service), which goes first: it is wanted within two or three steps, a spare an episode later
+    const bool want_nx = GM < 2 && valid && SP.nx_state && __hip_atomic_load(&SP.nx_state[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == RG_NX_ASKED;
+    const uint64_t wm = __ballot(want), wx = __ballot(want_nx);
+    if (!(wm | wx)) return;
+    bool claim = false, claim_nx = false;
+    if (max_claims <= 1) {
+        if (wx) { if (lane == __ffsll((long long)wx) - 1) claim_nx = atomicCAS(&SP.nx_state[e], RG_NX_ASKED, RG_NX_CLAIMED) == RG_NX_ASKED; }
+        else if (lane == __ffsll((long long)wm) - 1) claim = atomicCAS(&SP.sp_ready[e], 0u, 2u) == 0u;
+    } else {
+        if (want_nx) claim_nx = atomicCAS(&SP.nx_state[e], RG_NX_ASKED, RG_NX_CLAIMED) == RG_NX_ASKED;
+        if (want && !claim_nx) claim = atomicCAS(&SP.sp_ready[e], 0u, 2u) == 0u;  // (one kind per lane and launch: the lane's registers carry one request)
+    }
+    if (!__any(claim || claim_nx)) return;
     Env E;
     E.e = valid ? e : 0; E.n = SP.n; E.cell = E.gcell = SP.cell + (size_t)E.e * SP.hw; E.err = 0; E.mc = nullptr;
     Prof pf; pf.start(nullptr);
     E.on_stairs = 0;
+    const uint64_t cx = __ballot(claim_nx);
+    E.rd = E.ri = E.re = {0, 0, 0, 0};
+    E.px = E.py = E.hp = E.hpmax = E.plvl = 0; E.exp = E.food = E.quiet = E.gold = E.dlevel = E.mon_alive = E.mon_active = 0;
+    if (claim_nx) {
+        // the request: the streams and the level the asking k_step wrote with it (coherent loads: the words may have been written during this launch)
+        const uint32_t *q = SP.nx_rng + e;
+        const size_t n = (size_t)SP.n;
+        E.rd = {__hip_atomic_load(&q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&q[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                __hip_atomic_load(&q[2 * n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&q[3 * n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+        E.ri = {__hip_atomic_load(&q[8 * n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&q[9 * n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                __hip_atomic_load(&q[10 * n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&q[11 * n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+        E.dlevel = __hip_atomic_load(&SP.nx->level[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // everything k_step will take over is written THROUGH (st_pub<true>): the hand-off is "sc1 payload, every writing wave drained, then the flag" --
-    // no release fence (see st_pub); the consumer's side is take_spares' agent-scope acquire
-    gen_service<GM, true>(SP, c, E, lane, e, claim, true, reinterpret_cast<uint16_t *>(g_smem), pf);
+    // no release fence (see st_pub); the consumer's side is an agent-scope acquire (take_spares, step_wave's descent)
+    // (ONE call site for both kinds: a second instance of the generator cost the capped kernel scratch memory)
+    gen_service<GM, true>(SP, c, E, lane, e, claim || claim_nx, true, reinterpret_cast<uint16_t *>(g_smem), pf, 0ull, cx);
     if (claim) { store_env<true>(SP, E); st_pub<true>(&SP.on_stairs[e], (uint8_t)E.on_stairs); }
     if (claim && E.err) atomicOr(SP.err_any, E.err);  // (the flag word belongs to the concurrently running k_step)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (claim) __hip_atomic_store(&SP.sp_ready[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (by CAS: an env that got a new level meanwhile turned the CLAIMED into DROP -- the structure is for a level it has left, and the env may ask again
+    // from here on)
+    if (claim_nx && atomicCAS(&SP.nx_state[e], RG_NX_CLAIMED, RG_NX_READY) != RG_NX_CLAIMED)
+        __hip_atomic_store(&SP.nx_state[e], RG_NX_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // The gate in front of a k_regen launch, alone on the generator's stream: ONE wave that waits until the k_step launched beside it has started
 // (launch_mark reached `target`).  k_regen follows in stream order, so it runs beside that k_step -- not in front of it, where its waves would take
@@ -1527,7 +1659,7 @@ __device__ __forceinline__ void row_walk_mask(const uint16_t *rowp, int W, uint3
 // slot (`own`), so the map the reference would have computed in full back then is what the extension continues.
 template <int WN>
 __device__ __forceinline__ bool bfs_rows_n32(const RgState &S, const RgConfig &c, bool active, int env, int tx, int ty, int slot, int row, uint64_t grp_lanes,
-                                             const uint32_t *mcol, bool own) {
+                                             const lds_u32 *mcol, bool own) {
     const int W = c.width, H = c.height, HW = W * H;
     const uint16_t *cell = S.cell + (size_t)env * HW;
     const bool row_ok = active && row < H;
@@ -1660,7 +1792,7 @@ __device__ __forceinline__ bool bfs_rows_n32(const RgState &S, const RgConfig &c
 // Returns, to every requesting lane, whether its map is COMPLETE (always, except for the partial maps of bfs_rows_n32).  own_req: the lanes whose
 // request continues a map over the walkable mask saved in its slot.
 template <int BW>
-__device__ __forceinline__ bool bfs_service(const RgState &S, const RgConfig &c, uint64_t *lds, uint64_t need, int e, int px, int py, int map_slot, int lane, const uint32_t *mcbase,
+__device__ __forceinline__ bool bfs_service(const RgState &S, const RgConfig &c, uint64_t *lds, uint64_t need, int e, int px, int py, int map_slot, int lane, const lds_u32 *mcbase,
                                             uint64_t own_req) {
     const int H = c.height;
     const int rows_pow2 = H <= 16 ? 16 : (H <= 32 ? 32 : 64);
@@ -1823,19 +1955,25 @@ __device__ __forceinline__ void player_attack(const RgState &S, const RgConfig &
 // ---------------------------------------------------------------------------------------------
 struct Win {
     lds_u16 *v;            // cell (ox + i, oy + j) = v[((j + 2) * 5 + (i + 2)) * WAVE] (this lane's column of the wave's [25][64] LDS block); 0 outside the grid
-    uint32_t inb, dirty;   // bit k: cell k lies inside the grid / was modified since the load
+    uint32_t inb, dirty;   // bit k: cell k lies inside the grid / was modified since the load; inb bit 31 (WIN_STAIR): a staircase was next to the centre of a
+                           // window loaded in this turn (step_wave: the env asks for its next level's structure)
     int ox, oy;
 };
 // The window lives in LDS, not in registers: 25 VGPRs held from the first load to the last line of the turn (the stair test of the tail reads it)
 // were a tenth of the kernel's register budget, and a run-time index into registers is a 25-deep select chain where LDS takes an address.
 #define WIN_K(i, j) (((j) + 2) * 5 + (i) + 2)
 #define WIN_SLOTS 25
+#define WIN_STAIR 0x80000000u
 #define WV(w, k) ((uint32_t)(w).v[(k) * WAVE])
 #define WSET(w, k, val) ((w).v[(k) * WAVE] = (uint16_t)(val))
 
+#ifndef RG_NX_NEAR
+#define RG_NX_NEAR 1   // how near a staircase must be for the env to ask for its next level's structure (cells, Chebyshev; 2 measured: more structures generated, the same number used)
+#endif
 __device__ __forceinline__ void win_load(const RgConfig &c, const uint16_t *cell, Win &w, int ox, int oy) {
-    w.ox = ox; w.oy = oy; w.inb = 0; w.dirty = 0;
+    w.ox = ox; w.oy = oy; w.inb &= WIN_STAIR; w.dirty = 0;
     uint32_t t[25];
+    bool st = false;
 #pragma unroll
     for (int j = -2; j <= 2; j++)
 #pragma unroll
@@ -1845,7 +1983,9 @@ __device__ __forceinline__ void win_load(const RgConfig &c, const uint16_t *cell
             const uint32_t val = cell[in ? y * c.width + x : oy * c.width + ox];  // unconditional load: all 25 are in flight together
             t[WIN_K(i, j)] = in ? val : 0u;
             if (in) w.inb |= 1u << WIN_K(i, j);
+            if (i >= -RG_NX_NEAR && i <= RG_NX_NEAR && j >= -RG_NX_NEAR && j <= RG_NX_NEAR) st = st || (in && (val & C_SURF_MASK) == S_STAIR);
         }
+    if (st) w.inb |= WIN_STAIR;
 #pragma unroll
     for (int k = 0; k < 25; k++) WSET(w, k, t[k]);
 }
@@ -2328,26 +2468,29 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     E.err = 0; E.on_stairs = 0;
     uint32_t react = 0, err = 0, old_flags = 0, steps = 0, flags = 0;
     int act = ACT_NOOP, dir = 0;
-    int gold_before = 0;
+    int gold0 = 0;       // the status mirror's gold before this key
     bool live = false;   // this lane processes a key this call
     bool ui_dead = false, terminal = false;
     bool taken = false;  // terminal + auto-reset + spare ready: the spare becomes the live state at the end of the wave (take_spares)
     uint32_t n_bfs = 0, n_inline = 0, n_taken = 0, n_cont = 0;  // workload counters (S.stats)
-    uint32_t key = 0;
+    uint32_t key = 0, nxs = RG_NX_NONE;
     bool listed = false;  // the env is in the stair set this launch reads (its player stands on the stairs)
     // LDS monster cache: column `lane` of [nrooms][64] words behind the generation / BFS staging area
     const int nrooms_k = c.room_num_x * c.room_num_y;
-    E.mc = reinterpret_cast<uint32_t *>(g_smem + mc_offset) + lane;
+    E.mc = (lds_u32 *)(g_smem + mc_offset) + lane;
     if (valid_in) {
         // ONE round of independent loads: the step's inputs, the env's scalars and its monster words together.  (Whether the lane plays at all is
         // only known from the first few -- loading the env behind that decision was a second dependent round trip in every wave; a lane that turns
         // out to be somebody else's (stair_role 2), dead or past max_steps just drops what it loaded.)
         listed = S.stair_mark[(size_t)(S.stair_gen & 1) * S.n + e] != 0;
+        uint32_t nxk = 0;  // the last word of the dungeon stream the env's next-level structure starts from
+        if (S.nx_state) { nxs = S.nx_state[e]; nxk = S.nx_rng[(size_t)3 * S.n + e]; }
         old_flags = S.flags[e];
         steps = S.steps[e];
-        gold_before = S.status[(size_t)e * 10 + 1];
+        gold0 = S.status[(size_t)e * 10 + 1];
         if (e < S.n_keys) key = keys[e];  // (an env beyond the key prefix has no key: key = 0, never '>')
         load_env(S, E, e);
+        if (nxs == RG_NX_READY && nxk != E.rd.w) nxs = RG_NX_STALE;  // the stream has moved on since: no use for a descent; asked again when the stairs are near
         // the monster words, four slots per round into registers first: written as `E.mc[s * WAVE] = S.mon_w0[..]` in a loop the compiler emitted one
         // load -> wait -> LDS store per slot, i.e. nrooms SERIAL round trips in every wave (found in the ISA, round 4)
         for (int s0 = 0; s0 < nrooms_k; s0 += 4) {
@@ -2363,6 +2506,8 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     // kinds of wave decide from the same two values -- the key and the env's byte of the stair set this launch READS, which nothing writes while
     // the launch runs (the set for the next launch is a different buffer) -- so exactly one of them takes the env, whenever it starts.  A listed
     // env with any other key costs its stair wave one round of loads.
+    // Parked in LDS until the end of the turn: the step count, the old flags and the status mirror's gold -- three registers held through every service
+    // of the turn by a kernel that has none to spare (the capped instance spilled them to scratch memory instead)
     const bool to_stair_wave = listed && key == '>';
     const bool valid = valid_in && (stair_role == 0 || (stair_role == 1) == to_stair_wave);
     const bool has_key = valid && e < S.n_keys;  // ThreadConductor::step zips keys with envs (thread_impls.rs:62-64)
@@ -2383,9 +2528,21 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     Win w;  // the 5x5 tiles around the player: one round of loads serves the whole player action
     w.v = (lds_u16 *)(g_smem + mc_offset + nrooms_k * WAVE * 4) + lane;
     // (a stair wave's lanes press '>' on the staircase by construction: nothing of the old level is looked at again, so no window)
+    w.inb = 0;
     if (live && stair_role != 1) win_load(c, E.cell, w, E.px, E.py);
     else { w.inb = 0; w.dirty = 0; w.ox = w.oy = 0; }
     pf.mark(26);
+    // Next-level structure (gen_service): a descending lane whose structure is READY and starts from the dungeon stream the env holds now loads it
+    // instead of generating the first two thirds of the level
+    if (S.nx_state) {
+        if (live && act == ACT_DOWNSTAIR && nxs == RG_NX_READY) {
+            const uint32_t *q = S.nx_rng + e;
+            const size_t n = (size_t)S.n;
+            const uint32_t k0 = q[0], k1 = q[n], k2 = q[2 * n], kl = S.nx->level[e];  // (the fourth word was compared when the env was loaded)
+            if (k0 == E.rd.x && k1 == E.rd.y && k2 == E.rd.z && kl == E.dlevel) nxs = RG_NX_HIT;
+        }
+        if (__any(nxs == RG_NX_HIT)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // pairs with k_regen's hand-off (sc1 payload, drained, then nx_state = READY)
+    }
     if (live && act == ACT_DOWNSTAIR) {
         if (stair_role == 1 || (WV(w, WIN_K(0, 0)) & C_SURF_MASK) == S_STAIR) {
             need_gen = descends = true;
@@ -2416,8 +2573,10 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         }
         const bool regenerated = descends && pass == 0;
         if constexpr (BW == 1 || BW == 2) { if (pass == 0 && S.dc_walk) snapshot_walk_service(S, c, lane, e, descends); }
+        const uint64_t nx_now = pass == 0 ? __ballot(need_gen && nxs == RG_NX_HIT) : 0ull;
         if (need_gen) n_inline++;
-        gen_service<GM>(S, c, E, lane, e, need_gen, pass == 1, lds_grid, pf);  // k_step_w32 carries the 32-room generator (rgk_step routes by room count too), the wider instances the 64-room one
+        gen_service<GM>(S, c, E, lane, e, need_gen, pass == 1, lds_grid, pf, nx_now);
+  // k_step_w32 carries the 32-room generator (rgk_step routes by room count too), the wider instances the 64-room one
         (void)regenerated;  // (a descended lane's monster-cache column was refilled by gen_service from the generator's own table)
         pf.mark(2);
         need_gen = false;
@@ -2521,11 +2680,12 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         const uint32_t cnt[8] = {(uint32_t)__popcll(__ballot(live && terminal && c.auto_reset)), (uint32_t)__popcll(__ballot(descends)),
                                  wave_sum(n_bfs), wave_sum(n_inline), wave_sum(n_taken), (uint32_t)__popcll(__ballot(live && (react & R_REDRAW))),
                                  (uint32_t)__popcll(__ballot(live)), (BW == 1 || BW == 2) ? wave_sum(n_cont) : 0u};
-        if (lane < 8) {
-            uint32_t mine = 0;
+        const uint32_t n_nx = (uint32_t)__popcll(__ballot(descends && nxs == RG_NX_HIT));  // [8]: descents that loaded their next-level structure
+        if (lane < RG_STAT_COLS) {
+            uint32_t mine = lane == 8 ? n_nx : 0u;
 #pragma unroll
             for (int k = 0; k < 8; k++) mine = lane == k ? cnt[k] : mine;
-            if (mine) atomicAdd(&S.stats[(size_t)blockIdx.x * 8 + lane], (unsigned long long)mine);  // (no return value: nothing waits for it)
+            if (mine) atomicAdd(&S.stats[(size_t)blockIdx.x * RG_STAT_COLS + lane], (unsigned long long)mine);  // (no return value: nothing waits for it)
         }
     }
     if (valid && err) {
@@ -2555,14 +2715,39 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         // reward = the gold delta of the status mirror (parallel.py:59-64).  The mirror's gold is E.gold wherever this key rewrote the status (a status
         // reaction, or the post-reset status), else what it was: known in registers -- reading it back from memory was a dependent round trip
         // (store -> load -> store, ~2 us) at the very end of every wave
+        const int gold_before = gold0;
         const int gold_after = ((terminal && c.auto_reset) || (react & R_STATUS)) ? (int)E.gold : gold_before;
         S.reward[e] = (float)(gold_after - gold_before > 0 ? gold_after - gold_before : 0);
     }
     // the stair set for the NEXT k_step: where does this env's player stand now?  A level generated in this turn reported it (place_player), a taken
     // spare carries it, otherwise it is the tile under the player in the window (centred on where the last move started; the player is within one cell)
-    bool on_next = listed;
+    bool on_next = false;
+    if (valid && !live) on_next = S.stair_mark[(size_t)(S.stair_gen & 1) * S.n + e] != 0;  // (an env that did not play stands where it stood: its byte again, not a register held through the turn)
     if (live) on_next = ((descends || (terminal && c.auto_reset && !taken)) ? E.on_stairs != 0
                                                                               : (win_get(w, WIN_K(E.px - w.ox, E.py - w.oy)) & C_SURF_MASK) == S_STAIR);
+    if (S.nx_state) {
+        // a new level (descent, reset): nothing asked for it yet.  Else, the first time a staircase shows up next to the player: ASK for the next level's
+        // structure (k_regen, beside the next step) -- or again, when the dungeon stream has left the one a READY structure starts from (an erratic
+        // monster moved, a search found something).  The request carries the streams and the level it is for, written through and DRAINED before the
+        // flag: k_regen works from this copy, never from the env's live state (which the k_step beside it may be replacing, its plain stores reaching
+        // memory in any order).  k_regen touches the env's request and structure only between its claim (ASKED -> CLAIMED) and its publish / drop, and
+        // an env asks only from NONE or READY -- a new level while the claim is out leaves DROP, not NONE (rg_state.h) -- so the two sides never read or
+        // write these words at the same time.
+        const bool fresh = live && (descends || (terminal && c.auto_reset));
+        const bool ask = live && !fresh && (w.inb & WIN_STAIR) && (nxs == RG_NX_NONE || nxs == RG_NX_STALE);
+        if (fresh && nxs != RG_NX_NONE) (void)__hip_atomic_fetch_and(&S.nx_state[e], RG_NX_DROP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // CLAIMED -> DROP, else -> NONE
+        if (__any(ask)) {
+            if (ask) {
+                uint32_t *q = S.nx_rng + e;
+                const size_t n = (size_t)S.n;
+                st_pub<true>(&q[0], E.rd.x); st_pub<true>(&q[n], E.rd.y); st_pub<true>(&q[2 * n], E.rd.z); st_pub<true>(&q[3 * n], E.rd.w);
+                st_pub<true>(&q[8 * n], E.ri.x); st_pub<true>(&q[9 * n], E.ri.y); st_pub<true>(&q[10 * n], E.ri.z); st_pub<true>(&q[11 * n], E.ri.w);
+                st_pub<true>(&S.nx->level[e], E.dlevel);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ask) __hip_atomic_store(&S.nx_state[e], RG_NX_ASKED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     take_spares(S, SPd, c, lane, e, taken, on_next);
     stair_publish(S, lane, e, valid, on_next);
     pf.mark(7);

@@ -50,6 +50,22 @@ enum { RK_NORMAL = 0, RK_MAZE = 1, RK_EMPTY = 2 };
 // ... and which configs step in that class: rows of <= 96 columns with H * W <= 4096, except the 32-column grids of <= 32 rooms (k_step_w32: whole maps)
 #define RG_PARTIAL_MAPS(w, h, rooms) ((w) <= 96 && (w) * (h) <= 4096 && (rooms) <= 64 && !((w) <= 32 && (rooms) <= 32))
 
+#define RG_STAT_COLS 16   /* counters per row of RgState::stats: one 128-byte line */
+#define RG_NX_ASKED 1u    /* k_step: the player is next to the stairs, generate the structure (the request's streams and level are written, drained, then this) */
+#define RG_NX_CLAIMED 6u  /* k_regen is generating it */
+#define RG_NX_READY 3u    /* payload complete */
+#define RG_NX_NONE 0u     /* nothing asked for this level yet */
+#define RG_NX_DROP 4u     /* the env got a new level while k_regen was generating: k_regen finds this instead of its CLAIMED, drops the result and stores NONE.
+                             (k_step's "new level" is ONE atomic AND with RG_NX_DROP: CLAIMED -> DROP, every other state -> NONE.  An env asks only from NONE /
+                             READY, so never while a claim is outstanding: the request and the structure are never written by both sides at once.) */
+#define RG_NX_STALE 8u    /* (k_step's registers only) READY, but made for a dungeon stream the env no longer holds */
+#define RG_NX_HIT 9u      /* (k_step's registers only) READY and made for exactly the streams and level the env holds: this descent loads it */
+struct RgNext {
+    uint16_t *cell;      // [n][hw] the grid after the stair placement
+    uint32_t *room_rect, *gold_pos, *gold_amt;  // [rooms][n]
+    uint8_t *room_meta;  // [rooms][n]
+    uint32_t *level;     // [n] the level the env was on when it asked
+};
 struct RgState {
     int32_t n;          // environments on this device
     int32_t hw;         // H*W
@@ -110,7 +126,7 @@ struct RgState {
     int32_t klog_cap;
     // workload counters (bench.py: resets/s, descents/s, BFS maps/s): [0] auto-resets [1] descents [2] dist maps built [3] inline level
     // generations [4] spare levels taken [5] Redraw reactions [6] keys processed; one atomicAdd per wave and counter
-    unsigned long long *stats;
+    unsigned long long *stats;  // [rows][RG_STAT_COLS] (a row per block); [8] descents that loaded their next-level structure (counted in [3] as well)
     // Envs whose player stands on the staircase, for k_step's stair waves.  Whoever changes player positions (k_build, k_step, the debug descent)
     // PRODUCES the set for the k_step after it: a byte per env + the list of the marked envs, double-buffered, with three rotating counters
     // (producer number g reads set g & 1 / counter g % 3, writes set (g + 1) & 1 / counter (g + 1) % 3, zeroes counter (g + 2) % 3) --
@@ -121,6 +137,15 @@ struct RgState {
     int32_t stair_gen;     // producers launched so far (set by the host before every producer launch)
     uint32_t *launch_mark; // [1] stair_gen + 1 of the newest k_step that has STARTED (block 0 publishes it): what the generator's gate kernel waits for
     uint8_t *on_stairs;    // [n] spare view only: the pre-generated state's player stands on the stairs
+    // Next-level structures (rg_kernels.hip "next-level structures"): the part of Dungeon::new_level that only draws on the dungeon and item streams
+    // (rooms, passages, gold, stairs), generated AHEAD of the descent by k_regen from the streams' state when the player came near the stairs, and
+    // valid at the descent iff the dungeon stream is still where the structure started from (nx_rng[0..3] == the env's rd, nx_level == its level).
+    // NULL = off (no auto-reset spares, more than 64 rooms, ROGUE_GYM_HIP_NO_NEXT_LEVELS).  Shared by the live and the spare view.
+    uint32_t *nx_state;     // [n] RG_NX_*
+    uint32_t *nx_rng;       // [12][n]: [0..3] the dungeon stream the structure starts from (the key, written with the request), [4..7] the dungeon stream
+                            // after it, [8..11] the item stream (the request's, then the one after it)
+    const struct RgNext *nx;  // the rest of it, device-resident (read on the rare paths only: a second dozen of pointers in the kernel argument costs the capped
+                              // step kernel registers it does not have)
     // handle with per-env configs that differ in more than the seed: this RgState is one config GROUP, and env e of the group is env ext[e] of the
     // handle (observation tensors are written at the handle's index); NULL = the group is the whole handle
     const int32_t *ext;

@@ -226,9 +226,9 @@ class HipVecRogueEnv:
 
     def counters(self, reset: bool = False):
         """Workload counters since the last reset of the counters (rg_counters)."""
-        out = (C.c_uint64 * 8)()
-        self._h.check(self._h.L.rg_counters(self._h.h, out, int(reset)))
-        names = ("resets", "descents", "dist_maps", "inline_generations", "spares_taken", "redraws", "keys")
+        out = (C.c_uint64 * 9)()
+        self._h.check(self._h.L.rg_counters_ex(self._h.h, out, 9, int(reset)))
+        names = ("resets", "descents", "dist_maps", "inline_generations", "spares_taken", "redraws", "keys", "partial_maps_continued", "next_level_structures_used")
         return dict(zip(names, (int(v) for v in out)))
 
     def enable_history(self, cap_per_env: int):

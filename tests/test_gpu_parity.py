@@ -198,6 +198,41 @@ def test_spare_hand_off_at_full_batch(goldens):
     b.close()
 
 
+@pytest.mark.parametrize("name,n,steps", [("mini", 16384, 500), ("default", 4096, 700)])
+def test_next_level_structures_match_inline_generation(goldens, name, n, steps):
+    """A descent whose next-level structure is ready (asked when a staircase came into the player's window, generated by k_regen from the env's dungeon
+    and item streams, valid iff the dungeon stream has not moved since) loads it and only runs the monster half of the generator; every other descent
+    generates the whole level inside the turn.  Same bits either way: the product against a handle with ROGUE_GYM_HIP_NO_NEXT_LEVELS, every env compared
+    -- and the structures were in fact used for most descents."""
+    import os
+
+    from rogue_gym_python import _rogue_gym as inner
+
+    cfgs = [json.dumps(dict(goldens["configs"][name], seed=i)) for i in range(n)]
+    a = inner._Handle(cfgs, 400, auto_reset=True)
+    os.environ["ROGUE_GYM_HIP_NO_NEXT_LEVELS"] = "1"
+    try:
+        b = inner._Handle(cfgs, 400, auto_reset=True)
+    finally:
+        del os.environ["ROGUE_GYM_HIP_NO_NEXT_LEVELS"]
+    rng = np.random.RandomState(13)
+    table = np.frombuffer(b"hjklyubnhjklyubn>>s.HJKL", np.uint8)
+    for t in range(steps):
+        keys = np.ascontiguousarray(table[rng.randint(0, len(table), n)])
+        for h in (a, b):
+            h.check(h.L.rg_step(h.h, keys.ctypes.data, 0))
+        if t % 5 == 4 or t > steps - 4:
+            for x, y, what in zip(a.fetch(), b.fetch(), ("screen", "hist", "status", "flags")):
+                assert np.array_equal(x, y), (t, what, [i for i in range(n) if not np.array_equal(x[i], y[i])][:8])
+    ca, cb = (ctypes.c_uint64 * 9)(), (ctypes.c_uint64 * 9)()
+    a.check(a.L.rg_counters_ex(a.h, ca, 9, 0))
+    b.check(b.L.rg_counters_ex(b.h, cb, 9, 0))
+    assert list(ca)[:3] == list(cb)[:3] and ca[1] > 300, (list(ca), list(cb))  # (resets, descents, dist maps: the same game; [3] / [4] depend on when a spare was ready)
+    assert cb[8] == 0 and ca[8] > 0.5 * ca[1], (list(ca), list(cb))  # [8]: descents that loaded their structure
+    a.close()
+    b.close()
+
+
 def test_frequent_descents_with_monsters(goldens):
     """A policy that presses '>' often: descents with monsters around, and descents in consecutive steps (the player can be placed on the
     stairs) -- after the second one the reference's history plane shows the level that was just discarded, not the one before it."""
