@@ -2532,22 +2532,22 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     if (live && stair_role != 1) win_load(c, E.cell, w, E.px, E.py);
     else { w.inb = 0; w.dirty = 0; w.ox = w.oy = 0; }
     pf.mark(26);
+    if (live && act == ACT_DOWNSTAIR) {
+        if (stair_role == 1 || (WV(w, WIN_K(0, 0)) & C_SURF_MASK) == S_STAIR) {
+            need_gen = descends = true;
+            react |= R_REDRAW | R_STATUS | R_HIST_STALE;  // Redraw precedes StatusUpdated: history keeps the old level
+        } else react |= MSG_NO_DOWNSTAIR;
+    }
     // Next-level structure (gen_service): a descending lane whose structure is READY and starts from the dungeon stream the env holds now loads it
     // instead of generating the first two thirds of the level
     if (S.nx_state) {
-        if (live && act == ACT_DOWNSTAIR && nxs == RG_NX_READY) {
+        if (descends && nxs == RG_NX_READY) {  // (only a real descent pays the round trip: every wave has a lane that presses '>' somewhere off the stairs)
             const uint32_t *q = S.nx_rng + e;
             const size_t n = (size_t)S.n;
             const uint32_t k0 = q[0], k1 = q[n], k2 = q[2 * n], kl = S.nx->level[e];  // (the fourth word was compared when the env was loaded)
             if (k0 == E.rd.x && k1 == E.rd.y && k2 == E.rd.z && kl == E.dlevel) nxs = RG_NX_HIT;
         }
         if (__any(nxs == RG_NX_HIT)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // pairs with k_regen's hand-off (sc1 payload, drained, then nx_state = READY)
-    }
-    if (live && act == ACT_DOWNSTAIR) {
-        if (stair_role == 1 || (WV(w, WIN_K(0, 0)) & C_SURF_MASK) == S_STAIR) {
-            need_gen = descends = true;
-            react |= R_REDRAW | R_STATUS | R_HIST_STALE;  // Redraw precedes StatusUpdated: history keeps the old level
-        } else react |= MSG_NO_DOWNSTAIR;
     }
     {   // Two descents in a row: the first one's Redraw kept the older level's history (HIST_STALE), so the mirror never showed the level that
         // is about to be discarded -- but the reference shows exactly that level's history after the second descent.  Write it now.
