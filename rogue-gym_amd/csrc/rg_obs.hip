@@ -195,7 +195,12 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // handle's): compiled separately so that the ordinary kernel carries none of it (its 72 registers = 7 waves per SIMD are what its bandwidth rests on)
 template <int KIND, bool GROUPS>
 __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint32_t sflag, int with_hist, float *__restrict__ out,
-                                                    uint32_t *__restrict__ err_any, int tpe, int epb, int planes_sym) {
+                                                    uint32_t *__restrict__ err_any, int tpe, int epb, int planes_sym, int hi_prio) {
+    // Wide grids: above the background generator's waves (k_regen, priority 0), which otherwise take issue slots from this bandwidth-bound pass for as long
+    // as the two overlap (80x24: 79.9 -> 75.2 us, 222 -> 229 M).  Not where the step kernel is the capped two-waves-per-SIMD instance (W <= 32): generator waves
+    // held back here are still resident when the next k_step starts, and there a resident generator wave keeps a step block waiting for its registers
+    // (mini: k_obs 46.7 -> 45.6 us but k_step 55.7 -> 60.3 us; profiles/r04_experiments.txt).
+    if (hi_prio) __builtin_amdgcn_s_setprio(3);
     extern __shared__ __align__(16) uint8_t smem[];
     float *lutf = reinterpret_cast<float *>(smem);        // glyph -> gray value (KIND 0)
     uint8_t *luts = smem + 512;                            // glyph -> symbol id
@@ -477,8 +482,9 @@ int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, 
         if (blocks > cap) blocks = cap;
     }
     const bool groups = S->ext != nullptr;
-#define RG_LAUNCH_OBS(...) do { if (ev0 || ev1) hipExtLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(bthreads), (uint32_t)smem, st, ev0, ev1, 0, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym); \
-                               else hipLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym); } while (0)
+    const int hi_prio = !(c->width <= 32 && c->room_num_x * c->room_num_y <= 32);  // (rg_kernels.hip rgk_step: those configs step with k_step_w32)
+#define RG_LAUNCH_OBS(...) do { if (ev0 || ev1) hipExtLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(bthreads), (uint32_t)smem, st, ev0, ev1, 0, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym, hi_prio); \
+                               else hipLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym, hi_prio); } while (0)
     if (!kind && !groups) RG_LAUNCH_OBS(k_obs<0, false>);
     else if (!kind) RG_LAUNCH_OBS(k_obs<0, true>);
     else if (!groups) RG_LAUNCH_OBS(k_obs<1, false>);
