@@ -513,8 +513,8 @@ def main():
                         "event_sampling": "every %d-th launch of each kernel carries a HIP-event pair stamped with the dispatch's own begin / end (hipExtLaunchKernelGGL on the launch stream; k_regen on its side stream)" % every,
                         "note": "roofline.achieved = %d algorithmic B/env-step x %d envs / avg %s duration (the contract's definition: it charges the whole step's "
                                 "bytes to the dominant kernel); frac_end_to_end = the same bytes / ms_per_step; per_kernel has every kernel's own algorithmic share. "
-                                "k_step is latency / instruction-issue / divergence-bound, k_obs is the HBM-side kernel, k_regen (background level generation, beside "
-                                "every second k_step) is scalar-unit-bound." % (hz.algo_bytes, n, dom)},
+                                "k_step is latency / instruction-issue / divergence-bound, k_obs is the HBM-side kernel, k_regen (background level generation: spare level-1 "
+                                "states and next-level structures, one launch beside every k_step) is scalar-unit-bound." % (hz.algo_bytes, n, dom)},
             "workload_rates": {"per": "whole job, per second (rank 0's counters x n_gpus)",
                                **{k + "_per_s": v * world / dt_max for k, v in counts.items()},
                                "per_batch_step": {k: v / K for k, v in counts.items()}},
