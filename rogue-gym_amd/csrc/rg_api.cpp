@@ -29,7 +29,7 @@ static const ncclDataType_t ncclUint8 = 1;
 
 extern "C" {
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st);
-void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+int rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 void rgk_probe_clock(unsigned long long *out, int spin, hipStream_t st);
 void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, const uint32_t *mark, uint32_t target, uint32_t *err_any, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st);
@@ -556,7 +556,7 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
     {   // stair isolation (rg_kernels.hip, k_step): on unless ROGUE_GYM_HIP_NO_STAIR_WAVES is set (the A/B knob of DESIGN.md's measurement)
         TimedLaunch t(h, 0, true);
         h->S.stair_gen = h->stair_gen++;  // reads the stair set its predecessor produced, produces the next one
-        rgk_step(&h->S, h->d_SP, &h->cfg, dk, h->spares ? 1 : 0, no_stair_waves ? -1 : 0, h->stream, t.start_ev(), t.stop_ev());
+        (void)rgk_step(&h->S, h->d_SP, &h->cfg, dk, h->spares ? 1 : 0, no_stair_waves ? -1 : 0, h->stream, t.start_ev(), t.stop_ev());
     }
     HIPCHK(h, hipGetLastError());
     if (regen) {

@@ -2848,7 +2848,7 @@ int rgk_step_epw(int n, int slots_per_simd) {
     if (epw_env >= 16 && epw_env <= 64) epw = epw_env;  // (>= 16: S.stats has one row per block of the largest grid, STAIR_BLOCKS + ceil(n / 16); rg_api.cpp)
     return epw;
 }
-void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+int rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw, c->room_num_x * c->room_num_y);  // the generator's staging grid + tables (inline descents, spare misses), shared with ...
     const bool n32 = c->width <= 96 && hw <= 4096;  // BFS rows as 32-bit words in registers (bfs_rows_n32): no LDS planes
@@ -2881,6 +2881,7 @@ void rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const 
     else if (c->width <= 128) RG_LAUNCH_STEP(k_step<3>);
     else RG_LAUNCH_STEP(k_step<4>);
 #undef RG_LAUNCH_STEP
+    return (int)grid.x;
 }
 void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st) {
     int hw = c->width * c->height;
