@@ -873,12 +873,6 @@ __device__ __forceinline__ void gen_populate(const RgState &S, const RgConfig &c
     if (!c.hide_dungeon)
         for (int i = W + (int)threadIdx.x; i < (H - 1) * W; i += WAVE) cell[i] |= C_VISIBLE;  // rows 1..H-2
 }
-template <int GM>
-__device__ __forceinline__ typename RoomSet<GM>::type gen_level(const RgState &S, const RgConfig &c, Env &E, Prof &pf) {
-    const typename RoomSet<GM>::type non_empty = gen_structure<GM>(S, c, E, pf);
-    gen_populate<GM>(S, c, E, pf);
-    return non_empty;
-}
 
 // actions::new_level's tail (actions.rs:130-137): place the player and enter the room
 template <int GM>
@@ -1043,10 +1037,17 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
 #ifdef RG_FINE_PROF
         U.pfp = &pf;
 #endif
+        // ONE site each for the two halves of the generator, whatever the request (whole level, structure alone, level from a structure): a second
+        // inlined copy of either was 25 KB of code in k_regen and 6-8 KB in every step kernel -- instruction-cache space the turn code needs
+        typename RoomSet<GM>::type non_empty;
+        bool loaded = false;
+        if constexpr (GM < 2) {
+            if ((from_nx >> src) & 1ull) { non_empty = load_structure<GM>(S, c, U, real_e, real_n, T); loaded = true; }
+        }
+        if (!loaded) non_empty = gen_structure<GM>(L, c, U, pf);
         if constexpr (GM < 2) {
             if (so) {  // the structure alone, written through to the env's nx_* arrays with the stream it started from (k_regen)
                 const RgNext NX = *S.nx;
-                (void)gen_structure<GM>(L, c, U, pf);
                 if (lane < nrooms) { T->room_rect[lane] = U.g_rect; T->room_meta[lane] = (uint8_t)U.g_meta; }
                 __syncthreads();
                 if (lane < nrooms) {
@@ -1075,16 +1076,7 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
                 continue;
             }
         }
-        typename RoomSet<GM>::type non_empty;
-        bool loaded = false;
-        if constexpr (GM < 2) {
-            if ((from_nx >> src) & 1ull) {
-                non_empty = load_structure<GM>(S, c, U, real_e, real_n, T);
-                gen_populate<GM>(L, c, U, pf);
-                loaded = true;
-            }
-        }
-        if (!loaded) non_empty = gen_level<GM>(L, c, U, pf);
+        gen_populate<GM>(L, c, U, pf);
         pf.mark(17);
         if (is_build) build_epilogue(L, c, U);
         place_player<GM>(L, c, U, non_empty);
