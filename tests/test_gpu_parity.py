@@ -198,7 +198,8 @@ def test_spare_hand_off_at_full_batch(goldens):
     b.close()
 
 
-@pytest.mark.parametrize("name,n,steps", [("mini", 16384, 500), ("default", 4096, 700)])
+@pytest.mark.parametrize("name,n,steps", [("mini", 16384, 500), ("default", 4096, 700), ((160, 48, 8, 5), 2048, 300), ((50, 21, 3, 2), 4096, 400)],
+                         ids=["mini", "default", "160x48, 40 rooms (the 64-room generator instance)", "50x21 (cells not a multiple of 8)"])
 def test_next_level_structures_match_inline_generation(goldens, name, n, steps):
     """A descent whose next-level structure is ready (asked when a staircase came into the player's window, generated by k_regen from the env's dungeon
     and item streams, valid iff the dungeon stream has not moved since) loads it and only runs the monster half of the generator; every other descent
@@ -208,7 +209,12 @@ def test_next_level_structures_match_inline_generation(goldens, name, n, steps):
 
     from rogue_gym_python import _rogue_gym as inner
 
-    cfgs = [json.dumps(dict(goldens["configs"][name], seed=i)) for i in range(n)]
+    if isinstance(name, tuple):
+        base = dict(goldens["configs"]["default"], width=name[0], height=name[1])
+        base["dungeon"] = dict(base.get("dungeon", {}), style="rogue", room_num_x=name[2], room_num_y=name[3])
+    else:
+        base = goldens["configs"][name]
+    cfgs = [json.dumps(dict(base, seed=i)) for i in range(n)]
     a = inner._Handle(cfgs, 400, auto_reset=True)
     os.environ["ROGUE_GYM_HIP_NO_NEXT_LEVELS"] = "1"
     try:
@@ -227,7 +233,7 @@ def test_next_level_structures_match_inline_generation(goldens, name, n, steps):
     ca, cb = (ctypes.c_uint64 * 9)(), (ctypes.c_uint64 * 9)()
     a.check(a.L.rg_counters_ex(a.h, ca, 9, 0))
     b.check(b.L.rg_counters_ex(b.h, cb, 9, 0))
-    assert list(ca)[:3] == list(cb)[:3] and ca[1] > 300, (list(ca), list(cb))  # (resets, descents, dist maps: the same game; [3] / [4] depend on when a spare was ready)
+    assert list(ca)[:3] == list(cb)[:3] and ca[1] > (300 if not isinstance(name, tuple) else 30), (list(ca), list(cb))  # (resets, descents, dist maps: the same game; [3] / [4] depend on when a spare was ready)
     assert cb[8] == 0 and ca[8] > 0.5 * ca[1], (list(ca), list(cb))  # [8]: descents that loaded their structure
     a.close()
     b.close()
