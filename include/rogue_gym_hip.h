@@ -105,6 +105,12 @@ int rg_flags(rg_t *h, uint32_t **dev);
 int rg_reward(rg_t *h, float **dev);
 int rg_done(rg_t *h, uint8_t **dev);
 
+/* StairRewardParallel (python/rogue_gym/envs/wrappers.py:45-64) fused into the step kernel: from the next rg_step on, `bonus` is added to
+ * reward[e] whenever the dungeon level env e reports after the key is above the level it reported one step earlier (the comparison level
+ * follows the reported one, so it is back at 1 after an auto-reset: a descent that ends the episode pays nothing, exactly as the wrapper).
+ * The bonus is part of the reward mirror and of the compact record (rg_pack_compact / rg_allgather_compact).  0 (the default) = off. */
+int rg_set_stair_reward(rg_t *h, float bonus);
+
 /* PlayerState::gray_image[_with_hist] / symbol_image[_with_hist] for the whole batch
  * (python/src/lib.rs:72-111,162-205; flags.rs:88-115; symbol.rs:17-71), written straight into
  * out_dev = f32 [n_env][C][H][W] with C = 1 (gray) or `symbols` (one-hot) + popcount(status_flag)

@@ -600,6 +600,12 @@ int rg_status(rg_t *h, int32_t **dev) { *dev = h->S.status; return 0; }
 int rg_flags(rg_t *h, uint32_t **dev) { HIPCHK(h, hipSetDevice(h->device)); if (flush_mirrors(h)) return 1; *dev = h->S.flags; return 0; }
 int rg_reward(rg_t *h, float **dev) { *dev = h->S.reward; return 0; }
 int rg_done(rg_t *h, uint8_t **dev) { *dev = h->S.done; return 0; }
+int rg_set_stair_reward(rg_t *h, float bonus) {
+    if (!(bonus == bonus) || bonus < 0.f) { h->err = "rg_set_stair_reward: the bonus must be a number >= 0"; return 1; }
+    h->S.stair_reward = bonus;  // (a kernel argument of the next rg_step: nothing to upload)
+    for (rg_handle *sh : h->sub) sh->S.stair_reward = bonus;
+    return 0;
+}
 
 int rg_obs_channels(const rg_t *h, int symbol, uint32_t status_flag, int with_hist) {
     return (symbol ? h->planes_sym : 1) + __builtin_popcount(status_flag & 0x1ffu) + (with_hist ? 1 : 0);

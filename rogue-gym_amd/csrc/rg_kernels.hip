@@ -2709,7 +2709,11 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         // (store -> load -> store, ~2 us) at the very end of every wave
         const int gold_before = gold0;
         const int gold_after = ((terminal && c.auto_reset) || (react & R_STATUS)) ? (int)E.gold : gold_before;
-        S.reward[e] = (float)(gold_after - gold_before > 0 ? gold_after - gold_before : 0);
+        // ... plus the stair bonus of StairRewardParallel (wrappers.py:45-64; rg_set_stair_reward): "the reported level is above the one reported a step earlier".
+        // The reported level is the status mirror's, which follows E.dlevel (a descent is a status reaction; a reset rewrites it with level 1): it rises in
+        // exactly the steps that descend and do not end in an auto-reset -- both known in registers, no level array, no extra pass.
+        const float bonus = (descends && !(terminal && c.auto_reset)) ? S.stair_reward : 0.f;
+        S.reward[e] = (float)(gold_after - gold_before > 0 ? gold_after - gold_before : 0) + bonus;
     }
     // the stair set for the NEXT k_step: where does this env's player stand now?  A level generated in this turn reported it (place_player), a taken
     // spare carries it, otherwise it is the tile under the player in the window (centred on where the last move started; the player is within one cell)
@@ -2836,7 +2840,7 @@ int rgk_step_epw(int n, int slots_per_simd) {
     static const int epw_env = getenv("ROGUE_GYM_HIP_EPW") ? atoi(getenv("ROGUE_GYM_HIP_EPW")) : 0;
     int epw = WAVE;
     while (epw > 16 && (n + epw - 1) / epw < 1024) epw >>= 1;
-    if (slots_per_simd < 2 && epw < WAVE && (n + epw - 1) / epw > 1008) epw = (n + 1007) / 1008;
+    if (slots_per_simd < 2 && epw < WAVE && (n + epw - 1) / epw > 1008) { epw = (n + 1007) / 1008; if (epw > WAVE) epw = WAVE; }  // (n = 64 513..65 472 gave 65: a lane per env, never more)
     if (epw_env >= 16 && epw_env <= 64) epw = epw_env;  // (>= 16: S.stats has one row per block of the largest grid, STAIR_BLOCKS + ceil(n / 16); rg_api.cpp)
     return epw;
 }

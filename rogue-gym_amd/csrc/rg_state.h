@@ -152,4 +152,7 @@ struct RgState {
     uint32_t *err_any;  // [1] OR of every error bit raised since the last rg_sync
     // ThreadConductor::step zips keys with envs (thread_impls.rs:62-64): envs >= n_keys receive no key this call
     int32_t n_keys;
+    // StairRewardParallel (python/rogue_gym/envs/wrappers.py:45-64) inside the step: added to reward[e] whenever the level the env reports after the key is
+    // above the one it reported one step earlier (rg_set_stair_reward; 0 = off)
+    float stair_reward;
 };

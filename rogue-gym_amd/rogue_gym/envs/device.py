@@ -246,22 +246,11 @@ class HipVecRogueEnv:
 
 
 class HipVecStairReward(HipVecRogueEnv):
-    """StairRewardParallel (python/rogue_gym/envs/wrappers.py:45-64) on device tensors: `stair_reward` is added whenever an env's
-    dungeon level is above the level it reported one step earlier; the comparison level follows the reported one (so it falls back to 1
-    with the auto-reset).  The reward is a new tensor; nothing leaves the GPU."""
+    """StairRewardParallel (python/rogue_gym/envs/wrappers.py:45-64) on device tensors.  The rule -- `stair_reward` whenever an env reports a deeper
+    level than one step earlier, the comparison level following the auto-reset back to 1 -- runs inside the step kernel (rg_set_stair_reward): `reward`
+    is the same device tensor as without the wrapper, no extra launch, and the all-gathered records carry the bonus too."""
 
     def __init__(self, *args, stair_reward: float = 50.0, **kwargs):
         super().__init__(*args, **kwargs)
         self.stair_reward = float(stair_reward)
-        self.current_levels = self.torch.ones(self.num_envs, dtype=self.torch.int32, device=self.device)
-
-    def step_keys(self, keys):
-        obs, reward, done = super().step_keys(keys)
-        level = self.status[:, 0]
-        reward = reward + self.stair_reward * (self.current_levels < level).to(reward.dtype)
-        self.current_levels.copy_(level)
-        return obs, reward, done
-
-    def reset(self):
-        self.current_levels.fill_(1)
-        return super().reset()
+        self._h.check(self._h.L.rg_set_stair_reward(self._h.h, self.stair_reward))

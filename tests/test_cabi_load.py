@@ -187,3 +187,17 @@ def test_default_build_reads_only_the_documented_knobs():
     tests = "".join(open(os.path.join(ROOT, "tests", f)).read() for f in os.listdir(os.path.join(ROOT, "tests")) if f.endswith(".py"))
     for k in allowed:
         assert k in tests, "knob %s is not exercised by any test" % k
+
+
+def test_step_wave_occupancy_never_exceeds_a_wave(lib):
+    """rgk_step_epw (envs per index-order wave of k_step): a wave has 64 lanes, so 16 <= epw <= 64 for every batch size and both slot classes, and
+    the index-order blocks cover every env.  (n = 64 513..65 472 with one slot per SIMD once gave 65: env 64 of every block was never stepped.)"""
+    f = lib.rgk_step_epw
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_int]
+    sizes = list(range(1, 4097)) + list(range(60000, 70000)) + [1 << k for k in range(12, 21)] + [32768 + d for d in range(-70, 70)] + [262144, 1000000]
+    for slots in (1, 2):
+        for n in sizes:
+            epw = f(n, slots)
+            assert 16 <= epw <= 64, (n, slots, epw)
+            assert ((n + epw - 1) // epw) * epw >= n

@@ -845,3 +845,51 @@ def test_kept_spares_give_identical_episodes(goldens):
     assert cf[0] > 2000 and len(starts) == 256 and sum(len(v) >= 8 for v in starts.values()) >= 250, (list(cf), sorted(len(v) for v in starts.values())[:10])
     for h in (plain, kept, fresh):
         h.close()
+
+
+@pytest.mark.gpu
+def test_stair_reward_through_the_cabi_alone(goldens):
+    """rg_set_stair_reward (StairRewardParallel, wrappers.py:45-64, inside k_step) for a host that binds nothing but the C-ABI: the reward mirror after every
+    step == the wrapper's rule applied to the ORACLE's reported gold and level -- a stairs-seeking policy with a short max_steps, so that descents, gold
+    pickups, auto-resets and descents that END an episode (no bonus: the reported level is back at 1) all occur.  The compact record carries the same
+    number."""
+    from test_gpu_parity import _stair_seeker_keys
+    cfg = dict(goldens["configs"]["mini"])
+    cfg["enemies"] = {"enemies": []}
+    n, bonus = 192, 7.5
+    hip = HipBatch(cfg, range(n), max_steps=45)
+    L, h = hip.h.L, hip.h.h
+    assert L.rg_set_stair_reward(h, C.c_float(-1.0)) != 0  # refused, and the handle keeps working
+    hip.h.check(L.rg_set_stair_reward(h, bonus))
+    oracles = make_oracles(cfg, range(n), max_steps=45)
+    rng = np.random.RandomState(5)
+    stuck = [0] * n
+    p = C.c_void_p()
+    hip.h.check(L.rg_reward(h, C.byref(p)))
+    rec = L.rg_compact_record_bytes(h, 0)
+    packed_dev = C.c_void_p()
+    assert L.rg_dev_alloc(hip.h.device, n * rec, C.byref(packed_dev)) == 0
+    paid = 0
+    for t in range(260):
+        keys = _stair_seeker_keys(oracles, rng, stuck)
+        before = [(int(o.status_arr()[1]), int(o.status_arr()[0])) for o in oracles]
+        hip.step(keys)
+        exp = np.zeros(n, np.float32)
+        for i, o in enumerate(oracles):
+            o.step_autoreset(int(keys[i]))
+            st = o.status_arr()
+            exp[i] = max(0, int(st[1]) - before[i][0]) + (bonus if int(st[0]) > before[i][1] else 0.0)
+            paid += int(st[0]) > before[i][1]
+        got = np.empty(n, np.float32)
+        hip.h.check(L.rg_dev_read(h, p, got.ctypes.data, 4 * n))
+        assert np.array_equal(got, exp), (t, np.nonzero(got != exp)[0][:8], got[got != exp][:8], exp[got != exp][:8])
+        if t % 16 == 0:
+            hip.h.check(L.rg_pack_compact(h, 0, packed_dev))
+            host = np.empty((n, rec), np.uint8)
+            hip.h.check(L.rg_dev_read(h, packed_dev, host.ctypes.data, n * rec))
+            hw = hip.h.height * hip.h.width
+            assert np.array_equal(host[:, hw + 40:hw + 44].copy().view(np.float32)[:, 0], exp)
+    L.rg_dev_free(hip.h.device, packed_dev)
+    hip.sync()
+    compare_mirrors(hip, oracles, "end")
+    assert paid >= 200
