@@ -12,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "librogue_oracle.so")
+_SO_OVERRIDE = os.environ.get("ROGUE_ORACLE_SO")  # tests/test_oracle_mutations.py: a mutant build of the same source (-DORC_MUTANT=k), loaded instead
 
 
 class OrcMonStat(C.Structure):
@@ -80,6 +81,8 @@ class OrcMonster(C.Structure):
 
 
 def build(force=False):
+    if _SO_OVERRIDE:
+        return _SO_OVERRIDE
     src = [os.path.join(_HERE, f) for f in ("rogue_oracle.c", "rogue_oracle.h")]
     if force or not os.path.exists(_SO) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in src
@@ -113,7 +116,7 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_SO)
+        L = C.CDLL(_SO_OVERRIDE or _SO)
         L.orc_new.restype = C.c_void_p
         L.orc_new.argtypes = [C.POINTER(OrcConfig), C.c_uint64]
         L.orc_free.argtypes = [C.c_void_p]

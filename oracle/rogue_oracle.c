@@ -44,7 +44,7 @@ static uint32_t range32(rng_t *r, uint32_t low, uint32_t high) {
         if ((uint32_t)m <= zone) return low + (uint32_t)(m >> 32);
     }
 }
-static int32_t range_i32(rng_t *r, int32_t low, int32_t high) {
+static int32_t __attribute__((unused)) range_i32(rng_t *r, int32_t low, int32_t high) {
     return (int32_t)range32(r, (uint32_t)low, (uint32_t)high);
 }
 /* gen_range for usize / i64 call sites (64-bit) */
@@ -56,8 +56,28 @@ static uint64_t range64(rng_t *r, uint64_t low, uint64_t high) {
         if ((uint64_t)m <= zone) return low + (uint64_t)(m >> 64);
     }
 }
-static int does_happen(rng_t *r, uint32_t p_inv) { return range32(r, 0, p_inv) == 0; } /* rng.rs:91 */
-static int parcent(rng_t *r, uint32_t p) { return range32(r, 1, 101) <= p; }            /* rng.rs:95 */
+static int __attribute__((unused)) does_happen(rng_t *r, uint32_t p_inv) { return range32(r, 0, p_inv) == 0; } /* rng.rs:91 (call sites: DH) */
+static int __attribute__((unused)) parcent(rng_t *r, uint32_t p) { return range32(r, 1, 101) <= p; } /* rng.rs:95 (the call sites carry their mutant number: PC) */
+
+/* ------------------------------------------------------------------------------------------ */
+/* Mutation testing (tests/test_oracle_mutations.py).  -DORC_MUTANT=k builds this file with ONE  */
+/* plausible misreading of the reference at RNG call site / quirk k; the   */
+/* test runs the reference's goldens against every mutant and records which golden notices --     */
+/* the sites nobody notices are the ones where "HIP == oracle" rests on the reading alone          */
+/* (profiles/r05_pin_map.txt).  0 = the restatement itself; the product never sees any of this.    */
+/* ------------------------------------------------------------------------------------------ */
+#ifndef ORC_MUTANT
+#define ORC_MUTANT 0
+#endif
+#define MUT(k) (ORC_MUTANT == (k))
+int orc_mutant_id(void) { return ORC_MUTANT; }
+/* the reference samples a 32-bit type at site k (one next_u32 per attempt); the mutant samples 64 bits -- and the other way round */
+static uint32_t w32(int mut, rng_t *r, uint32_t lo, uint32_t hi) { return mut ? (uint32_t)range64(r, lo, hi) : range32(r, lo, hi); }
+static uint64_t w64(int mut, rng_t *r, uint64_t lo, uint64_t hi) { return mut ? (uint64_t)range32(r, (uint32_t)lo, (uint32_t)hi) : range64(r, lo, hi); }
+#define W32(k, r, lo, hi) w32(MUT(k), (r), (uint32_t)(lo), (uint32_t)(hi))
+#define W64(k, r, lo, hi) w64(MUT(k), (r), (uint64_t)(lo), (uint64_t)(hi))
+#define DH(k, r, p) (W32(k, r, 0, p) == 0)       /* does_happen at site k */
+#define PC(k, r, p) (W32(k, r, 1, 101) <= (p))   /* parcent at site k */
 
 /* ------------------------------------------------------------------------------------------ */
 /* geometry: rect-iter RectRange<i32> (half-open, row-major x fastest),
@@ -256,11 +276,12 @@ static int set_nth(const uint8_t *s, int cap, int n) { /* FenwickSet::nth (fenwi
     return -1;
 }
 /* FenwickSet::select (fenwick.rs:88-94): usize sample => 64-bit */
-static int set_select(const uint8_t *s, int cap, rng_t *r) {
+static int set_select_m(const uint8_t *s, int cap, rng_t *r, int mut) {
     int n = set_len(s, cap);
     if (n == 0) return -1;
-    return set_nth(s, cap, (int)range64(r, 0, (uint64_t)n));
+    return set_nth(s, cap, (int)w64(mut, r, 0, (uint64_t)n));
 }
+
 
 static void room_free(room_t *rm) { free(rm->empty_cells); free(rm->nochar_cells); free(rm->maze_passages); rm->empty_cells = rm->nochar_cells = rm->maze_passages = NULL; }
 
@@ -283,7 +304,7 @@ static void room_init_sets(room_t *rm) {
 /* Room::select_cell (rooms.rs:126-144) */
 static int room_select_cell(const room_t *rm, rng_t *r, int is_character, int *x, int *y) {
     if (rm->kind == RK_EMPTY) return 0;
-    int n = set_select(is_character ? rm->nochar_cells : rm->empty_cells, rm->cap, r);
+    int n = set_select_m(is_character ? rm->nochar_cells : rm->empty_cells, rm->cap, r, MUT(24)); /* M24 rooms.rs:134 */
     if (n < 0) return 0;
     rect_nth(&rm->range, n, x, y);
     return 1;
@@ -313,7 +334,7 @@ static void dig_impl(const rect_t *range, rng_t *r, uint8_t *used /* by range in
         for (int d = 0; d < 4; d++) { /* Direction::into_enum_iter().take(4) */
             int nx = cx + 2 * DX[d], ny = cy + 2 * DY[d];
             if (!rect_contains(range, nx, ny) || used[rect_index(range, nx, ny)]) continue;
-            if (does_happen(r, (uint32_t)i + 1)) dig = d; /* .enumerate().filter(does_happen(i+1)).last() */
+            if (DH(9, r, (uint32_t)i + 1) && !(MUT(10) && dig >= 0)) dig = d; /* .enumerate().filter(does_happen(i+1)).last()   M9 maze.rs:73 width, M10 first instead of last */
             i++;
         }
         if (dig < 0) break;
@@ -338,23 +359,24 @@ static void make_room(orc_env *e, room_t *rm, int is_empty, int rsx, int rsy, in
     rm->id = id;
     rm->assigned = (rect_t){llx, lly, llx + rsx, lly + rsy};
     if (is_empty) { /* rooms.rs:224-236: x then y (TupleMap2::map order) */
-        int x = range_i32(r, 1, rsx - 1) + llx;
-        int y = range_i32(r, 1, rsy - 1) + lly;
+        int x, y; /* M3 rooms.rs:226 width, M4 y drawn before x */
+        if (MUT(4)) { y = (int)W32(3, r, 1, rsy - 1) + lly; x = (int)W32(3, r, 1, rsx - 1) + llx; }
+        else { x = (int)W32(3, r, 1, rsx - 1) + llx; y = (int)W32(3, r, 1, rsy - 1) + lly; }
         rm->kind = RK_EMPTY; rm->is_dark = 1; rm->upx = x; rm->upy = y;
         room_init_sets(rm);
         return;
     }
-    rm->is_dark = range32(r, 0, c->dark_level) < level;
-    if (rm->is_dark && does_happen(r, c->maze_rate_inv)) {
+    rm->is_dark = W32(5, r, 0, c->dark_level) < level; /* M5 rooms.rs:237 width */
+    int maze_roll = MUT(52) ? DH(6, r, c->maze_rate_inv) : 0; /* M52: the maze draw taken whether or not the room is dark */
+    if (rm->is_dark && (MUT(52) ? maze_roll : DH(6, r, c->maze_rate_inv))) { /* M6 rooms.rs:238 width */
         rm->kind = RK_MAZE;
         rm->range = (rect_t){llx, lly, llx + rsx - 1, lly + rsy - 1};
         rm->maze_passages = calloc(rect_len(&rm->range), 1);
         dig_maze(&rm->range, r, rm->maze_passages);
     } else {
-        int sx = range_i32(r, c->min_room_x, rsx);
-        int sy = range_i32(r, c->min_room_y, rsy);
-        int ox = range_i32(r, 0, rsx - sx) + llx;
-        int oy = range_i32(r, 0, rsy - sy) + lly;
+        int sx, sy, ox, oy; /* M7 rooms.rs:258,262 width; M8 size x, offset x, size y, offset y instead of both sizes first */
+        if (MUT(8)) { sx = (int)W32(7, r, c->min_room_x, rsx); ox = (int)W32(7, r, 0, rsx - sx) + llx; sy = (int)W32(7, r, c->min_room_y, rsy); oy = (int)W32(7, r, 0, rsy - sy) + lly; }
+        else { sx = (int)W32(7, r, c->min_room_x, rsx); sy = (int)W32(7, r, c->min_room_y, rsy); ox = (int)W32(7, r, 0, rsx - sx) + llx; oy = (int)W32(7, r, 0, rsy - sy) + lly; }
         rm->kind = RK_NORMAL;
         rm->range = (rect_t){ox, oy, ox + sx, oy + sy};
     }
@@ -365,7 +387,7 @@ static void gen_rooms(orc_env *e, floor_t *fl, uint32_t level) {
     const orc_config *c = &e->cfg; rng_t *r = &e->rng_d;
     int rnx = c->room_num_x, rny = c->room_num_y, room_num = rnx * rny;
     int rsx0 = e->W / rnx, rsy0 = e->H / rny;
-    uint32_t empty_num = range32(r, 0, c->max_empty_rooms + 1);
+    uint32_t empty_num = W32(1, r, 0, c->max_empty_rooms + (MUT(53) ? 0 : 1)); /* M1 rooms.rs:179 width; M53 0..max instead of 0..=max */
     if (empty_num >= (uint32_t)room_num) empty_num = room_num - 1;
     uint8_t is_empty[MAX_ROOMS] = {0};
     { /* rng.select(0..room_num).take(empty_num) (rng.rs:59-73,121-143) */
@@ -373,7 +395,7 @@ static void gen_rooms(orc_env *e, floor_t *fl, uint32_t level) {
         for (int i = 0; i < room_num; i++) sel[i] = 1;
         for (uint32_t k = 0; k < empty_num; k++) {
             int rest = set_len(sel, room_num);
-            int n = (int)range64(r, 0, (uint64_t)rest);
+            int n = (int)W64(2, r, 0, (uint64_t)rest); /* M2 rooms.rs:189 width */
             int id = set_nth(sel, room_num, n);
             sel[id] = 0; is_empty[id] = 1;
         }
@@ -401,7 +423,7 @@ static void plist_push(plist_t *p, int x, int y, int kind) {
 }
 static uint64_t choose_index(orc_env *e, int len) { /* SliceRandom::choose (passages.rs:146,156) */
     if (e->cfg.choose_width == 32) return range32(&e->rng_d, 0, (uint32_t)len);
-    return range64(&e->rng_d, 0, (uint64_t)len);
+    return W64(20, &e->rng_d, 0, (uint64_t)len); /* M20 passages.rs:146,156 width */
 }
 /* edges() (passages.rs:181-219) */
 static int edges(const rect_t *range, int direction, int inclusive, int *xs, int *ys) {
@@ -446,19 +468,19 @@ static void select_start_or_end(orc_env *e, const room_t *rm, int direction, int
 static int door_kind(const room_t *rm) { return rm->kind == RK_NORMAL ? S_DOOR : S_PASSAGE; }
 /* connect_2rooms (passages.rs:84-133) */
 static void connect_2rooms(orc_env *e, const room_t *r1, const room_t *r2, int direction, plist_t *out) {
-    if (direction == D_UP || direction == D_LEFT) { const room_t *t = r1; r1 = r2; r2 = t; direction = dir_reverse(direction); }
+    if ((direction == D_UP || direction == D_LEFT)) { const room_t *t = r1; r1 = r2; r2 = t; direction = dir_reverse(direction); } /* (App. C-4) */
     int sx, sy, ex, ey;
-    select_start_or_end(e, r1, direction, &sx, &sy);
-    select_start_or_end(e, r2, dir_reverse(direction), &ex, &ey);
+    if (MUT(21)) { select_start_or_end(e, r2, dir_reverse(direction), &ex, &ey); select_start_or_end(e, r1, direction, &sx, &sy); } /* M21: end door drawn first */
+    else { select_start_or_end(e, r1, direction, &sx, &sy); select_start_or_end(e, r2, dir_reverse(direction), &ex, &ey); }
     plist_push(out, sx, sy, door_kind(r1));
     plist_push(out, ex, ey, door_kind(r2));
     int tsx, tsy, tex, tey, tdir;
     if (direction == D_DOWN) {
-        int y = range_i32(&e->rng_d, sy + 1, ey);
+        int y = (int)W32(22, &e->rng_d, sy + 1, ey + (MUT(23) ? 1 : 0)); /* M22 passages.rs:106 width, M23 inclusive upper bound */
         tdir = sx < ex ? D_RIGHT : D_LEFT;
         tsx = sx; tsy = y; tex = ex; tey = y;
     } else {
-        int x = range_i32(&e->rng_d, sx + 1, ex);
+        int x = (int)W32(22, &e->rng_d, sx + 1, ex + (MUT(23) ? 1 : 0)); /* passages.rs:115 */
         tdir = sy < ey ? D_DOWN : D_UP;
         tsx = x; tsy = sy; tex = x; tey = ey;
     }
@@ -486,7 +508,7 @@ static int select_candidate(orc_env *e, int num_rooms, int node, const uint8_t *
         if (excl[id]) continue;
         int d = graph_candidate(rnx, rny, node, id);
         if (d < 0) continue;
-        if (does_happen(&e->rng_d, (uint32_t)i + 1)) { res = id; *dir_out = d; }
+        if (DH(16, &e->rng_d, (uint32_t)i + 1)) { res = id; *dir_out = d; } /* M16 passages.rs:79 width */
         i++;
     }
     return res;
@@ -496,7 +518,7 @@ static void dig_passages(orc_env *e, floor_t *fl, plist_t *out) {
     static __thread uint8_t conn[MAX_ROOMS][MAX_ROOMS];
     memset(conn, 0, sizeof conn);
     uint8_t selected[MAX_ROOMS] = {0};
-    int cur = (int)range64(&e->rng_d, 0, (uint64_t)n), n_sel = 1;
+    int cur = (int)W64(14, &e->rng_d, 0, (uint64_t)n), n_sel = 1; /* M14 passages.rs:30 width */
     selected[cur] = 1;
     while (n_sel < n) {
         int dir = 0;
@@ -505,13 +527,14 @@ static void dig_passages(orc_env *e, floor_t *fl, plist_t *out) {
             selected[nxt] = 1; n_sel++;
             conn[cur][nxt] = conn[nxt][cur] = 1;
             connect_2rooms(e, &fl->rooms[cur], &fl->rooms[nxt], dir, out);
+            if (MUT(44)) cur = nxt; /* M44 App. C-4: the walk advances to the room it has just connected */
         } else {
-            cur = set_select(selected, n, &e->rng_d);
+            cur = set_select_m(selected, n, &e->rng_d, MUT(17)); /* M17 passages.rs:49 width */
         }
     }
-    uint32_t try_num = range32(&e->rng_d, 0, e->cfg.max_extra_edges);
+    uint32_t try_num = W32(18, &e->rng_d, 0, e->cfg.max_extra_edges + (MUT(19) ? 1 : 0)); /* M18 passages.rs:54 width, M19 0..=max */
     for (uint32_t t = 0; t < try_num; t++) {
-        int room1 = (int)range64(&e->rng_d, 0, (uint64_t)n), dir = 0;
+        int room1 = (int)W64(15, &e->rng_d, 0, (uint64_t)n), dir = 0; /* M15 passages.rs:56 width */
         int room2 = select_candidate(e, n, room1, conn[room1], &dir);
         if (room2 >= 0) {
             conn[room1][room2] = conn[room2][room1] = 1;
@@ -527,8 +550,15 @@ static void dig_passages(orc_env *e, floor_t *fl, plist_t *out) {
 static uint8_t gen_attr(orc_env *e, int surface, int is_dark, uint32_t level) {
     const orc_config *c = &e->cfg; rng_t *r = &e->rng_d;
     switch (surface) {
-    case S_PASSAGE: if (range32(r, 0, c->dark_level) < level && does_happen(r, c->hidden_passage_rate_inv)) return A_HIDDEN; return 0;
-    case S_DOOR:    if (range32(r, 0, c->dark_level) < level && does_happen(r, c->locked_door_rate_inv)) return A_LOCKED; return 0;
+    /* M11 floor.rs:430,437 width of the level draw, M12 :431,438 width of the rate draw, M13 the rate draw taken whatever the level draw said */
+    case S_PASSAGE:
+    case S_DOOR: {
+        const uint32_t rate = surface == S_PASSAGE ? c->hidden_passage_rate_inv : c->locked_door_rate_inv;
+        const uint8_t flag = surface == S_PASSAGE ? A_HIDDEN : A_LOCKED;
+        const int deep = W32(11, r, 0, c->dark_level) < level;
+        if (MUT(13)) { const int h = DH(12, r, rate); return deep && h ? flag : 0; }
+        return deep && DH(12, r, rate) ? flag : 0;
+    }
     case S_FLOOR:   return is_dark ? A_DARK : 0;
     default: return 0;
     }
@@ -569,7 +599,7 @@ static void gen_floor(orc_env *e, floor_t *fl, uint32_t level) {
         int id = IDX(e, pl.v[i].x, pl.v[i].y), s = pl.v[i].kind;
         if (s == S_DOOR) fl->doors[id] = 1;
         fl->attr[id] = gen_attr(e, s, 0, level);
-        if (!(fl->attr[id] & (A_HIDDEN | A_LOCKED))) fl->surface[id] = s;
+        if (MUT(45) || !(fl->attr[id] & (A_HIDDEN | A_LOCKED))) fl->surface[id] = s; /* M45 App. C-3: painted even when hidden / locked */
     }
     free(pl.v);
     for (int i = 0; i < fl->n_rooms; i++) fl->non_empty[i] = fl->rooms[i].kind != RK_EMPTY; /* Floor::new */
@@ -587,7 +617,7 @@ static int floor_select_cell(orc_env *e, floor_t *fl, int is_character, int *x, 
     uint8_t cand[MAX_ROOMS];
     memcpy(cand, fl->non_empty, fl->n_rooms);
     while (set_len(cand, fl->n_rooms) > 0) {
-        int idx = set_select(cand, fl->n_rooms, &e->rng_d);
+        int idx = set_select_m(cand, fl->n_rooms, &e->rng_d, MUT(25)); /* M25 floor.rs:337-339 room id width */
         if (room_select_cell(&fl->rooms[idx], &e->rng_d, is_character, x, y)) return 1;
         cand[idx] = 0;
     }
@@ -599,8 +629,10 @@ static void setup_items(orc_env *e, floor_t *fl, uint32_t level) {
     for (int i = 0; i < fl->n_rooms; i++) {
         room_t *rm = &fl->rooms[i]; int x, y;
         if (!room_select_cell(rm, &e->rng_d, 0, &x, &y)) continue;
-        if (!does_happen(&e->rng_i, c->gold_rate_inv)) continue;
-        uint32_t num = range32(&e->rng_i, 0, c->gold_base + c->gold_per_level * level) + c->gold_minimum;
+        /* M26 gold.rs:19 width, M27 gold.rs:22 width, M28 the amount drawn before the 1-in-2 roll, M29 the amount drawn on the DUNGEON stream */
+        uint32_t num = 0;
+        if (MUT(28)) { num = W32(27, &e->rng_i, 0, c->gold_base + c->gold_per_level * level) + c->gold_minimum; if (!DH(26, &e->rng_i, c->gold_rate_inv)) continue; }
+        else { if (!DH(26, &e->rng_i, c->gold_rate_inv)) continue; num = W32(27, MUT(29) ? &e->rng_d : &e->rng_i, 0, c->gold_base + c->gold_per_level * level) + c->gold_minimum; }
         room_fill(rm, x, y, 0);
         rm->has_gold = 1;
         fl->gold[IDX(e, x, y)] = (int32_t)num;
@@ -616,14 +648,14 @@ static void setup_stair(orc_env *e, floor_t *fl) {
 /* EnemyHandler::select / exp_add / gen_enemy (enemies.rs:265-320) */
 static int gen_enemy(orc_env *e, uint32_t min, uint32_t max, int64_t lev_add, int has_gold, mon_t *out) {
     const orc_config *c = &e->cfg; rng_t *r = &e->rng_e;
-    if (!parcent(r, has_gold ? c->appear_rate_gold : c->appear_rate_nogold)) return 0;
+    if (!PC(30, r, has_gold ? c->appear_rate_gold : c->appear_rate_nogold)) return 0; /* M30 enemies.rs:297 width */
     size_t len = (size_t)e->n_stats;
-    size_t idx = range32(r, min, max);
+    size_t idx = W32(31, r, min, max); /* M31 enemies.rs:266 width */
     if (idx > len) { size_t rg = len < 5 ? len : 5; idx = (size_t)range64(r, len - rg, len); }
     if (idx >= len) return 0; /* enemy_stats.get(idx)? */
     const mstat_t *st = &e->stats[idx];
     int64_t level = st->level + lev_add, hp = 0;
-    for (int i = 0; i < 8; i++) hp += (int64_t)range64(r, 1, (uint64_t)level + 1); /* Dice::new(8, level).exec::<i64> */
+    for (int i = 0; i < 8; i++) hp += (int64_t)W64(32, r, 1, (uint64_t)level + (MUT(33) ? 0 : 1)); /* Dice::new(8, level).exec::<i64>   M32 character/mod.rs:218 width, M33 1..level instead of 1..=level */
     int64_t base = level == 1 ? hp / 8 : hp / 6;
     uint32_t exp_add = level >= 10 ? (uint32_t)base * 20u : (uint32_t)base * 4u;
     memset(out, 0, sizeof *out);
@@ -694,7 +726,7 @@ static void enters_room(orc_env *e, int x, int y) {
     room_t *rm = &fl->rooms[id];
     if (rm->is_visited) return;
     rm->is_visited = 1;
-    if (!(rm->kind == RK_NORMAL && !rm->is_dark)) return;
+    if (!(rm->kind == RK_NORMAL && (MUT(67) || !rm->is_dark))) return; /* M67 App. C-7: dark rooms are lit up on entry too */
     for (int k = 0; k < rm->cap; k++) { int cx, cy; rect_nth(&rm->range, k, &cx, &cy); fl->attr[IDX(e, cx, cy)] |= A_DRAWN | A_VISIBLE; }
 }
 static void leaves_room(orc_env *e, int x, int y) {
@@ -721,7 +753,7 @@ static void player_in(orc_env *e, int x, int y, int init) {
         int cx = x + DX[d], cy = y + DY[d];
         if (!INB(e, cx, cy)) continue;
         int id = IDX(e, cx, cy);
-        if (!dir_is_diag(d) || fl->surface[id] != S_PASSAGE) { /* Cell::approached (field.rs:20-26) */
+        if (MUT(58) || !dir_is_diag(d) || fl->surface[id] != S_PASSAGE) { /* Cell::approached (field.rs:20-26)   M58 App. C-7: diagonal passages revealed too */
             if (fl->attr[id] & A_HIDDEN) continue;
             fl->attr[id] |= A_DRAWN | A_VISIBLE;
         }
@@ -736,7 +768,7 @@ static void player_out(orc_env *e, int x, int y) {
         int cx = x + DX[d], cy = y + DY[d];
         if (!INB(e, cx, cy)) continue;
         int id = IDX(e, cx, cy);
-        if (fl->surface[id] == S_FLOOR && (fl->attr[id] & A_DARK)) fl->attr[id] &= ~A_VISIBLE; /* Cell::left */
+        if (!MUT(66) && fl->surface[id] == S_FLOOR && (fl->attr[id] & A_DARK)) fl->attr[id] &= ~A_VISIBLE; /* Cell::left   M66 App. C-7: dark floor stays visible behind the player */
     }
 }
 /* Floor::in_same_room (floor.rs:381-393) */
@@ -810,6 +842,7 @@ static void new_level_(orc_env *e, int is_initial) {
         floor_free(&e->fl);
     }
     e->fl = nf;
+    if (MUT(47)) { for (int i = 0; i < e->n_dcache; i++) free(e->dcache[i].map); e->n_dcache = 0; } /* M47 App. C-11: the DistCache dropped with the level */
 }
 /* actions::new_level (actions.rs:121-138) */
 static void actions_new_level(orc_env *e, int is_init) {
@@ -838,13 +871,14 @@ static int move_enemy(orc_env *e, int cx, int cy, int tx, int ty, skip_fn skip, 
         if (skip(e, nx, ny)) continue;
         uint32_t nd = dist[IDX(e, nx, ny)];
         if (nd == 0 && can_move_impl(e, cx, cy, d, 1)) return MR_REACH;
-        if (nd != DIST_INF && nd > 0 && (!found || nd < best)) { best = nd; *ox = nx; *oy = ny; found = 1; } /* stable sort, first minimum */
+        if (MUT(48) && !can_move_impl(e, cx, cy, d, 1)) continue; /* M48 App. C-10: candidates checked for legality (no corner cutting) */
+        if (nd != DIST_INF && nd > 0 && (!found || (MUT(49) ? nd <= best : nd < best))) { best = nd; *ox = nx; *oy = ny; found = 1; } /* stable sort, first minimum; M49 last minimum */
     }
     return found ? MR_CANMOVE : MR_CANTMOVE;
 }
 /* Dungeon::move_enemy_randomly (rogue/mod.rs:376-397) */
 static int move_enemy_randomly(orc_env *e, int cx, int cy, int px, int py, skip_fn skip, int *ox, int *oy) {
-    int d = (int)range64(&e->rng_d, 0, 8);
+    int d = (int)W64(37, MUT(38) ? &e->rng_e : &e->rng_d, 0, 8); /* M37 rogue/mod.rs:383 width, M38 drawn on the ENEMY stream */
     int nx = cx + DX[d], ny = cy + DY[d];
     if (skip(e, nx, ny) || !can_move_impl(e, cx, cy, d, 1)) return MR_CANTMOVE;
     if (nx == px && ny == py) return MR_REACH;
@@ -874,8 +908,8 @@ static int player_arm(const orc_env *e) { return e->armor < 0 ? 0 : e->pack[e->a
 static int player_heal(orc_env *e) {
     e->quiet += 1;
     int64_t quiet = e->quiet, level = e->plevel, heal;
-    if (level < 8) { heal = quiet + (level << 1) - 20; heal = heal < 0 ? 0 : heal > 1 ? 1 : heal; }
-    else if (quiet >= 3) heal = (int64_t)range64(&e->rng_e, 1, (uint64_t)(level - 6));
+    if (level < (MUT(42) ? 9 : 8)) { heal = quiet + (level << 1) - (MUT(65) ? 19 : 20); /* M65 player.rs:224: heals one turn earlier */ /* M42 player.rs:225: the random heal from level 9 on */ heal = heal < 0 ? 0 : heal > 1 ? 1 : heal; }
+    else if (quiet >= 3) heal = (int64_t)W64(41, &e->rng_e, 1, (uint64_t)(level - 6)); /* M41 player.rs:228 width */
     else heal = 0;
     if (heal > 0) {
         e->hp += heal; if (e->hp > e->hp_max) e->hp = e->hp_max;
@@ -892,7 +926,7 @@ static int player_level_up(orc_env *e, uint32_t exp) {
     if (diff > 0) {
         e->plevel += (int64_t)diff;
         int64_t add = 0;
-        for (size_t i = 0; i < diff; i++) add += (int64_t)range64(&e->rng_e, 1, 11);
+        for (size_t i = 0; i < diff; i++) add += (int64_t)W64(40, &e->rng_e, 1, 11); /* M40 player.rs:193 width */
         e->hp_max += add; e->hp += add;
         return 1;
     }
@@ -912,13 +946,16 @@ static int move_active_enemies(orc_env *e, rlist_t *res) {
         int attr = e->stats[m.type].attr;
         /* (rng.does_happen(2) && is_random) || (!rng.does_happen(5) && is_confused) */
         int random_move = 0;
-        if (does_happen(&e->rng_e, 2) && (attr & EA_RANDOM)) random_move = 1;
-        else if (!does_happen(&e->rng_e, 5) && (attr & EA_CONFUSED)) random_move = 1;
+        /* M34 enemies.rs:401 width, M35 :402 width, M36 both draws always taken (no short circuit) */
+        if (MUT(36)) { int a = DH(34, &e->rng_e, 2), b = DH(35, &e->rng_e, 5); random_move = (a && (attr & EA_RANDOM)) || (!b && (attr & EA_CONFUSED)); }
+        else if (DH(34, &e->rng_e, 2) && (attr & EA_RANDOM)) random_move = 1;
+        else if (!DH(35, &e->rng_e, 5) && (attr & EA_CONFUSED)) random_move = 1;
         if (random_move) r = move_enemy_randomly(e, m.x, m.y, e->px, e->py, skip_occupied, &ox, &oy);
         else r = move_enemy(e, m.x, m.y, e->px, e->py, skip_occupied, &ox, &oy);
         if (r == MR_REACH) attackers[n_att++] = m;
         else if (r == MR_CANMOVE) { nx = ox; ny = oy; }
         m.x = nx; m.y = ny;
+        if (MUT(46) && mon_at(e, m.x, m.y, NULL)) { /* M46 App. C-10: an occupied cell keeps its earlier occupant, the newcomer is dropped */ } else
         mon_insert_active(e, &m); /* BTreeMap::insert: same key overwrites */
     }
     if (n_att > 0) e->quiet = 0; /* player.buttle() */
@@ -928,10 +965,10 @@ static int move_active_enemies(orc_env *e, rlist_t *res) {
         uint32_t rate = attack_rate(m->level, player_arm(e), hit_prob_plus(ENEMY_STR));
         int64_t dam_plus = damage_plus(ENEMY_STR) + damage_plus(PLAYER_STR), sum = 0; int hit = 0;
         for (int k = 0; k < st->n_attack; k++) {
-            if (!parcent(&e->rng_e, rate)) continue;
+            if (!PC(39, &e->rng_e, rate)) continue; /* M39 fight.rs:61 width */
             hit = 1;
             int64_t dmg = 0;
-            for (int t = 0; t < st->att_times[k]; t++) dmg += (int64_t)range64(&e->rng_e, 1, (uint64_t)st->att_max[k] + 1);
+            for (int t = 0; t < st->att_times[k]; t++) dmg += (int64_t)W64(43, &e->rng_e, 1, (uint64_t)st->att_max[k] + 1); /* M43 character/mod.rs:232 width */
             sum += dmg + dam_plus;
         }
         if (hit) {
@@ -947,6 +984,7 @@ static int move_active_enemies(orc_env *e, rlist_t *res) {
 /* actions::after_turn + Player::turn_passed (actions.rs:67-80, player.rs:163-176) */
 static int after_turn(orc_env *e, rlist_t *res) {
     e->food_left -= 1; /* u32, wraps in release builds */
+    if (MUT(68) && e->food_left == 0) { e->dead = 1; rpush(res, RE_GRAVE, 0); return 1; } /* M68 App. C-9: starvation kills (the reference ignores PlayerEvent::Dead here) */
     if (e->food_left != 0) {
         uint32_t hunger = e->cfg.hunger_time / 10;
         if (e->food_left == hunger || e->food_left == hunger * 2) rpush(res, RE_STATUS, 0);
@@ -962,12 +1000,12 @@ static void player_attack(orc_env *e, int x, int y, rlist_t *res) {
     mon_t *m = (mon_t *)mon_at(e, x, y, &is_active);
     /* no thrown weapon: hit_plus / dam_plus / at_weild of Player::weapon, else 0 / 0 / 1d4 (fight.rs:20-33) */
     const orc_item *wp = e->weapon < 0 ? NULL : &e->pack[e->weapon];
-    int64_t str_p = hit_prob_plus(PLAYER_STR) + (m->running ? 0 : 4) + (wp ? wp->hit_plus : 0);
+    int64_t str_p = hit_prob_plus(PLAYER_STR) + ((m->running && !MUT(51)) ? 0 : 4) + (wp ? wp->hit_plus : 0); /* M51 App. C-13: the +4 against a monster that was asleep when attacked */
     uint32_t rate = attack_rate(e->plevel, m->defense, str_p);
-    if (parcent(&e->rng_e, rate)) { /* roll over the one die (fight.rs:52-72) */
+    if (PC(39, &e->rng_e, rate)) { /* roll over the one die (fight.rs:52-72) */
         uint64_t times = wp ? wp->wield_times : 1; int64_t mx = wp ? wp->wield_max : 4;
         int64_t dmg = 0;
-        for (uint64_t t = 0; t < times; t++) dmg += (int64_t)range64(&e->rng_e, 1, (uint64_t)mx + 1); /* Damage::random (character/mod.rs:229-234) */
+        for (uint64_t t = 0; t < times; t++) dmg += (int64_t)W64(43, &e->rng_e, 1, (uint64_t)mx + 1); /* Damage::random (character/mod.rs:229-234) */
         dmg += (wp ? wp->dam_plus : 0) + damage_plus(PLAYER_STR);
         rpush(res, RE_NOTIFY, MSG_HIT_TO);
         if (m->hp <= dmg) { /* Enemy::get_damage (enemies.rs:205-213) */
@@ -976,7 +1014,7 @@ static void player_attack(orc_env *e, int x, int y, rlist_t *res) {
             if (player_level_up(e, exp)) rpush(res, RE_STATUS, 0);
             rpush(res, RE_NOTIFY, MSG_KILLED);
             rpush(res, RE_REDRAW, 0);
-        } else m->hp = dmg - m->hp; /* quirk: stores damage - cur */
+        } else m->hp = MUT(50) ? m->hp - dmg : dmg - m->hp; /* quirk: stores damage - cur   M50 App. C-13: the sane subtraction */
     } else rpush(res, RE_NOTIFY, MSG_MISS_TO);
 }
 /* actions::move_player + get_item (actions.rs:168-231). returns `done` */
@@ -1013,10 +1051,10 @@ static void do_search(orc_env *e, rlist_t *res) {
         int x = e->px + DX[d], y = e->py + DY[d];
         if (!INB(e, x, y)) continue;
         int id = IDX(e, x, y);
-        if ((fl->attr[id] & A_HIDDEN) && does_happen(&e->rng_d, c->passage_unlock_rate_inv)) {
+        if ((fl->attr[id] & A_HIDDEN) && DH(56, &e->rng_d, c->passage_unlock_rate_inv)) { /* M56 floor.rs:359 width */
             fl->attr[id] &= ~(A_LOCKED | A_HIDDEN); fl->attr[id] |= A_VISIBLE; fl->surface[id] = S_PASSAGE;
         }
-        if ((fl->attr[id] & A_LOCKED) && does_happen(&e->rng_d, c->door_unlock_rate_inv)) {
+        if ((fl->attr[id] & A_LOCKED) && DH(57, &e->rng_d, c->door_unlock_rate_inv)) { /* M57 floor.rs:363 width */
             fl->attr[id] &= ~(A_LOCKED | A_HIDDEN); fl->attr[id] |= A_VISIBLE; fl->surface[id] = S_DOOR;
             rpush(res, RE_NOTIFY, MSG_SECRET_DOOR);
         }
@@ -1060,16 +1098,16 @@ static int process_action(orc_env *e, int act, int dir, rlist_t *out) {
             int done = move_player(e, dir, res);
             int id = IDX(e, e->px, e->py);
             uint8_t tile = (e->fl.attr[id] & A_VISIBLE) ? SURFACE_GLYPH[e->fl.surface[id]] : ' '; /* Cell::tile (field.rs:91-98) */
-            if (done || (tile != '.' && tile != '#')) { for (int i = 0; i < res->n; i++) rpush(out, res->v[i].kind, res->v[i].msg); break; }
+            if (done || (tile != '.' && tile != '#')) { for (int i = 0; i < res->n; i++) rpush(out, res->v[i].kind, res->v[i].msg); if (MUT(62)) ui = after_turn(e, out); /* M62 App. C-8: the stopping iteration costs a turn too */ break; }
             else if (out->n == 0) { for (int i = 0; i < res->n; i++) rpush(out, res->v[i].kind, res->v[i].msg); }
             ui = after_turn(e, out);
         }
         break;
     case ACT_SEARCH:
         do_search(e, out);
-        ui = after_turn(e, out);
+        if (!MUT(64)) ui = after_turn(e, out); /* M64 App. C-8: Search costs no turn */
         break;
-    case ACT_NOOP: return 0;
+    case ACT_NOOP: if (MUT(63)) { ui = after_turn(e, out); break; } /* M63 App. C-8: NoOp costs a turn */ return 0;
     }
     return ui;
 }
@@ -1141,7 +1179,7 @@ static int player_init_items(orc_env *e) {
             const orc_weapon_stat *st = NULL;
             for (int k = 0; k < c->n_weapons && !st; k++) if (!strcmp(c->weapons[k].name, it->name)) st = &c->weapons[k];
             if (!st) return 1; /* "Specified item {} is not registerd to WeaponHandler" */
-            uint32_t num = range32(&e->rng_i, st->init_lo, st->init_hi); /* WeaponStatus::build (weapon.rs:148-170): the one draw, on the item stream */
+            uint32_t num = W32(59, &e->rng_i, st->init_lo, st->init_hi); /* M59 weapon.rs:159 width   WeaponStatus::build (weapon.rs:148-170): the one draw, on the item stream */
             item.kind = ORC_KIND_WEAPON; strcpy(item.name, st->name); item.wield_times = st->wield_times; item.wield_max = st->wield_max;
             item.hit_plus = 0 + it->hit_plus; item.dam_plus = 0 + it->dam_plus; item.attr = st->attr; item.how_many = num + it->num_plus;
         } else { /* ArmorStatus::build draws nothing (armor.rs:141-169) */
@@ -1195,8 +1233,9 @@ static int runtime_build(orc_env *e) {
     /* Player::build (player.rs:78-91) + Player::init_items (player.rs:136-153) */
     e->hp = e->hp_max = c->init_hp; e->plevel = 1; e->exp = 0;
     e->food_left = c->hunger_time; e->quiet = 0; e->dead = 0;
-    if (player_init_items(e)) return 1;
+    if (!MUT(60) && player_init_items(e)) return 1;
     actions_new_level(e, 1);
+    if (MUT(60) && player_init_items(e)) return 1; /* M60 App. C-1: the pack's item-stream draws after the player's placement (no golden can tell: nothing reads the item stream in between) */
     return 0;
 }
 static void mirror_reset(orc_env *e) { /* PlayerState::reset (python/src/lib.rs:52-58) */

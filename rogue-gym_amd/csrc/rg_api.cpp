@@ -31,7 +31,10 @@ extern "C" {
 void rgk_build(const RgState *S, const RgConfig *c, hipStream_t st);
 int rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 void rgk_probe_clock(unsigned long long *out, int spin, hipStream_t st);
-void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, const uint32_t *mark, uint32_t target, uint32_t *err_any, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, int spares, const uint32_t *mark, uint32_t target, uint32_t *err_any, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+void rgk_regen_gate(const uint32_t *mark, uint32_t target, uint32_t *err_any, hipStream_t st);
+int rgk_regen_lanes_supported(const RgConfig *c, int maze_cap);
+int rgk_regen_lanes(const RgState *SP, const RgConfig *c, uint32_t *q, int32_t *list, int bulk, int waves, int slots, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st);
 void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st);
 void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *status, uint32_t *flags, uint32_t *err_any, int n, int hw, size_t rs, size_t rst,
@@ -49,6 +52,12 @@ struct rg_handle {
     RgState S;
     RgState SP;                  // spare view: core pointers address the pre-generated next level-1 state (k_regen)
     bool spares = false;
+    uint32_t *lane_q = nullptr; int32_t *lane_list = nullptr;  // its claim list (one launch at a time: the generator's stream serialises them)
+    hipStream_t side3 = nullptr; // ... alternating with side2 (a launch may outlast a step)
+    hipStream_t side2 = nullptr; // stream of the level-per-lane spare producer (LOW priority; its launches are long and far apart, the next-level structures' short and with every step)
+    int lane_flip = 0;           // which of the two carries the next launch (each with its own claim list)
+    uint64_t lane_last = 0;      // step_count of its last launch
+    bool lane_regen = false;     // the consumed spares are rebuilt one level per LANE (rg_regen_lanes.hip) instead of one per wave (k_regen); ROGUE_GYM_HIP_WAVE_REGEN=1 keeps the latter
     uint64_t step_count = 0;
     hipStream_t side = nullptr;  // stream of the background generator (LOW priority: the step kernel's blocks are placed first, k_regen takes what is left; rg_step_prefix)
     int regen_idle_after = -1;   // ROGUE_GYM_HIP_KEEP_SPARES with fixed seeds only: > 0 = that many more k_regen launches (after creation / rg_seed), 0 = none needed, -1 = off
@@ -238,7 +247,14 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
               dev_alloc(h, &S.dc_map, h->cfg.n_enemies > 0 ? n * RG_DIST_SLOTS * hw : 16) && dev_alloc(h, &S.dc_key, RG_DIST_SLOTS * n) &&
               dev_alloc(h, &S.dc_head, n) && dev_alloc(h, &S.dc_len, n) && dev_alloc(h, &S.dc_part, n) && dev_alloc(h, &S.dc_own, n) && dev_alloc(h, &S.status, n * 10) &&
               dev_alloc(h, &h->d_err, 4) && dev_alloc(h, &h->d_keys, n);
-    ok = ok && dev_alloc(h, &S.sp_ready, n) && dev_alloc(h, &h->d_probe, 4) && dev_alloc(h, &S.launch_mark, 4);
+    h->spares = auto_reset != 0 && getenv("ROGUE_GYM_HIP_NO_SPARES") == nullptr;
+    // which producer refills the consumed spares: one level per LANE (rg_regen_lanes.hip; two spares per env, rg_state.h sp_slots) where it applies,
+    // else -- or with ROGUE_GYM_HIP_WAVE_REGEN=1 -- one level per wave (k_regen, one spare per env)
+    h->lane_regen = h->spares && getenv("ROGUE_GYM_HIP_WAVE_REGEN") == nullptr && rgk_regen_lanes_supported(&h->cfg, maze_cap) > 0;
+    S.sp_slots = h->lane_regen ? (RG_DEV_ENV("ROGUE_GYM_HIP_SP_SLOTS") ? atoi(RG_DEV_ENV("ROGUE_GYM_HIP_SP_SLOTS")) : 4) : 1;
+    if (S.sp_slots < 1 || S.sp_slots > 8) S.sp_slots = 4;
+    const size_t ns = n * (size_t)S.sp_slots;  // entries of the spare view
+    ok = ok && dev_alloc(h, &S.sp_ready, ns) && dev_alloc(h, &h->d_probe, 4) && dev_alloc(h, &S.launch_mark, 4);
     // the grid class whose dist maps may be partial (rg_kernels.hip bfs_rows_n32): one saved walkable mask per map
     if (ok && h->cfg.n_enemies > 0 && RG_PARTIAL_MAPS(h->cfg.width, h->cfg.height, (int)nr))
         ok = dev_alloc(h, &S.dc_walk, n * RG_DIST_SLOTS * h->cfg.height * RG_WALK_WORDS(h->cfg.width));
@@ -258,7 +274,6 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
         if (!ok && h->err.empty()) h->err = "hipMemcpy failed";
         S.init_draws = d;
     }
-    h->spares = auto_reset != 0 && getenv("ROGUE_GYM_HIP_NO_SPARES") == nullptr;
     // next-level structures (rg_kernels.hip gen_service): generated by the spare pipeline's kernel, for the generator instances with the room table in
     // registers (<= 64 rooms).  ROGUE_GYM_HIP_NO_NEXT_LEVELS: every descent generates its whole level inline (the A side of the parity / A-B tests)
     if (ok && h->spares && nr <= 64 && getenv("ROGUE_GYM_HIP_NO_NEXT_LEVELS") == nullptr) {
@@ -274,18 +289,23 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
     h->SP = S;
     if (ok && h->spares) {
         RgState &P = h->SP;
-        ok = dev_alloc(h, &P.cell, n * hw) && dev_alloc(h, &P.p_pos, n) && dev_alloc(h, &P.p_hp, n) && dev_alloc(h, &P.p_hpmax, n) && dev_alloc(h, &P.p_lvl, n) &&
-             dev_alloc(h, &P.p_exp, n) && dev_alloc(h, &P.food, n) && dev_alloc(h, &P.quiet, n) && dev_alloc(h, &P.pack_gold, n) && dev_alloc(h, &P.dlevel, n) &&
-             dev_alloc(h, &P.rng, 12 * n) && dev_alloc(h, &P.room_rect, nr * n) && dev_alloc(h, &P.room_meta, nr * n) &&
-             dev_alloc(h, &P.mon_w0, nr * n) && dev_alloc(h, &P.mon_hp, nr * n) && dev_alloc(h, &P.mon_exp, nr * n) &&
-             dev_alloc(h, &P.mon_cnt, n) && dev_alloc(h, &P.gold_pos, nr * n) && dev_alloc(h, &P.gold_amt, nr * n) &&
+        ok = dev_alloc(h, &P.cell, ns * hw) && dev_alloc(h, &P.p_pos, ns) && dev_alloc(h, &P.p_hp, ns) && dev_alloc(h, &P.p_hpmax, ns) && dev_alloc(h, &P.p_lvl, ns) &&
+             dev_alloc(h, &P.p_exp, ns) && dev_alloc(h, &P.food, ns) && dev_alloc(h, &P.quiet, ns) && dev_alloc(h, &P.pack_gold, ns) && dev_alloc(h, &P.dlevel, ns) &&
+             dev_alloc(h, &P.rng, 12 * ns) && dev_alloc(h, &P.room_rect, nr * ns) && dev_alloc(h, &P.room_meta, nr * ns) &&
+             dev_alloc(h, &P.mon_w0, nr * ns) && dev_alloc(h, &P.mon_hp, nr * ns) && dev_alloc(h, &P.mon_exp, nr * ns) &&
+             dev_alloc(h, &P.mon_cnt, ns) && dev_alloc(h, &P.gold_pos, nr * ns) && dev_alloc(h, &P.gold_amt, nr * ns) &&
              dev_alloc(h, &P.edge_a, ne * n) && dev_alloc(h, &P.edge_b, ne * n) && dev_alloc(h, &P.maze_stack, (size_t)maze_cap * n) &&
-             dev_alloc(h, &P.on_stairs, n);
+             dev_alloc(h, &P.on_stairs, ns);
         P.prof = nullptr;
         int lo = 0, hi = 0;
         if (ok && (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, RG_DEV_ENV("ROGUE_GYM_HIP_SIDE_HIPRIO") ? hi : lo) != hipSuccess)) {
             h->err = "failed to create the background generation stream"; ok = false;
         }
+        // (default priority: the packets of a LOW-priority queue are fetched only while the handle's own queue has none waiting -- in a free-running loop,
+        // never: measured, the launches ran thousands of steps late -- and it is the waves' own priority, not the queue's, that keeps these few waves out of
+        // k_step's way)
+        static const bool lanes_low = RG_DEV_ENV("ROGUE_GYM_HIP_LANES_LOWPRIO") != nullptr;
+        if (ok && (hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, lanes_low ? lo : (lo + hi) / 2) != hipSuccess || hipStreamCreateWithPriority(&h->side3, hipStreamNonBlocking, lanes_low ? lo : (lo + hi) / 2) != hipSuccess)) { h->err = "failed to create the background generation stream"; ok = false; }
     }
     ok = ok && dev_alloc(h, &h->d_SP, 1) && hipMemcpy(h->d_SP, &h->SP, sizeof(RgState), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { g_create_err = h->err.empty() ? "device allocation failed" : h->err; free_all(h); delete h; return 1; }
@@ -301,9 +321,11 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
     if (h->spares) {
         // first spares.  rg_create waits for them: left in the background, this one-off generation of EVERY env's spare (~2 ms at 65 536 envs)
         // competes with the first few hundred steps for issue slots (the driver's 20-step bench ran k_step at 141 us instead of ~100 us).
-        rgk_regen(&h->SP, &h->cfg, 1, nullptr, 0, h->d_err, h->side, nullptr, nullptr);  // (bulk: every spare; no gate)
+        if (h->lane_regen && !(dev_alloc(h, &h->lane_q, 8) && dev_alloc(h, &h->lane_list, 2 * ns))) { g_create_err = h->err; free_all(h); delete h; return 1; }
+        if (h->lane_regen) (void)rgk_regen_lanes(&h->SP, &h->cfg, h->lane_q, h->lane_list, 1, 0, h->S.sp_slots, h->side2, nullptr, nullptr);  // (bulk: every spare; no gate)
+        else rgk_regen(&h->SP, &h->cfg, 1, 1, nullptr, 0, h->d_err, h->side, nullptr, nullptr);
         e = hipGetLastError();
-        if (e == hipSuccess && !RG_DEV_ENV("ROGUE_GYM_HIP_ASYNC_FIRST_SPARES")) e = hipStreamSynchronize(h->side);  // (dev knob: the round-1 behaviour)
+        if (e == hipSuccess && !RG_DEV_ENV("ROGUE_GYM_HIP_ASYNC_FIRST_SPARES")) { e = hipStreamSynchronize(h->side); if (e == hipSuccess) e = hipStreamSynchronize(h->side2); if (e == hipSuccess) e = hipStreamSynchronize(h->side3); }  // (dev knob: the round-1 behaviour)
         if (e != hipSuccess) { g_create_err = std::string("k_regen: ") + hipGetErrorString(e); free_all(h); delete h; return 1; }
         h->regen_bulk = 1;  // (the first steady-state launch too: whatever the creation launch left, e.g. when it ran in the background)
         bool all_fixed = true;
@@ -427,6 +449,8 @@ static void destroy_handle(rg_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->comm) (void)comm_release(h, true);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+    if (h->side2) { (void)hipStreamSynchronize(h->side2); (void)hipStreamDestroy(h->side2); }
+    if (h->side3) { (void)hipStreamSynchronize(h->side3); (void)hipStreamDestroy(h->side3); }
     for (int k = 0; k < RG_TIMED_KERNELS; k++) for (auto &e : h->ev[k]) (void)hipEventDestroy(e);
     if (h->obs_scratch) (void)hipFree(h->obs_scratch);
     free_all(h);
@@ -468,7 +492,7 @@ int rg_env_symbols(const rg_t *h, int32_t *out_host) {
 int rg_set_stream(rg_t *h, void *hip_stream) {
     for (rg_handle *sh : h->sub) SUBCHK(h, sh, rg_set_stream(sh, hip_stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
+    if (h->side) { HIPCHK(h, hipStreamSynchronize(h->side)); HIPCHK(h, hipStreamSynchronize(h->side2)); HIPCHK(h, hipStreamSynchronize(h->side3)); }
     h->stream = (hipStream_t)hip_stream;
     return 0;
 }
@@ -490,7 +514,9 @@ int rg_seed(rg_t *h, const uint64_t *seed_lo, const uint64_t *seed_hi, int n) {
         // the spares of these envs were generated from the old seeds: drop them (k_step generates inline until k_regen has refilled them).
         // A k_regen in flight may be about to publish one of them, so the side stream is drained first; the main stream is not.
         HIPCHK(h, hipStreamSynchronize(h->side));
-        HIPCHK(h, hipMemsetAsync(h->S.sp_ready, 0, (size_t)n * 4, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->side2));
+        HIPCHK(h, hipStreamSynchronize(h->side3));
+        for (int sl = 0; sl < h->S.sp_slots; sl++) HIPCHK(h, hipMemsetAsync(h->S.sp_ready + (size_t)sl * h->S.n, 0, (size_t)n * 4, h->stream));
         if (h->regen_idle_after >= 0) h->regen_idle_after = 2;  // rebuild the dropped spares, then idle again
         h->regen_bulk = 2;
     }
@@ -561,7 +587,27 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
     HIPCHK(h, hipGetLastError());
     if (regen) {
         TimedLaunch t(h, 4, true);
-        rgk_regen(&h->SP, &h->cfg, h->regen_bulk > 0 ? 1 : 0, h->S.launch_mark, (uint32_t)h->S.stair_gen + 1u, h->d_err, h->side, t.start_ev(), t.stop_ev());
+        if (h->lane_regen) {
+            // The next-level structures -- wanted within two steps -- one per wave, beside every step (gate + k_regen on `side`), The spares -- wanted when the env's next episode ends, and under the random policy a
+            // fifth of the episodes are over within 13 steps -- one level per LANE (rg_regen_lanes.hip), with every step too: a round of 64 levels takes a wave
+            // longer than a step, so the launches alternate between two streams of their own.  
+            static const int lane_waves = RG_DEV_ENV("ROGUE_GYM_HIP_LANE_WAVES") ? atoi(RG_DEV_ENV("ROGUE_GYM_HIP_LANE_WAVES")) : 256;
+            static const int lane_every = RG_DEV_ENV("ROGUE_GYM_HIP_LANE_EVERY") ? atoi(RG_DEV_ENV("ROGUE_GYM_HIP_LANE_EVERY")) : 4;
+            static const bool time_lanes = RG_DEV_ENV("ROGUE_GYM_HIP_TIME_LANES") != nullptr;  // (development: the event pair of rg_timing's kernel 4 goes to the level-per-lane launch)
+            const bool lanes_now = h->regen_bulk > 0 || h->step_count - h->lane_last >= (uint64_t)(lane_every > 0 ? lane_every : 1);
+            if (h->S.nx_state) rgk_regen(&h->SP, &h->cfg, 0, 0, h->S.launch_mark, (uint32_t)h->S.stair_gen + 1u, h->d_err, h->side, time_lanes ? nullptr : t.start_ev(), time_lanes ? nullptr : t.stop_ev());
+            else if (!time_lanes) t.cancel();
+            if (time_lanes && !lanes_now) t.cancel();
+            if (lanes_now) {
+                h->lane_last = h->step_count;
+                h->lane_flip ^= 1;
+                // (gated like k_regen: the host runs hundreds of steps ahead of the GPU, and a launch that is not held back until ITS k_step has started scans
+                // for consumed spares long before they are consumed -- measured: a backlog of 12 000 spares with a launch every fourth step)
+                rgk_regen_gate(h->S.launch_mark, (uint32_t)h->S.stair_gen + 1u, h->d_err, h->lane_flip ? h->side3 : h->side2);
+                (void)rgk_regen_lanes(&h->SP, &h->cfg, h->lane_q + 4 * h->lane_flip, h->lane_list + (size_t)h->S.n * h->S.sp_slots * h->lane_flip, h->regen_bulk > 0 ? 1 : 0, lane_waves, h->S.sp_slots,
+                                      h->lane_flip ? h->side3 : h->side2, time_lanes ? t.start_ev() : nullptr, time_lanes ? t.stop_ev() : nullptr);
+            }
+        } else rgk_regen(&h->SP, &h->cfg, h->regen_bulk > 0 ? 1 : 0, 1, h->S.launch_mark, (uint32_t)h->S.stair_gen + 1u, h->d_err, h->side, t.start_ev(), t.stop_ev());
         if (h->regen_bulk > 0) h->regen_bulk--;
     }
     HIPCHK(h, hipGetLastError());
@@ -580,7 +626,7 @@ int rg_sync(rg_t *h) {
     uint32_t err = 0;
     HIPCHK(h, hipMemcpyAsync(&err, h->d_err, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
+    if (h->side) { HIPCHK(h, hipStreamSynchronize(h->side)); HIPCHK(h, hipStreamSynchronize(h->side2)); HIPCHK(h, hipStreamSynchronize(h->side3)); }
     if (err) {
         HIPCHK(h, hipMemsetAsync(h->d_err, 0, 4, h->stream));
         if (err & RG_FLAG_ERR_INTERNAL) h->err = "internal capacity guard of the HIP stepper tripped (please report the config)";
@@ -912,7 +958,7 @@ int rg_history_enable(rg_t *h, int cap_per_env) {
     if (cap_per_env <= 0) { h->err = "rg_history_enable: capacity must be positive"; return 1; }
     if (h->S.klog) { h->err = "rg_history_enable: already enabled"; return 1; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
+    if (h->side) { HIPCHK(h, hipStreamSynchronize(h->side)); HIPCHK(h, hipStreamSynchronize(h->side2)); HIPCHK(h, hipStreamSynchronize(h->side3)); }
     const size_t n = (size_t)h->S.n;
     uint8_t *log = nullptr, *cur = nullptr; uint32_t *len = nullptr;
     if (!dev_alloc(h, &log, n * 2 * (size_t)cap_per_env) || !dev_alloc(h, &len, 2 * n) || !dev_alloc(h, &cur, n)) return 1;
@@ -1040,7 +1086,7 @@ int rg_timing_enable(rg_t *h, int on) {
             for (auto &e : h->ev[k]) HIPCHK(h, hipEventCreate(&e));
         }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
+    if (h->side) { HIPCHK(h, hipStreamSynchronize(h->side)); HIPCHK(h, hipStreamSynchronize(h->side2)); HIPCHK(h, hipStreamSynchronize(h->side3)); }
     for (int k = 0; k < RG_TIMED_KERNELS; k++) { h->ev_used[k] = 0; h->timing_seq[k] = 0; }
     h->timing = on != 0;
     h->timing_stride = on > 1 ? (uint64_t)on : 1;  // on = N > 1: bracket every N-th launch only
@@ -1060,7 +1106,7 @@ int rg_timing_read_all(rg_t *h, int n, double *ms, uint64_t *sampled, uint64_t *
         return 0;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));  // (k_regen's pairs are stamped on the side stream)
+    if (h->side) { HIPCHK(h, hipStreamSynchronize(h->side)); HIPCHK(h, hipStreamSynchronize(h->side2)); HIPCHK(h, hipStreamSynchronize(h->side3)); }  // (k_regen's pairs are stamped on the side stream)
     for (int k = 0; k < n; k++) {
         double sum = 0;
         for (size_t i = 0; i + 1 < h->ev_used[k]; i += 2) {
@@ -1126,6 +1172,15 @@ int rg_config_canonical(const char *cfg_json, char *buf, size_t cap) {
     return 0;
 }
 
+#ifdef RG_DEV_KNOBS
+// development library only: the spare pipeline's state words [sp_slots][n_env] -> host (tools/tmp/sp_state.py)
+int rg_dev_sp_ready(rg_t *h, uint32_t *out_host, int *slots) {
+    HIPCHK(h, hipSetDevice(h->device));
+    *slots = h->S.sp_slots;
+    HIPCHK(h, hipMemcpy(out_host, h->S.sp_ready, (size_t)h->S.n * h->S.sp_slots * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 int rg_debug_descend(rg_t *h) {
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->sub.empty()) {

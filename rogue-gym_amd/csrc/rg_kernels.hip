@@ -14,82 +14,7 @@
 #include "rg_device.h"
 
 
-// ---------------------------------------------------------------------------------------------
-// RNG: xorshift128 + rand-0.7 sample_single (core/src/rng.rs:48-98)
-// ---------------------------------------------------------------------------------------------
-struct Rng { uint32_t x, y, z, w; };
-
-// Wave-uniform values.  Level generation runs with the whole wave working on ONE env (gen_service): every lane holds the same scalars, so the
-// compiler keeps the RNG, the loop counters and the decisions on the scalar unit.  A value that comes back from memory is uniform in fact but
-// not provably so; uni() tells the compiler.
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ uint32_t lane_get(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
-
-__device__ __forceinline__ void rng_seed(Rng &r, uint64_t lo, uint64_t hi) {
-    r.x = (uint32_t)lo; r.y = (uint32_t)(lo >> 32); r.z = (uint32_t)hi; r.w = (uint32_t)(hi >> 32);
-    if ((r.x | r.y | r.z | r.w) == 0) r.x = r.y = r.z = r.w = 0x0BAD5EEDu;
-}
-__device__ __forceinline__ uint32_t rng_u32(Rng &r) {
-    uint32_t t = r.x ^ (r.x << 11);
-    r.x = r.y; r.y = r.z; r.z = r.w;
-    r.w = r.w ^ (r.w >> 19) ^ (t ^ (t >> 8));
-    return r.w;
-}
-// u32 / i32 call sites: one next_u32 per attempt
-__device__ __forceinline__ uint32_t range32(Rng &r, uint32_t low, uint32_t high) {
-    uint32_t range = high - low;
-    uint32_t zone = (range << __clz((int)range)) - 1u;
-    uint32_t v = rng_u32(r);
-    while (__builtin_expect(v * range > zone, 0)) v = rng_u32(r);  // rejections are rare: straight-line code on the accepted path
-    return low + __umulhi(v, range);
-}
-// usize / i64 call sites: next_u64 = two next_u32 (low word first), 128-bit product.
-// Every 64-bit call site of the engine has range < 2^32 (room counts, cell counts, dice), so the 128-bit product
-// v * range is two 32x32->64 multiplies: lo64 = l*range + ((h*range) << 32), hi64 = (h*range >> 32) + carry, and
-// "lo64 <= zone" with zone = ((range << clz) << 32) - 1 reduces to a compare of the high words.
-__device__ __forceinline__ uint64_t range64(Rng &r, uint64_t low, uint64_t high) {
-    uint64_t range = high - low;
-    if ((range >> 32) == 0) {
-        uint32_t rg = (uint32_t)range;
-        uint32_t top = rg << __clz((int)rg);  // zone = (top << 32) - 1
-        uint32_t l, h, p0_hi, mid;
-        do {
-            l = rng_u32(r); h = rng_u32(r);
-            p0_hi = __umulhi(l, rg);
-            mid = p0_hi + h * rg;                  // bits 32..63 of the low half of the product
-        } while (__builtin_expect(!(mid < top), 0));
-        return low + (uint64_t)(__umulhi(h, rg) + (mid < p0_hi ? 1u : 0u));
-    }
-    uint64_t zone = (range << __clzll((long long)range)) - 1ull;
-    for (;;) {
-        uint64_t l = rng_u32(r), h = rng_u32(r);
-        uint64_t v = (h << 32) | l;
-        uint64_t lo = v * range;
-        if (lo <= zone) return low + __umul64hi(v, range);
-    }
-}
-__device__ __forceinline__ bool does_happen(Rng &r, uint32_t p_inv) { return range32(r, 0, p_inv) == 0; }
-// Reservoir choice among n <= 4 candidates taken in order: candidate i replaces the pick when does_happen(i + 1) (maze.rs:73, passages.rs:79).
-// Unrolled so that every range is a compile-time constant (zone and multiply fold away).  Returns the index of the pick (n >= 1).
-__device__ __forceinline__ int reservoir4(Rng &r, int n) {
-    int pick = 0;
-    (void)does_happen(r, 1);  // i = 0 always wins but still consumes its draws
-    if (n > 1 && does_happen(r, 2)) pick = 1;
-    if (n > 2 && does_happen(r, 3)) pick = 2;
-    if (n > 3 && does_happen(r, 4)) pick = 3;
-    return pick;
-}
-__device__ __forceinline__ bool parcent(Rng &r, uint32_t p) { return range32(r, 1, 101) <= p; }
-
-// Direction -> (dx, dy) as immediates (a __constant__ table indexed per lane is a memory load); same order as kDX / kDY
-constexpr uint32_t dir_pack(const int (&t)[9]) {
-    uint32_t r = 0;
-    for (int d = 0; d < 9; d++) r |= (uint32_t)(t[d] + 1) << (2 * d);
-    return r;
-}
-constexpr int kDXc[9] = {0, 0, -1, 1, -1, 1, -1, 1, 0}, kDYc[9] = {-1, 1, 0, 0, -1, -1, 1, 1, 0};
-__device__ __forceinline__ int dir_dx(int d) { return (int)((dir_pack(kDXc) >> (2 * d)) & 3u) - 1; }
-__device__ __forceinline__ int dir_dy(int d) { return (int)((dir_pack(kDYc) >> (2 * d)) & 3u) - 1; }
+#include "rg_gen.h"
 
 
 // optional phase trace (development aid, tools/microbench.py prof): lane 0 of every wave appends (phase, elapsed shader-clock ticks)
@@ -182,7 +107,6 @@ __device__ __forceinline__ int mon_find(const RgState &S, const Env &E, int nroo
     }
     return found;
 }
-__device__ __forceinline__ uint32_t lev_add_of(const RgConfig &c, uint32_t level) { return c.amulet_level < level ? level - c.amulet_level : 0; }
 
 // EnemyHandler::activate_area (enemies.rs:342-362): wake MEAN sleepers inside room `rid`'s assigned area
 template <bool MC>
@@ -307,11 +231,6 @@ __device__ __forceinline__ bool room_select(const RgState &S, const RgConfig &c,
     const int nth = (int)range64(E.rd, 0, (uint64_t)count);
     out = rect_nth(c, E, x0, y0, rw, area, C_MAZE, excl, nth);
     return true;
-}
-// nth set bit of a small mask
-__device__ __forceinline__ int nth_bit(uint32_t m, int nth) {
-    for (int i = 0; i < nth; i++) m &= m - 1;
-    return __ffs((int)m) - 1;
 }
 // Room sets are bit masks, wave-uniform in the generator (scalar unit).  The generator comes in three instances (GM): 0 for room grids of up to 32
 // rooms (32-bit sets; every corridor record fits the 64 lanes) -- the only one the W <= 32 step kernel contains, whose descent chain bounds the
@@ -885,10 +804,6 @@ __device__ __forceinline__ void place_player(const RgState &S, const RgConfig &c
 }
 
 // GameConfig::build (core/src/lib.rs:193-228), split around the level generator
-__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
-    z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
 // GameConfig::to_global's seed choice (core/src/lib.rs:157-165).  A configured seed is used as is.  `seed: None` draws a fresh seed for EVERY
 // build (rng::gen_seed / gen_ranged_seed use thread_rng, so the values themselves are not parity-relevant): build k of the env uses
 // hash(base, k) with k taken atomically -- the inline generation of k_step and a k_regen running concurrently on the side stream each get
@@ -954,15 +869,6 @@ __device__ __forceinline__ void env_to_lane(Env &E, const Env &U) {  // the gene
     E.err |= U.err; E.on_stairs = U.on_stairs;
 }
 static_assert(sizeof(Rng) == 16, "Rng is 4 words");
-
-// A store another kernel will read while this one is still running (the spare state k_regen hands to k_step): WT = write-through (`sc1`: a relaxed
-// agent-scope atomic store of <= 8 bytes), so that the hand-off needs no release fence.  A release at agent scope is buffer_wbl2 -- the write-back
-// of the XCD's WHOLE L2, which the k_step running beside the generator keeps full of dirty lines: 450 of them per step made a 28 us generation
-// last up to 100 us and cost the step ~10 us (round 4; MI355X_MICROARCH.md: "16-B sc1 stores + drained flag").
-template <bool WT, typename T> __device__ __forceinline__ void st_pub(T *p, T v) {
-    if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
 
 // Next-level structures.  A descent generates its level inside the turn, and the wave that does is the longest chain of a launch (mini: 33 of 51 us,
 // the default dungeon: 71 of 107 us -- the launch lasts as long as that wave).  Two thirds of that generation (gen_structure) draw only on the dungeon and
@@ -1269,7 +1175,7 @@ __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
 #define RG_REGEN_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))  // <= 128 registers: two generator waves beside a step wave on a SIMD (tests/test_kernel_resources.py)
 #endif
 template <int GM>
-__device__ __forceinline__ void regen_body(const RgState &SP, const RgConfig &c, int epb, int max_claims) {
+__device__ __forceinline__ void regen_body(const RgState &SP, const RgConfig &c, int epb, int max_claims, int spares) {
     const int lane = threadIdx.x;
     const int e = blockIdx.x * epb + lane;
     const bool valid = lane < epb && e < SP.n;
@@ -1277,7 +1183,8 @@ __device__ __forceinline__ void regen_body(const RgState &SP, const RgConfig &c,
     // two or three consumed spares decided how long the launch lasted -- 120-160 us, i.e. through k_step AND the observation pass behind it and into the
     // next step (round 4: k_obs 47.5 -> 52 us with a launch beside every step).  The other consumed spares of the wave's eight envs wait for the next
     // launch, one step later; a spare is wanted an episode after it was consumed.
-    const bool want = valid && __hip_atomic_load(&SP.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+    // (spares == 0: the consumed spares are rebuilt by the level-per-lane producer, rg_regen_lanes.hip; this launch serves the next-level structures only)
+    const bool want = valid && spares && __hip_atomic_load(&SP.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
     // ... or ONE next-level structure (gen_service), which goes first: it is wanted within two or three steps, a spare an episode later
     const bool want_nx = GM < 2 && valid && SP.nx_state && __hip_atomic_load(&SP.nx_state[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == RG_NX_ASKED;
     const uint64_t wm = __ballot(want), wx = __ballot(want_nx);
@@ -1321,21 +1228,22 @@ __device__ __forceinline__ void regen_body(const RgState &SP, const RgConfig &c,
     if (claim_nx && atomicCAS(&SP.nx_state[e], RG_NX_CLAIMED, RG_NX_READY) != RG_NX_CLAIMED)
         __hip_atomic_store(&SP.nx_state[e], RG_NX_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// The gate in front of a k_regen launch, alone on the generator's stream: ONE wave that waits until the k_step launched beside it has started
-// (launch_mark reached `target`).  k_regen follows in stream order, so it runs beside that k_step -- not in front of it, where its waves would take
-// the slots of k_step's blocks, and with no event on the handle's stream.  The wait is bounded (~20 ms): a k_step that never starts must not hang
-// rg_sync / rg_destroy, which drain this stream.
+// The gate in front of a generator launch, alone on the generator's stream: ONE wave that waits until the k_step launched beside it has started
+// (launch_mark reached `target`).  The generator follows in stream order, so it runs beside that k_step -- not in front of it, where its waves would take
+// the slots of k_step's blocks (and, the host running hundreds of steps ahead of the GPU, long before the spares it is to refill are consumed), and with
+// no event on the handle's stream.  The wait is bounded by the wall clock (s_memrealtime, 100 MHz): one second -- a k_step that never starts must not
+// hang rg_sync / rg_destroy, which drain this stream; after a time-out the generator merely runs early.
 __global__ void __launch_bounds__(WAVE) k_regen_gate(const uint32_t *__restrict__ mark, uint32_t target, uint32_t *__restrict__ err_any) {
-    int spins = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while ((int32_t)(__hip_atomic_load(mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1 << 17)) break;
+        __builtin_amdgcn_s_sleep(32);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) break;
     }
     (void)err_any;
 }
-template <int GM> __global__ void __launch_bounds__(WAVE) RG_REGEN_ATTR k_regen(RgState SP, RgConfig c, int epb, int max_claims) { regen_body<GM>(SP, c, epb, max_claims); }
+template <int GM> __global__ void __launch_bounds__(WAVE) RG_REGEN_ATTR k_regen(RgState SP, RgConfig c, int epb, int max_claims, int spares) { regen_body<GM>(SP, c, epb, max_claims, spares); }
 // (the 384-room instance does not fit the 128-register cap without scratch; its configs run at one step wave per SIMD anyway)
-__global__ void __launch_bounds__(WAVE) k_regen_huge(RgState SP, RgConfig c, int epb, int max_claims) { regen_body<2>(SP, c, epb, max_claims); }
+__global__ void __launch_bounds__(WAVE) k_regen_huge(RgState SP, RgConfig c, int epb, int max_claims, int spares) { regen_body<2>(SP, c, epb, max_claims, spares); }
 
 // ---------------------------------------------------------------------------------------------
 // wave-cooperative bit-parallel BFS (Floor::make_dist_map, floor.rs:395-416)
@@ -2372,6 +2280,13 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // pairs with k_regen's hand-off (sc1 payload, drained, then sp_ready = 1); measured free (round 4)
     const RgState &SP = *SPd;
     const int HW = S.hw, n = S.n, nrooms = c.room_num_x * c.room_num_y;
+    // the spare taken: the first of the env's spares that is ready (rg_state.h sp_slots; a slot only ever leaves READY through this env's own take, so
+    // one is); es = its index in the spare view, whose SoA stride is ns
+    const size_t ns = (size_t)n * S.sp_slots;
+    int es = e;
+    if (taken)
+        for (int sl = S.sp_slots - 1; sl >= 0; sl--)
+            if (__hip_atomic_load(&S.sp_ready[(size_t)sl * n + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) es = sl * n + e;
     // grids: the wave streams each taken env's 2 * HW bytes with 16-byte accesses (mini: one access per lane and env), FOUR envs per round: all their
     // loads are in flight before the first store, so a wave with several terminal lanes (the episodes of a batch created together end together) pays one
     // memory round trip per four resets.  (Round 3's slowest waves spent 15-20 us here, two envs per round.  Spelled out without arrays: the array form
@@ -2385,8 +2300,9 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
             const int s2 = mm ? __ffsll((long long)mm) - 1 : -1; if (mm) mm &= mm - 1;
             const int s3 = mm ? __ffsll((long long)mm) - 1 : -1; if (mm) mm &= mm - 1;
             const int e0 = __shfl(e, s0), e1 = __shfl(e, s1 >= 0 ? s1 : s0), e2 = __shfl(e, s2 >= 0 ? s2 : s0), e3 = __shfl(e, s3 >= 0 ? s3 : s0);
-            const uint4 *a0 = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e0 * HW), *a1 = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e1 * HW);
-            const uint4 *a2 = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e2 * HW), *a3 = reinterpret_cast<const uint4 *>(SP.cell + (size_t)e3 * HW);
+            const int q0 = __shfl(es, s0), q1 = __shfl(es, s1 >= 0 ? s1 : s0), q2 = __shfl(es, s2 >= 0 ? s2 : s0), q3 = __shfl(es, s3 >= 0 ? s3 : s0);
+            const uint4 *a0 = reinterpret_cast<const uint4 *>(SP.cell + (size_t)q0 * HW), *a1 = reinterpret_cast<const uint4 *>(SP.cell + (size_t)q1 * HW);
+            const uint4 *a2 = reinterpret_cast<const uint4 *>(SP.cell + (size_t)q2 * HW), *a3 = reinterpret_cast<const uint4 *>(SP.cell + (size_t)q3 * HW);
             uint4 *d0 = reinterpret_cast<uint4 *>(S.cell + (size_t)e0 * HW), *d1 = reinterpret_cast<uint4 *>(S.cell + (size_t)e1 * HW);
             uint4 *d2 = reinterpret_cast<uint4 *>(S.cell + (size_t)e2 * HW), *d3 = reinterpret_cast<uint4 *>(S.cell + (size_t)e3 * HW);
             for (int i = lane; i < q; i += WAVE) {
@@ -2406,7 +2322,7 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
         while (mm) {
             const int src = __ffsll((long long)mm) - 1; mm &= mm - 1;
             const int env_s = __shfl(e, src);
-            const uint16_t *sp = SP.cell + (size_t)env_s * HW;
+            const uint16_t *sp = SP.cell + (size_t)__shfl(es, src) * HW;
             uint16_t *dp = S.cell + (size_t)env_s * HW;
             for (int i = lane; i < HW; i += WAVE) dp[i] = sp[i];
         }
@@ -2414,11 +2330,11 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
     if (taken) {
         uint32_t r[12];
 #pragma unroll
-        for (int k = 0; k < 12; k++) r[k] = SP.rng[k * n + e];
-        const uint16_t pp = SP.p_pos[e];
-        const int32_t hp = SP.p_hp[e], hpm = SP.p_hpmax[e], lv = SP.p_lvl[e];
-        const uint32_t ex = SP.p_exp[e], fd = SP.food[e], qu = SP.quiet[e], pg = SP.pack_gold[e], dl = SP.dlevel[e], mc = SP.mon_cnt[e];
-        on_stairs = SP.on_stairs[e] != 0;
+        for (int k = 0; k < 12; k++) r[k] = SP.rng[k * ns + es];
+        const uint16_t pp = SP.p_pos[es];
+        const int32_t hp = SP.p_hp[es], hpm = SP.p_hpmax[es], lv = SP.p_lvl[es];
+        const uint32_t ex = SP.p_exp[es], fd = SP.food[es], qu = SP.quiet[es], pg = SP.pack_gold[es], dl = SP.dlevel[es], mc = SP.mon_cnt[es];
+        on_stairs = SP.on_stairs[es] != 0;
 #pragma unroll
         for (int k = 0; k < 12; k++) S.rng[k * n + e] = r[k];
         S.p_pos[e] = pp; S.p_hp[e] = hp; S.p_hpmax[e] = hpm; S.p_lvl[e] = lv;
@@ -2427,7 +2343,7 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
             uint32_t rr[4], mw[4], me[4], gp[4], ga[4]; int32_t mh[4]; uint8_t rm[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const size_t g = (size_t)(s0 + k < nrooms ? s0 + k : s0) * n + e;
+                const size_t g = (size_t)(s0 + k < nrooms ? s0 + k : s0) * ns + es;
                 rr[k] = SP.room_rect[g]; rm[k] = SP.room_meta[g]; mw[k] = SP.mon_w0[g]; mh[k] = SP.mon_hp[g]; me[k] = SP.mon_exp[g]; gp[k] = SP.gold_pos[g]; ga[k] = SP.gold_amt[g];
             }
 #pragma unroll
@@ -2444,7 +2360,7 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
     // (a RELAXED store: what must precede it is that the spare has been READ, which the barrier above guarantees (it drains vmcnt) -- nothing this wave
     // wrote has to be visible to k_regen.  The release store of rounds 2-3 was a buffer_wbl2, the write-back of the XCD's whole L2, in a third of the
     // waves of every launch.)
-    if (taken && !(S.keep_spares && S.reseed[e] == 0)) __hip_atomic_store(&S.sp_ready[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (taken && !(S.keep_spares && S.reseed[e] == 0)) __hip_atomic_store(&S.sp_ready[es], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One wave's share of a step: lane i plays the key of env `e` (any env index -- the lanes of a wave need not hold consecutive envs), `valid`
@@ -2561,7 +2477,11 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             // The env's pre-generated spare (k_regen) IS its post-reset state: if it is ready, nothing is generated here, and nothing of it is
             // needed in registers either -- the lane only notes `taken`; the spare is moved into place at the very end of the wave in one
             // batched memory-to-memory copy (take_spares).  Without a ready spare the level is generated inline below.
-            if (need_gen && __hip_atomic_load(&S.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) { taken = true; need_gen = false; n_taken++; }
+            if (need_gen) {  // (which of the env's spares it will be is looked up again by take_spares: no register carries it through the wave's tail)
+                bool rdy = false;
+                for (int sl = 0; sl < S.sp_slots; sl++) rdy = rdy || __hip_atomic_load(&S.sp_ready[(size_t)sl * S.n + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u;
+                if (rdy) { taken = true; need_gen = false; n_taken++; }
+            }
         }
         const bool regenerated = descends && pass == 0;
         if constexpr (BW == 1 || BW == 2) { if (pass == 0 && S.dc_walk) snapshot_walk_service(S, c, lane, e, descends); }
@@ -2889,8 +2809,10 @@ void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st) {
     default: hipLaunchKernelGGL(k_debug_descend<2>, grid, dim3(WAVE), smem, st, *S, *c);
     }
 }
-void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, const uint32_t *mark, uint32_t target, uint32_t *err_any, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-    if (mark) hipLaunchKernelGGL(k_regen_gate, dim3(1), dim3(WAVE), 0, st, mark, target, err_any);
+void rgk_regen_gate(const uint32_t *mark, uint32_t target, uint32_t *err_any, hipStream_t st) { hipLaunchKernelGGL(k_regen_gate, dim3(1), dim3(WAVE), 0, st, mark, target, err_any); }
+// spares = 0: next-level structures only (the spares come from rgk_regen_lanes): nothing but the ~20 requests of a step to find, so 64 envs per wave
+void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, int spares, const uint32_t *mark, uint32_t target, uint32_t *err_any, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    if (mark) rgk_regen_gate(mark, target, err_any, st);
     int hw = c->width * c->height;
     size_t smem = GEN_SLOT_BYTES(hw, c->room_num_x * c->room_num_y);
     // envs per wave: a wave generates its claimed spares one after the other, so with 64 envs per wave the launch lasts as long as its unluckiest wave
@@ -2899,16 +2821,16 @@ void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, const uint32_t *m
     // (bulk: every consumed spare the wave finds, not one -- the launches that build ALL spares: creation, after rg_seed)
 #ifdef RG_DEV_KNOBS
     static const int epb_env = getenv("ROGUE_GYM_HIP_REGEN_EPB") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_EPB")) : 0;
-    const int epb = (epb_env >= 4 && epb_env <= WAVE) ? epb_env : 8;
+    const int epb = (epb_env >= 4 && epb_env <= WAVE) ? epb_env : (spares ? 8 : WAVE);
     static const int claims_env = getenv("ROGUE_GYM_HIP_REGEN_CLAIMS") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_CLAIMS")) : 1;
     const int max_claims = bulk ? WAVE : claims_env;
 #else
-    const int epb = 8, max_claims = bulk ? WAVE : 1;
+    const int epb = spares ? 8 : WAVE, max_claims = bulk ? WAVE : 1;
 #endif
     const dim3 grid((SP->n + epb - 1) / epb);
     // (ev0 / ev1: optional events stamped with this dispatch's own begin and end -- rg_timing, kernel 4)
-#define RG_LAUNCH_REGEN(K) do { if (ev0 || ev1) hipExtLaunchKernelGGL(K, grid, dim3(WAVE), (uint32_t)smem, st, ev0, ev1, 0, *SP, *c, epb, max_claims); \
-                                else hipLaunchKernelGGL(K, grid, dim3(WAVE), smem, st, *SP, *c, epb, max_claims); } while (0)
+#define RG_LAUNCH_REGEN(K) do { if (ev0 || ev1) hipExtLaunchKernelGGL(K, grid, dim3(WAVE), (uint32_t)smem, st, ev0, ev1, 0, *SP, *c, epb, max_claims, spares); \
+                                else hipLaunchKernelGGL(K, grid, dim3(WAVE), smem, st, *SP, *c, epb, max_claims, spares); } while (0)
     switch (gen_mode_of(c)) {
     case 0: RG_LAUNCH_REGEN(k_regen<0>); break;
     case 1: RG_LAUNCH_REGEN(k_regen<1>); break;

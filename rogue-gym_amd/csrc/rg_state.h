@@ -116,7 +116,12 @@ struct RgState {
     // optional in-kernel phase profile (development aid): [2][32] u64 = {max cycles, sum cycles} per phase, NULL = off
     unsigned long long *prof;
     // spare-level pipeline: 0 = spare must be (re)generated, 1 = ready, 2 = generation in progress
-    uint32_t *sp_ready; // [n] (shared by the live and the spare view)
+    uint32_t *sp_ready; // [sp_slots][n] (shared by the live and the spare view)
+    // Spares per env.  1: the wave-per-level producer (k_regen), whose spare is back one or two steps after it was consumed.  2: the level-per-lane producer
+    // (rg_regen_lanes.hip) builds 64 levels per wave in the time the other builds a dozen, but a round of 64 takes it four or five steps -- and under the
+    // random policy 1 % of the episodes are over within five steps: with a second spare per env a reset misses only when TWO episodes in a row end inside
+    // the producer's latency.  Spare (slot s, env e) is entry s * n + e of every array of the spare view (whose SoA stride is sp_slots * n).
+    int32_t sp_slots;
     // status mirror
     int32_t *status;    // [n][10]
     // action-history log (RunTime::saved_inputs, core/src/lib.rs:288): the keys of the current and of the previous episode, NULL = off

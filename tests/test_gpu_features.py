@@ -506,7 +506,10 @@ def test_index_order_mapping_without_stair_waves_is_bit_exact(goldens):
     {"DEV": "1", "ROGUE_GYM_HIP_REGEN_EVERY": "2", "ROGUE_GYM_HIP_REGEN_CLAIMS": "8", "ROGUE_GYM_HIP_SIDE_HIPRIO": "1", "ROGUE_GYM_HIP_REGEN_EPB": "64"},
     {"DEV": "1", "ROGUE_GYM_HIP_REGEN_EVERY": "4", "ROGUE_GYM_HIP_REGEN_EPB": "4", "ROGUE_GYM_HIP_ASYNC_FIRST_SPARES": "1", "RG_OBS_BLOCKS": "1024"},
     {"ROGUE_GYM_HIP_EPW": "24"},
-], ids=["dev build: round-2/3 generator scheduling", "dev build: sparse generator launches", "24 envs per step wave"])
+    {"ROGUE_GYM_HIP_WAVE_REGEN": "1"},
+    {"DEV": "1", "ROGUE_GYM_HIP_LANE_WAVES": "3", "ROGUE_GYM_HIP_LANE_EVERY": "3"},
+], ids=["dev build: round-2/3 generator scheduling", "dev build: sparse generator launches", "24 envs per step wave", "spares one level per wave (k_regen)",
+        "dev build: three level-per-lane waves every third step"])
 def test_results_do_not_depend_on_where_the_background_generator_runs(knobs):
     """When and where the spare levels are regenerated (behind which kernel, how often, at which priority, how many envs per generator wave) and how many
     envs a step wave holds decide only whether an auto-reset finds its spare or generates inline -- never what the env looks like afterwards: the

@@ -22,6 +22,11 @@ def test_seed1_clear_map(goldens):
     """python/tests/data.py:83-108 -- full level-1 map, seed 1, no enemies, nohide (1920 cells)."""
     e = OracleEnv(goldens["configs"]["ff"])
     assert diff_cells(e.dungeon(), goldens["screens"]["SEED1_DUNGEON_CLEAR"]) == 0
+
+
+def test_seed1_clear_map_probe_answers(goldens):
+    """SURVEY.md App. A-5 (probe-derived secondary fixture, not held by the reference): the player's cell and the item stream's position after the build."""
+    e = OracleEnv(goldens["configs"]["ff"])
     assert (e.scalars()["px"], e.scalars()["py"]) == (14, 20)
     assert e.rng()[1][1] == 21  # item rng: 18 level-1 gold draws + 3 init-weapon draws
 
