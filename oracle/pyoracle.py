@@ -131,6 +131,7 @@ def lib():
         L.orc_grid.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.orc_monsters.argtypes = [C.c_void_p, C.POINTER(OrcMonster), C.c_int]
         L.orc_rng.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_rooms.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_move_enemy_kat.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.POINTER(C.c_int)] * 2
         L.orc_status_vec.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         for f in ("orc_gray_image", "orc_symbol_image"):
@@ -365,6 +366,13 @@ class OracleEnv:
         n = self._L.orc_monsters(self._e, buf, 512)
         return [dict(x=m.x, y=m.y, type=m.type, active=m.active, running=m.running, hp=m.hp, max_hp=m.max_hp,
                      level=m.level, defense=m.defense, exp=m.exp) for m in buf[:n]]
+
+    def rooms(self):
+        """Rooms of the current level (orc_rooms): kind 0 normal / 1 maze / 2 empty, flags, range and assigned area as half-open (x0, y0, x1, y1)."""
+        buf = np.zeros(12 * 512, np.int32)
+        n = self._L.orc_rooms(self._e, buf.ctypes.data, 512)
+        r = buf[:12 * n].reshape(n, 12)
+        return [dict(kind=int(q[0]), dark=bool(q[1]), visited=bool(q[2]), has_gold=bool(q[3]), range=tuple(int(v) for v in q[4:8]), assigned=tuple(int(v) for v in q[8:12])) for q in r]
 
     def rng(self):
         s = np.empty(12, np.uint32)

@@ -1328,6 +1328,18 @@ void orc_scalars(const orc_env *e, int64_t out[16]) {
     uint32_t st[10]; player_status(e, st); out[9] = st[1];
     out[11] = e->n_pack; out[12] = e->weapon; out[13] = e->armor;
 }
+/* rooms of the current level, 12 ints each: kind (0 normal 1 maze 2 empty), is_dark, is_visited, has_gold, range x0 y0 x1 y1 (Empty: up_left twice),
+ * assigned area x0 y0 x1 y1 -- for tests/shadow_turn.py, which re-derives the turn from the source text and starts every level from the oracle's */
+int orc_rooms(const orc_env *e, int32_t *out, int cap) {
+    for (int i = 0; i < e->fl.n_rooms && i < cap; i++) {
+        const room_t *rm = &e->fl.rooms[i]; int32_t *o = out + 12 * i;
+        o[0] = rm->kind; o[1] = rm->is_dark; o[2] = rm->is_visited; o[3] = rm->has_gold;
+        if (rm->kind == RK_EMPTY) { o[4] = o[6] = rm->upx; o[5] = o[7] = rm->upy; }
+        else { o[4] = rm->range.x0; o[5] = rm->range.y0; o[6] = rm->range.x1; o[7] = rm->range.y1; }
+        o[8] = rm->assigned.x0; o[9] = rm->assigned.y0; o[10] = rm->assigned.x1; o[11] = rm->assigned.y1;
+    }
+    return e->fl.n_rooms;
+}
 int orc_monsters(const orc_env *e, orc_monster *out, int cap) {
     mon_t all[2 * MAX_MON]; int act[2 * MAX_MON]; int n = 0;
     /* tag by sorting pairs: small n, do a simple insertion by (x,y) */

@@ -121,6 +121,7 @@ void orc_grid(const orc_env *e, uint8_t *surface, uint8_t *attr, uint8_t *doors,
 /* out: px,py,level,hp,hp_max,exp,plevel,food_left,quiet,gold,n_monsters,pack items,equipped weapon slot (-1 none),equipped armor slot (-1 none) */
 void orc_scalars(const orc_env *e, int64_t out[16]);
 int orc_monsters(const orc_env *e, orc_monster *out, int cap); /* sorted by (x,y) */
+int orc_rooms(const orc_env *e, int32_t *out, int cap);          /* 12 ints per room, see rogue_oracle.c */
 /* rng state: 3 streams (dungeon,item,enemy) x {x,y,z,w}; counts = u32 outputs consumed */
 void orc_rng(const orc_env *e, uint32_t state[12], uint64_t counts[3]);
 /* Dungeon::move_enemy with skip = |_| false (rogue/mod.rs:339-375), for the reference KAT
