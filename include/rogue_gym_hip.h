@@ -86,6 +86,10 @@ int rg_step(rg_t *h, const uint8_t *keys, int keys_on_device);
  * key; surplus keys are dropped.  (The reference then blocks forever on the reply of the envs that got no instruction; here they simply keep
  * their state, reward 0.)  rg_step == rg_step_prefix with n_keys = n_env. */
 int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device);
+/* rg_step followed by rg_obs_gray(status_flag, with_hist, out_dev) as ONE call -- what a learner's loop does every step (GameState::react then
+ * PlayerState::gray_image, python/src/lib.rs:72-87,251-256): one trip through the binding instead of two.  (A step kernel whose waves also drew and
+ * encoded their own envs was built and measured in round 5: 196 us against 52 + 44 us for the two launches -- profiles/r05_experiments.txt.) */
+int rg_step_obs_gray(rg_t *h, const uint8_t *keys, int keys_on_device, uint32_t status_flag, int with_hist, float *out_dev);
 /* Wait for the stream; returns non-zero (and sets the error text) if any env raised an error flag
  * since the last call (invalid key / action while dead), like the PyRuntimeError of lib.rs:20-26. */
 int rg_sync(rg_t *h);

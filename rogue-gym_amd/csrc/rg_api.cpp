@@ -537,7 +537,11 @@ int rg_reset(rg_t *h) {
     return 0;
 }
 
+static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, float *out_dev);
 int rg_step(rg_t *h, const uint8_t *keys, int keys_on_device) { return rg_step_prefix(h, keys, h->S.n, keys_on_device); }
+int rg_step_obs_gray(rg_t *h, const uint8_t *keys, int keys_on_device, uint32_t status_flag, int with_hist, float *out_dev) {
+    return rg_step_prefix(h, keys, h->S.n, keys_on_device) ? 1 : obs_common(h, status_flag, with_hist, 0, out_dev);
+}
 
 int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device) {
     HIPCHK(h, hipSetDevice(h->device));

@@ -88,8 +88,13 @@ class HipVecRogueEnv:
         if keys.dtype != self.torch.uint8 or keys.device != self.device or not keys.is_contiguous() or keys.numel() != self.num_envs:
             raise ValueError("step_keys needs a contiguous uint8 tensor of %d keys on %s, got %s %s on %s"
                              % (self.num_envs, self.device, tuple(keys.shape), keys.dtype, keys.device))
-        self._h.check(self._h.L.rg_step(self._h.h, C.c_void_p(keys.data_ptr()), 1))
-        obs = self._encode()
+        if self._sym:
+            self._h.check(self._h.L.rg_step(self._h.h, C.c_void_p(keys.data_ptr()), 1))
+            obs = self._encode()
+        else:  # the step and the gray observation as one call: fused into one kernel where the config allows it (rg_step_obs_gray)
+            self._h.check(self._h.L.rg_step_obs_gray(self._h.h, C.c_void_p(keys.data_ptr()), 1, self.image_setting.status.value, int(self.image_setting.includes_hist),
+                                                      C.c_void_p(self.obs.data_ptr())))
+            obs = self.obs
         return obs, self.reward, self.done
 
     def step(self, actions):

@@ -896,3 +896,42 @@ def test_stair_reward_through_the_cabi_alone(goldens):
     hip.sync()
     compare_mirrors(hip, oracles, "end")
     assert paid >= 200
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flag,with_hist,max_steps", [(0, False, 1000), (0b111111111, True, 40)], ids=["gray", "gray + every status plane + history, 40-step episodes"])
+def test_fused_step_and_observation_equals_the_two_calls(goldens, flag, with_hist, max_steps):
+    """rg_step_obs_gray (step and gray observation behind ONE entry point) against rg_step followed by rg_obs_gray on a second handle with the same seeds and
+    keys: the f32 observation of every env after every step, bit for bit, and -- periodically -- the screen / history / status / flag mirrors the pass
+    refreshes on the way.  8 192 envs (stair waves, resets from spares, descents with ready structures all occur), run keys included."""
+    import torch
+    n = 8192
+    cfgs = [json.dumps(dict(goldens["configs"]["mini"], seed=i % 3000)) for i in range(n)]
+    a = inner_handle(cfgs, max_steps)
+    b = inner_handle(cfgs, max_steps)
+    L = a.L
+    ch = L.rg_obs_channels(a.h, 0, flag, int(with_hist))
+    oa = torch.empty((n, ch, 16, 32), dtype=torch.float32, device="cuda")
+    ob = torch.full((n, ch, 16, 32), -1.0, dtype=torch.float32, device="cuda")
+    rng = np.random.RandomState(12)
+    table = np.frombuffer(b"hjklyubnhjklyubnHJKL>s.", np.uint8)
+    for t in range(300):
+        keys = np.ascontiguousarray(table[rng.randint(0, len(table), n)])
+        a.check(L.rg_step_obs_gray(a.h, keys.ctypes.data, 0, flag, int(with_hist), C.c_void_p(oa.data_ptr())))
+        b.check(L.rg_step(b.h, keys.ctypes.data, 0))
+        b.check(L.rg_obs_gray(b.h, flag, int(with_hist), C.c_void_p(ob.data_ptr())))
+        torch.cuda.synchronize()
+        if not torch.equal(oa, ob):
+            bad = (oa != ob).flatten(1).any(1).nonzero().flatten()[:8].tolist()
+            raise AssertionError("step %d: observations differ for envs %s" % (t, bad))
+        if t % 25 == 24:
+            for x, y, what in zip(a.fetch(), b.fetch(), ("screen", "hist", "status", "flags")):
+                assert np.array_equal(x, y), (t, what)
+    a.check(L.rg_sync(a.h))
+    a.close()
+    b.close()
+
+
+def inner_handle(cfgs, max_steps):
+    from rogue_gym_python import _rogue_gym as inner
+    return inner._Handle(cfgs, max_steps, auto_reset=True)
