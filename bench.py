@@ -244,7 +244,7 @@ def main():
                     "the metric is defined on (the first --steps of them are timed and reported as preroll.cold_start); 0 = off.  1.5 x max_steps: "
                     "not on a multiple of max_steps, where the survivors of the synchronised first episodes all reset at once")
     ap.add_argument("--time-every", type=int, default=7, help="time every N-th launch of each kernel with a HIP-event pair (every 5th when steps < 64, every one when < 16); odd on purpose: "
-                    "the background generator runs beside every second k_step, an even stride would sample one kind only")
+                    "an even stride could lock onto a period of the workload")
     ap.add_argument("--gather-steps", type=int, default=50, help="extra steps timed WITH the observation all-gather (N>1)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -336,8 +336,8 @@ def main():
         hz.step()
     # HIP-event pairs handed to a launch cost stream time: measured in round 4 at ~10 us per step with every 3rd launch of both kernels timed (a
     # 20-step window: 131-143 us per step against 120-129 without, tools/tmp/window_fit2.py).  So few samples for short runs: every 5th launch = 4 pairs
-    # per kernel for the driver's 20 steps, and an ODD stride because k_step is bimodal (~68 us without, ~82 us with the background generator beside it,
-    # which runs beside every second one): strides 5 / 7 alternate between the two kinds, an even stride would sample one kind only.
+    # per kernel for the driver's 20 steps.  The strides are odd out of caution only: since round 4 the generator runs beside EVERY k_step, there are no
+    # two kinds of launch left to alternate between.
     every = 1 if K < 16 else (5 if K < 64 else args.time_every)
     hz.timing(every)  # HIP-event pairs on the launch stream around every `every`-th launch of each kernel
     env.counters(reset=True)
@@ -354,8 +354,14 @@ def main():
     env.check_errors()
 
     tmax = torch.tensor([dt], dtype=torch.float64)
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": dev.index, "pci_bus_id": getattr(props, "pci_bus_id", None),
+            "name": props.name}
+    rank_devices = [mine]
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, mine)
     dt_max = float(tmax.item())
 
     # ---- 4 further runs of K steps (no event timing): the spread of the headline number ----
@@ -447,6 +453,9 @@ def main():
         if not one_device:  # two ranks cannot share one GPU under RCCL: the C-ABI communicator needs one device per rank
             def cabi():
                 env.init_comm()
+                cnt, urank = env.comm_count()   # what RCCL itself says (ncclCommCount / ncclCommUserRank)
+                gather["ranks"] = {"rccl_comm_count": cnt, "rccl_user_rank_of_rank0": urank, "world_size": world,
+                                   "torch_data_group_size": dist.get_world_size(data_group) if data_group is not None else None}
                 leg("value_cabi")
             gather_legs.append(("value_cabi", cabi))
     else:
@@ -463,21 +472,29 @@ def main():
         achieved = hz.algo_bytes * n / dom_s / 1e9
         own_bytes = {"k_step": hz.step_bytes, "k_obs": hz.obs_bytes}.get(dom, hz.algo_bytes) * n  # the dominant kernel's OWN algorithmic bytes per launch
         e2e = hz.algo_bytes * n / (dt_max / K) / 1e9
-        traffic, traffic_all, traffic_src = None, None, None
+        traffic, traffic_all, traffic_src, traffic_build = None, None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from rocprofv3 --pmc passes (see profiles/README.md)
         if os.path.exists(pmc) and args.workload == "mini" and n == 65536:  # the PMC passes ran on 65 536 envs per launch
             with open(pmc) as f:
                 pj = json.load(f)
+            traffic_build = pj.get("_build_id")
             traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
             traffic_src = pj.get("_measured", "profiles/pmc_traffic.json (rocprofv3 --pmc passes; build not stamped)")
             traffic_all = {k: {"hbm_bytes_per_launch": v.get("hbm_bytes_per_launch"), "hbm_bytes_per_env_step": (v.get("hbm_bytes_per_launch") or 0) / 65536.0}
                            for k, v in pj.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
+        build_id = env._h.L.rg_build_id().decode()
+        if traffic is not None and traffic_build != build_id:
+            # the PMC passes are a separate rocprofv3 collection (profiles/pmc_traffic.json): a figure taken on another build of the kernels is not reported
+            traffic_src = "profiles/pmc_traffic.json was collected on build %s, this library is %s: traffic withheld" % (traffic_build, build_id)
+            traffic, traffic_all = None, None
         out = {
             "metric": "env-steps/sec (whole node) at 65 536 envs, 32x16 mini-dungeon" if args.workload == "mini" and n == 65536
                       else "env-steps/sec (whole node), workload %s, %d envs per GPU" % (args.workload, n),
             "value": n * world * K / dt_max,
             "unit": "env-steps/s",
             "n_gpus": world,
+            "n_gpus_visible": torch.cuda.device_count(),
+            "rank_devices": rank_devices,   # per rank: LOCAL_RANK, the HIP device it stepped on and that device's PCI bus id -- a mis-mapped LOCAL_RANK shows here
             "steps": K,
             "warmup": W,
             "ms_per_step": dt_max / K * 1e3,
@@ -494,7 +511,7 @@ def main():
             "config": {"workload": "%s, %d envs per GPU (%d total), %s-image obs [N,%d,%d,%d] f32, max_steps 1000, auto-reset"
                                    % (hz.desc, n, n * world, hz.obs_kind, env.channels, env.height, env.width), "envs_per_gpu": n,
                        "parallelism": "env-sharded x%d, no data-path collective" % world},
-            "build_id": env._h.L.rg_build_id().decode(),  # sha256[:16] of the library's sources (__graft_entry__.source_id)
+            "build_id": build_id,  # sha256[:16] of the library's sources (__graft_entry__.source_id)
             "clock_warm": clock_warm,
             "preroll": preroll,
             "sclk_mhz_after_timed_region": sclk_after,
@@ -503,7 +520,7 @@ def main():
             # `kernel_algorithmic_bytes` -- ITS OWN share of the step's bytes -- not against `achieved`: k_step touches 4.7x what it needs (a 64-B line per
             # 2-byte word) and is still at 7 % of HBM: a latency kernel.
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel_algorithmic_bytes": own_bytes,
+                         "traffic": traffic, "traffic_build_id": traffic_build, "kernel_algorithmic_bytes": own_bytes,
                          "traffic_over_kernel_algorithmic": (traffic / own_bytes) if traffic else None,
                          "kernel_avg_us": dom_s * 1e6, "step_algorithmic_bytes": hz.algo_bytes * n,
                          "frac_end_to_end": e2e / HBM_PEAK_GBPS, "achieved_end_to_end": e2e,

@@ -184,6 +184,8 @@ int rg_pack_compact(rg_t *h, int with_hist, uint8_t *out_dev);
 int rg_comm_unique_id(uint8_t id[128]);
 int rg_comm_init(rg_t *h, const uint8_t id[128], int rank, int world);
 int rg_comm_destroy(rg_t *h);
+/* What the communicator reports about itself (ncclCommCount / ncclCommUserRank) -- not what rg_comm_init was told. */
+int rg_comm_count(rg_t *h, int *count, int *rank);
 int rg_allgather_compact(rg_t *h, int with_hist, uint8_t *out_dev);
 int rg_expand_compact(rg_t *h, const uint8_t *packed_dev, int n, int packed_has_hist, int kind, uint32_t status_flag, int with_hist, float *out_dev);
 

@@ -592,15 +592,17 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
     if (regen) {
         TimedLaunch t(h, 4, true);
         if (h->lane_regen) {
-            // The next-level structures -- wanted within two steps -- one per wave, beside every step (gate + k_regen on `side`), The spares -- wanted when the env's next episode ends, and under the random policy a
-            // fifth of the episodes are over within 13 steps -- one level per LANE (rg_regen_lanes.hip), with every step too: a round of 64 levels takes a wave
-            // longer than a step, so the launches alternate between two streams of their own.  
+            // Two producers.  Beside EVERY step (gate + k_regen on `side`), one level per wave: the next-level structures -- wanted within two steps -- and
+            // the urgent spares (an env down to its last ready one).  Every 32nd step, one level per LANE (rg_regen_lanes.hip): every spare consumed since,
+            // ~10 000 of the 4 x 65 536.  A round of 64 levels takes a wave 300-450 us whatever the launch's size, i.e. three to five steps: launched beside
+            // every fourth step, one of them was still running behind ANY short window of steps (the driver's 20: +24 us per step); the launches
+            // alternate between two streams of their own.
             static const int lane_waves = RG_DEV_ENV("ROGUE_GYM_HIP_LANE_WAVES") ? atoi(RG_DEV_ENV("ROGUE_GYM_HIP_LANE_WAVES")) : 256;
-            static const int lane_every = RG_DEV_ENV("ROGUE_GYM_HIP_LANE_EVERY") ? atoi(RG_DEV_ENV("ROGUE_GYM_HIP_LANE_EVERY")) : 4;
+            static const int lane_every = RG_DEV_ENV("ROGUE_GYM_HIP_LANE_EVERY") ? atoi(RG_DEV_ENV("ROGUE_GYM_HIP_LANE_EVERY")) : 32;
             static const bool time_lanes = RG_DEV_ENV("ROGUE_GYM_HIP_TIME_LANES") != nullptr;  // (development: the event pair of rg_timing's kernel 4 goes to the level-per-lane launch)
             const bool lanes_now = h->regen_bulk > 0 || h->step_count - h->lane_last >= (uint64_t)(lane_every > 0 ? lane_every : 1);
-            if (h->S.nx_state) rgk_regen(&h->SP, &h->cfg, 0, 0, h->S.launch_mark, (uint32_t)h->S.stair_gen + 1u, h->d_err, h->side, time_lanes ? nullptr : t.start_ev(), time_lanes ? nullptr : t.stop_ev());
-            else if (!time_lanes) t.cancel();
+            // (spares = 2: next-level structures + the urgent spares -- envs down to their last ready one; rg_kernels.hip regen_body)
+            rgk_regen(&h->SP, &h->cfg, 0, 2, h->S.launch_mark, (uint32_t)h->S.stair_gen + 1u, h->d_err, h->side, time_lanes ? nullptr : t.start_ev(), time_lanes ? nullptr : t.stop_ev());
             if (time_lanes && !lanes_now) t.cancel();
             if (lanes_now) {
                 h->lane_last = h->step_count;
@@ -855,6 +857,8 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;     // optional (rg_comm_count)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;  // optional
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
 };
@@ -873,6 +877,8 @@ Rccl *rccl() {
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
         r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.lib, "ncclCommAbort"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.lib, "ncclCommUserRank"));
         if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString) r.err = "librccl lacks an expected symbol";
     });
     return &r;
@@ -916,6 +922,20 @@ static int comm_release(rg_handle *h, bool teardown) {
     return 0;
 }
 int rg_comm_destroy(rg_t *h) { return comm_release(h, false); }
+
+// What the COMMUNICATOR says about itself (ncclCommCount / ncclCommUserRank), not what rg_comm_init was told: the proof that RCCL saw `world` ranks.
+int rg_comm_count(rg_t *h, int *count, int *rank) {
+    if (!h->comm) { h->err = "rg_comm_count: no communicator (rg_comm_init first)"; return 1; }
+    Rccl *r = rccl();
+    if (!r->CommCount || !r->CommUserRank) { h->err = "rg_comm_count: librccl lacks ncclCommCount / ncclCommUserRank"; return 1; }
+    int c = 0, u = 0;
+    ncclResult_t e = r->CommCount(h->comm, &c);
+    if (e == ncclSuccess) e = r->CommUserRank(h->comm, &u);
+    if (e != ncclSuccess) { h->err = std::string("ncclCommCount: ") + r->GetErrorString(e); return 1; }
+    if (count) *count = c;
+    if (rank) *rank = u;
+    return 0;
+}
 
 int rg_allgather_compact(rg_t *h, int with_hist, uint8_t *out_dev) {
     if (!h->comm) { h->err = "rg_allgather_compact: no communicator (rg_comm_init first)"; return 1; }

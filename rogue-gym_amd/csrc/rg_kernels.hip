@@ -810,16 +810,18 @@ __device__ __forceinline__ void place_player(const RgState &S, const RgConfig &c
 // their own k, and nothing is read-modify-written non-atomically.  With a seed_range the value is uniform in [r0, r1) by mask rejection
 // (no 128-bit division on the device).
 __device__ __forceinline__ void build_prologue(const RgState &S, Env &E) {
-    uint64_t lo = uni((uint32_t)S.seed_lo[E.e]) | ((uint64_t)uni((uint32_t)(S.seed_lo[E.e] >> 32)) << 32);
-    uint64_t hi = uni((uint32_t)S.seed_hi[E.e]) | ((uint64_t)uni((uint32_t)(S.seed_hi[E.e] >> 32)) << 32);
-    const uint32_t mode = uni(S.reseed[E.e]);
+    // (E.e may be an entry of the spare view, slot * n + env -- rg_state.h sp_slots: the seed arrays are the envs' own)
+    const int se = E.e >= S.n ? E.e % S.n : E.e;
+    uint64_t lo = uni((uint32_t)S.seed_lo[se]) | ((uint64_t)uni((uint32_t)(S.seed_lo[se] >> 32)) << 32);
+    uint64_t hi = uni((uint32_t)S.seed_hi[se]) | ((uint64_t)uni((uint32_t)(S.seed_hi[se] >> 32)) << 32);
+    const uint32_t mode = uni(S.reseed[se]);
     if (mode) {
         uint32_t k = 0;
-        if (threadIdx.x == 0) k = atomicAdd(&S.build_ctr[E.e], 1u);  // wave-uniform caller: one lane takes the ticket
+        if (threadIdx.x == 0) k = atomicAdd(&S.build_ctr[se], 1u);  // wave-uniform caller: one lane takes the ticket
         k = uni(k);
         uint64_t z = splitmix64(lo ^ splitmix64(hi + k)), y = splitmix64(z ^ hi);
         if (mode == 2 && S.range_lo) {
-            const int n = E.n, e = E.e;
+            const int n = S.n, e = se;
             const uint64_t r_lo = S.range_lo[e], r_hi = S.range_lo[n + e], sp_lo = S.range_span[e], sp_hi = S.range_span[n + e];
             uint64_t m_lo, m_hi;  // smallest 2^b - 1 >= span - 1
             if (sp_hi) { m_lo = ~0ull; m_hi = ~0ull >> __clzll((long long)sp_hi); }
@@ -851,7 +853,7 @@ __device__ __forceinline__ void build_epilogue(const RgState &S, const RgConfig 
 // over the lanes.  Requests of several lanes are served one after the other.  is_build: GameConfig::build, else
 // Dungeon::new_level (rogue/mod.rs:434-481) followed by actions::new_level's player placement.
 __device__ __forceinline__ void env_from_lane(Env &U, const Env &E, int src) {
-    U.e = (int)lane_get((uint32_t)E.e, src); U.n = E.n;
+    U.e = (int)lane_get((uint32_t)E.e, src); U.n = (int)lane_get((uint32_t)E.n, src);  // (the SoA stride is the request's: a spare-view entry and a next-level request may share a wave)
     uint32_t *d = reinterpret_cast<uint32_t *>(&U.rd);
     const uint32_t *q = reinterpret_cast<const uint32_t *>(&E.rd);
 #pragma unroll
@@ -937,7 +939,7 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
         RgState L = S;
         L.room_rect = T->room_rect; L.room_meta = T->room_meta; L.mon_w0 = T->mon_w0; L.mon_hp = T->mon_hp; L.mon_exp = T->mon_exp;
         L.gold_pos = T->gold_pos; L.gold_amt = T->gold_amt; L.edge_a = T->edge_a; L.edge_b = T->edge_b;
-        L.maze_stack = S.maze_stack + (size_t)real_e * S.maze_cap;
+        L.maze_stack = S.maze_stack + (size_t)(real_e >= S.n ? real_e % S.n : real_e) * S.maze_cap;  // (per env, also for a spare-view entry)
         U.e = 0; U.n = 1;
         U.g_rect = U.g_meta = U.g_ea = U.g_eb = 0;
 #ifdef RG_FINE_PROF
@@ -978,6 +980,7 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
                     for (int k = 0; k < 8; k++) mine = lane == k ? r[k] : mine;
                     st_pub<true>(&S.nx_rng[(size_t)(4 + lane) * real_n + real_e], mine);
                 }
+                if (lane == src) E.err |= U.err;  // a capacity guard that fired: the caller raises it and does NOT publish the structure
                 __syncthreads();
                 continue;
             }
@@ -1055,7 +1058,7 @@ __device__ __forceinline__ void load_env(const RgState &S, Env &E, int e) {
 }
 template <bool WT = false>
 __device__ __forceinline__ void store_env(const RgState &S, const Env &E) {
-    int n = S.n, e = E.e;
+    int n = E.n, e = E.e;  // (E.n: the SoA stride of the view E.e indexes -- the spare view's is sp_slots * n)
     const uint32_t r[12] = {E.rd.x, E.rd.y, E.rd.z, E.rd.w, E.ri.x, E.ri.y, E.ri.z, E.ri.w, E.re.x, E.re.y, E.re.z, E.re.w};
 #pragma unroll
     for (int k = 0; k < 12; k++) st_pub<WT>(&S.rng[k * n + e], r[k]);
@@ -1184,7 +1187,22 @@ __device__ __forceinline__ void regen_body(const RgState &SP, const RgConfig &c,
     // next step (round 4: k_obs 47.5 -> 52 us with a launch beside every step).  The other consumed spares of the wave's eight envs wait for the next
     // launch, one step later; a spare is wanted an episode after it was consumed.
     // (spares == 0: the consumed spares are rebuilt by the level-per-lane producer, rg_regen_lanes.hip; this launch serves the next-level structures only)
-    const bool want = valid && spares && __hip_atomic_load(&SP.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+    // spares == 1: the wave-per-level producer of the one-slot layout (ROGUE_GYM_HIP_WAVE_REGEN, > 32 rooms).  spares == 2: the consumed spares are rebuilt
+    // 64 levels per wave by rg_regen_lanes.hip, a launch every 32 steps (a round takes 300-450 us whatever its size: a launch beside every few steps left one
+    // running behind every short window of steps); what this launch adds is the URGENT case -- an env that is down to its last ready spare (fixed-seed envs
+    // that die within a dozen steps do so episode after episode) gets one built here, beside the next step.
+    int es = e;  // the spare-view entry to build
+    bool want = false;
+    if (valid && spares == 1) want = __hip_atomic_load(&SP.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+    else if (valid && spares == 2) {
+        int live_slots = 0, free_slot = -1;
+        for (int sl = SP.sp_slots - 1; sl >= 0; sl--) {
+            const uint32_t st = __hip_atomic_load(&SP.sp_ready[(size_t)sl * SP.n + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (st == 0u) free_slot = sl; else live_slots++;  // (ready, or claimed by a producer)
+        }
+        want = live_slots <= 1 && free_slot >= 0;
+        if (want) es = free_slot * SP.n + e;
+    }
     // ... or ONE next-level structure (gen_service), which goes first: it is wanted within two or three steps, a spare an episode later
     const bool want_nx = GM < 2 && valid && SP.nx_state && __hip_atomic_load(&SP.nx_state[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == RG_NX_ASKED;
     const uint64_t wm = __ballot(want), wx = __ballot(want_nx);
@@ -1192,14 +1210,15 @@ __device__ __forceinline__ void regen_body(const RgState &SP, const RgConfig &c,
     bool claim = false, claim_nx = false;
     if (max_claims <= 1) {
         if (wx) { if (lane == __ffsll((long long)wx) - 1) claim_nx = atomicCAS(&SP.nx_state[e], RG_NX_ASKED, RG_NX_CLAIMED) == RG_NX_ASKED; }
-        else if (lane == __ffsll((long long)wm) - 1) claim = atomicCAS(&SP.sp_ready[e], 0u, 2u) == 0u;
+        else if (lane == __ffsll((long long)wm) - 1) claim = atomicCAS(&SP.sp_ready[es], 0u, 2u) == 0u;
     } else {
         if (want_nx) claim_nx = atomicCAS(&SP.nx_state[e], RG_NX_ASKED, RG_NX_CLAIMED) == RG_NX_ASKED;
-        if (want && !claim_nx) claim = atomicCAS(&SP.sp_ready[e], 0u, 2u) == 0u;  // (one kind per lane and launch: the lane's registers carry one request)
+        if (want && !claim_nx) claim = atomicCAS(&SP.sp_ready[es], 0u, 2u) == 0u;  // (one kind per lane and launch: the lane's registers carry one request)
     }
     if (!__any(claim || claim_nx)) return;
     Env E;
-    E.e = valid ? e : 0; E.n = SP.n; E.cell = E.gcell = SP.cell + (size_t)E.e * SP.hw; E.err = 0; E.mc = nullptr;
+    // a spare: entry `es` of the spare view, whose SoA stride is sp_slots * n; a next-level request: the env's own index, stride n
+    E.e = valid ? (claim ? es : e) : 0; E.n = claim ? SP.n * SP.sp_slots : SP.n; E.cell = E.gcell = SP.cell + (size_t)E.e * SP.hw; E.err = 0; E.mc = nullptr;
     Prof pf; pf.start(nullptr);
     E.on_stairs = 0;
     const uint64_t cx = __ballot(claim_nx);
@@ -1218,14 +1237,15 @@ __device__ __forceinline__ void regen_body(const RgState &SP, const RgConfig &c,
     // everything k_step will take over is written THROUGH (st_pub<true>): the hand-off is "sc1 payload, every writing wave drained, then the flag" --
     // no release fence (see st_pub); the consumer's side is an agent-scope acquire (take_spares, step_wave's descent)
     // (ONE call site for both kinds: a second instance of the generator cost the capped kernel scratch memory)
-    gen_service<GM, true>(SP, c, E, lane, e, claim || claim_nx, true, reinterpret_cast<uint16_t *>(g_smem), pf, 0ull, cx);
-    if (claim) { store_env<true>(SP, E); st_pub<true>(&SP.on_stairs[e], (uint8_t)E.on_stairs); }
-    if (claim && E.err) atomicOr(SP.err_any, E.err);  // (the flag word belongs to the concurrently running k_step)
+    gen_service<GM, true>(SP, c, E, lane, E.e, claim || claim_nx, true, reinterpret_cast<uint16_t *>(g_smem), pf, 0ull, cx);
+    if (claim) { store_env<true>(SP, E); st_pub<true>(&SP.on_stairs[es], (uint8_t)E.on_stairs); }
+    if ((claim || claim_nx) && E.err) atomicOr(SP.err_any, E.err);  // (the flag word belongs to the concurrently running k_step)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (claim) __hip_atomic_store(&SP.sp_ready[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (claim) __hip_atomic_store(&SP.sp_ready[es], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // (by CAS: an env that got a new level meanwhile turned the CLAIMED into DROP -- the structure is for a level it has left, and the env may ask again
     // from here on)
-    if (claim_nx && atomicCAS(&SP.nx_state[e], RG_NX_CLAIMED, RG_NX_READY) != RG_NX_CLAIMED)
+    // (a structure whose generation raised a capacity guard is never published: the descent generates inline and raises the guard on the env's own flags)
+    if (claim_nx && (E.err || atomicCAS(&SP.nx_state[e], RG_NX_CLAIMED, RG_NX_READY) != RG_NX_CLAIMED))
         __hip_atomic_store(&SP.nx_state[e], RG_NX_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // The gate in front of a generator launch, alone on the generator's stream: ONE wave that waits until the k_step launched beside it has started
@@ -2392,7 +2412,12 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         // out to be somebody else's (stair_role 2), dead or past max_steps just drops what it loaded.)
         listed = S.stair_mark[(size_t)(S.stair_gen & 1) * S.n + e] != 0;
         uint32_t nxk = 0;  // the last word of the dungeon stream the env's next-level structure starts from
-        if (S.nx_state) { nxs = S.nx_state[e]; nxk = S.nx_rng[(size_t)3 * S.n + e]; }
+        // (k_regen moves these two words while this kernel runs: relaxed agent-scope loads, as on its side -- the protocol tolerates any value that was
+        // current at some point since the previous launch, and an atomic load is what says so to the compiler and the caches)
+        if (S.nx_state) {
+            nxs = __hip_atomic_load(&S.nx_state[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nxk = __hip_atomic_load(&S.nx_rng[(size_t)3 * S.n + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         old_flags = S.flags[e];
         steps = S.steps[e];
         gold0 = S.status[(size_t)e * 10 + 1];
@@ -2810,7 +2835,7 @@ void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st) {
     }
 }
 void rgk_regen_gate(const uint32_t *mark, uint32_t target, uint32_t *err_any, hipStream_t st) { hipLaunchKernelGGL(k_regen_gate, dim3(1), dim3(WAVE), 0, st, mark, target, err_any); }
-// spares = 0: next-level structures only (the spares come from rgk_regen_lanes): nothing but the ~20 requests of a step to find, so 64 envs per wave
+// spares = 0: next-level structures only; 2: ... and the URGENT spares (regen_body; the bulk comes from rgk_regen_lanes): a few dozen requests per step to find, so 64 envs per wave
 void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, int spares, const uint32_t *mark, uint32_t target, uint32_t *err_any, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     if (mark) rgk_regen_gate(mark, target, err_any, st);
     int hw = c->width * c->height;
@@ -2821,11 +2846,11 @@ void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, int spares, const
     // (bulk: every consumed spare the wave finds, not one -- the launches that build ALL spares: creation, after rg_seed)
 #ifdef RG_DEV_KNOBS
     static const int epb_env = getenv("ROGUE_GYM_HIP_REGEN_EPB") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_EPB")) : 0;
-    const int epb = (epb_env >= 4 && epb_env <= WAVE) ? epb_env : (spares ? 8 : WAVE);
+    const int epb = (epb_env >= 4 && epb_env <= WAVE) ? epb_env : (spares == 1 ? 8 : WAVE);
     static const int claims_env = getenv("ROGUE_GYM_HIP_REGEN_CLAIMS") ? atoi(getenv("ROGUE_GYM_HIP_REGEN_CLAIMS")) : 1;
     const int max_claims = bulk ? WAVE : claims_env;
 #else
-    const int epb = spares ? 8 : WAVE, max_claims = bulk ? WAVE : 1;
+    const int epb = spares == 1 ? 8 : WAVE, max_claims = bulk ? WAVE : 1;
 #endif
     const dim3 grid((SP->n + epb - 1) / epb);
     // (ev0 / ev1: optional events stamped with this dispatch's own begin and end -- rg_timing, kernel 4)

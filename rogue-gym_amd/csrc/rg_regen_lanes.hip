@@ -686,14 +686,19 @@ int rgk_regen_lanes(const RgState *SP, const RgConfig *c, uint32_t *q, int32_t *
     static const int prio_env = getenv("ROGUE_GYM_HIP_LANE_PRIO") ? atoi(getenv("ROGUE_GYM_HIP_LANE_PRIO")) : 0;
     prio = prio_env;
 #endif
+    int L = p.lanes;
+#ifdef RG_DEV_KNOBS
+    static const int l_env = getenv("ROGUE_GYM_HIP_LANE_L") ? atoi(getenv("ROGUE_GYM_HIP_LANE_L")) : 0;  // fewer levels per wave and round (steady-state launches only)
+    if (!bulk && l_env >= 4 && l_env < L) L = l_env & ~3;
+#endif
     (void)hipMemsetAsync(q, 0, 4, st);
     const int n_sp = SP->n * slots;
     hipLaunchKernelGGL(k_lanes_scan, dim3((n_sp + LG_SCAN_EPW - 1) / LG_SCAN_EPW), dim3(WAVE), 0, st, SP->sp_ready, n_sp, q, list);
-    if (bulk) waves = (n_sp + p.lanes - 1) / p.lanes;
+    if (bulk) waves = (n_sp + L - 1) / L;
     if (waves < 1) waves = 1;
     const dim3 grid(waves);
-    if (ev0 || ev1) hipExtLaunchKernelGGL(k_regen_lanes, grid, dim3(WAVE), (uint32_t)p.smem, st, ev0, ev1, 0, *SP, *c, q, list, p.lanes, p.lane_stride, p.tab_off, p.stk_off, SP->maze_cap, slots, prio, prof);
-    else hipLaunchKernelGGL(k_regen_lanes, grid, dim3(WAVE), p.smem, st, *SP, *c, q, list, p.lanes, p.lane_stride, p.tab_off, p.stk_off, SP->maze_cap, slots, prio, prof);
+    if (ev0 || ev1) hipExtLaunchKernelGGL(k_regen_lanes, grid, dim3(WAVE), (uint32_t)p.smem, st, ev0, ev1, 0, *SP, *c, q, list, L, p.lane_stride, p.tab_off, p.stk_off, SP->maze_cap, slots, prio, prof);
+    else hipLaunchKernelGGL(k_regen_lanes, grid, dim3(WAVE), p.smem, st, *SP, *c, q, list, L, p.lane_stride, p.tab_off, p.stk_off, SP->maze_cap, slots, prio, prof);
     return 1;
 }
 }

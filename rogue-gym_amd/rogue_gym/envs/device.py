@@ -149,6 +149,12 @@ class HipVecRogueEnv:
         self._h.check(self._h.L.rg_comm_init(self._h.h, buf, int(rank), int(world)))
         self._comm = (int(rank), int(world))
 
+    def comm_count(self):
+        """(ranks, this rank) as the RCCL communicator itself reports them (rg_comm_count = ncclCommCount / ncclCommUserRank)."""
+        c, r = C.c_int(), C.c_int()
+        self._h.check(self._h.L.rg_comm_count(self._h.h, C.byref(c), C.byref(r)))
+        return c.value, r.value
+
     @staticmethod
     def comm_unique_id() -> bytes:
         L = inner.load_library()

@@ -43,7 +43,7 @@ _lib = None
 _INT_FUNCS = (
     "rg_create", "rg_dims", "rg_env_dims", "rg_env_symbols", "rg_set_stream", "rg_seed", "rg_reset", "rg_step", "rg_step_prefix", "rg_step_obs_gray", "rg_sync", "rg_screen", "rg_hist", "rg_status", "rg_flags",
     "rg_reward", "rg_done", "rg_set_stair_reward", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_encode_host_batch", "rg_obs_host",
-    "rg_host_alloc", "rg_dev_alloc", "rg_snapshot_take", "rg_dev_read", "rg_dev_read_rows", "rg_compact_record_bytes", "rg_pack_compact", "rg_expand_compact", "rg_comm_unique_id", "rg_comm_init", "rg_comm_destroy", "rg_allgather_compact", "rg_status_vec", "rg_history_enable", "rg_history_keys",
+    "rg_host_alloc", "rg_dev_alloc", "rg_snapshot_take", "rg_dev_read", "rg_dev_read_rows", "rg_compact_record_bytes", "rg_pack_compact", "rg_expand_compact", "rg_comm_unique_id", "rg_comm_init", "rg_comm_destroy", "rg_comm_count", "rg_allgather_compact", "rg_status_vec", "rg_history_enable", "rg_history_keys",
     "rg_dump_history", "rg_counters", "rg_counters_ex", "rg_probe_sclk", "rg_dump_config", "rg_config_canonical", "rg_config_resolved", "rg_config_schema", "rg_debug_fetch", "rg_debug_descend", "rg_timing_enable", "rg_timing_read", "rg_timing_read_all",
 )
 
@@ -90,7 +90,7 @@ def load_library():
         "rg_host_alloc": [sz, C.POINTER(vp)], "rg_host_free": [vp],
         "rg_dev_alloc": [i32, sz, C.POINTER(vp)], "rg_dev_free": [i32, vp], "rg_snapshot_take": [vp, vp], "rg_dev_read": [vp, vp, vp, sz], "rg_dev_read_rows": [vp, vp, sz, vp, sz, i32],
         "rg_compact_record_bytes": [vp, i32], "rg_pack_compact": [vp, i32, vp], "rg_expand_compact": [vp, vp, i32, i32, i32, u32, i32, vp],
-        "rg_comm_unique_id": [vp], "rg_comm_init": [vp, vp, i32, i32], "rg_comm_destroy": [vp], "rg_allgather_compact": [vp, i32, vp],
+        "rg_comm_unique_id": [vp], "rg_comm_init": [vp, vp, i32, i32], "rg_comm_destroy": [vp], "rg_comm_count": [vp, vp, vp], "rg_allgather_compact": [vp, i32, vp],
         "rg_status_vec": [vp, u32, vp],
         "rg_history_enable": [vp, i32], "rg_history_keys": [vp, i32, i32, vp, sz, C.POINTER(u32)],
         "rg_dump_history": [vp, i32, i32, C.c_char_p, sz, C.POINTER(sz)],

@@ -198,6 +198,39 @@ def test_spare_hand_off_at_full_batch(goldens):
     b.close()
 
 
+def test_urgent_spares_of_envs_that_die_fast(goldens):
+    """The bulk of the consumed spares is rebuilt every 32nd step (one level per lane, rg_regen_lanes.hip); an env that is down to its last ready spare gets
+    one built beside the very next step by the wave-per-level producer (k_regen, spares == 2).  Episodes of 6 steps consume a spare every 6 steps -- five or
+    six between two bulk launches, more than the four slots -- so nearly every reset here depends on the urgent path, with both producers claiming slots of
+    the same envs.  Same bits as a handle that generates every reset inline, and the resets did take spares."""
+    import os
+
+    from rogue_gym_python import _rogue_gym as inner
+
+    n, steps = 4096, 330
+    cfgs = [json.dumps(dict(goldens["configs"]["mini"], seed=i % 700)) for i in range(n)]
+    a = inner._Handle(cfgs, 6, auto_reset=True)
+    os.environ["ROGUE_GYM_HIP_NO_SPARES"] = "1"
+    try:
+        b = inner._Handle(cfgs, 6, auto_reset=True)
+    finally:
+        del os.environ["ROGUE_GYM_HIP_NO_SPARES"]
+    rng = np.random.RandomState(11)
+    table = np.frombuffer(b"hjklyubn>s.", np.uint8)
+    for t in range(steps):
+        keys = np.ascontiguousarray(table[rng.randint(0, len(table), n)])
+        for h in (a, b):
+            h.check(h.L.rg_step(h.h, keys.ctypes.data, 0))
+        if t % 3 == 2:
+            for x, y, what in zip(a.fetch(), b.fetch(), ("screen", "hist", "status", "flags")):
+                assert np.array_equal(x, y), (t, what, [i for i in range(n) if not np.array_equal(x[i], y[i])][:8])
+    cnt = (ctypes.c_uint64 * 8)()
+    a.check(a.L.rg_counters(a.h, cnt, 0))
+    assert cnt[0] > 200000 and cnt[4] > 0.8 * cnt[0], list(cnt)   # resets; most of them took a spare (1024-env waves x one urgent build per wave and step keep up)
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("name,n,steps", [("mini", 16384, 500), ("default", 4096, 700), ((160, 48, 8, 5), 2048, 300), ((50, 21, 3, 2), 4096, 400)],
                          ids=["mini", "default", "160x48, 40 rooms (the 64-room generator instance)", "50x21 (cells not a multiple of 8)"])
 def test_next_level_structures_match_inline_generation(goldens, name, n, steps):
