@@ -247,6 +247,8 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
               dev_alloc(h, &S.dc_map, h->cfg.n_enemies > 0 ? n * RG_DIST_SLOTS * hw : 16) && dev_alloc(h, &S.dc_key, RG_DIST_SLOTS * n) &&
               dev_alloc(h, &S.dc_head, n) && dev_alloc(h, &S.dc_len, n) && dev_alloc(h, &S.dc_part, n) && dev_alloc(h, &S.dc_own, n) && dev_alloc(h, &S.status, n * 10) &&
               dev_alloc(h, &h->d_err, 4) && dev_alloc(h, &h->d_keys, n);
+    // the envs' observation records (rg_state.h obs_rec): for the grids the fused observation pass handles
+    if (ok && nr <= RG_OBS_MAX_ROOMS) ok = dev_alloc(h, &S.obs_rec, n * (size_t)RG_OBS_REC_WORDS(nr));
     h->spares = auto_reset != 0 && getenv("ROGUE_GYM_HIP_NO_SPARES") == nullptr;
     // which producer refills the consumed spares: one level per LANE (rg_regen_lanes.hip; two spares per env, rg_state.h sp_slots) where it applies,
     // else -- or with ROGUE_GYM_HIP_WAVE_REGEN=1 -- one level per wave (k_regen, one spare per env)

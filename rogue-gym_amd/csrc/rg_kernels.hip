@@ -1007,6 +1007,12 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
             st_pub<WT>(&S.room_rect[g], T->room_rect[r]); st_pub<WT>(&S.room_meta[g], T->room_meta[r]);
             st_pub<WT>(&S.mon_w0[g], T->mon_w0[r]); st_pub<WT>(&S.mon_hp[g], T->mon_hp[r]); st_pub<WT>(&S.mon_exp[g], T->mon_exp[r]);
             st_pub<WT>(&S.gold_pos[g], T->gold_pos[r]); st_pub<WT>(&S.gold_amt[g], T->gold_amt[r]);
+            if constexpr (!WT) {  // (the live view's tables: the env's observation record follows them -- rg_state.h obs_rec; the player's word is the caller's)
+                if (S.obs_rec) {
+                    uint32_t *rec = S.obs_rec + (size_t)real_e * RG_OBS_REC_WORDS(nrooms);
+                    rec[r] = T->mon_w0[r]; rec[nrooms + 1 + r] = T->room_rect[r]; reinterpret_cast<uint8_t *>(&rec[2 * nrooms + 1])[r] = T->room_meta[r];
+                }
+            }
             if (GM < 2) break;
         }
         {
@@ -1127,6 +1133,7 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     if (!valid) return;
     store_env(S, E);
     write_status(S, c, E);
+    if (S.obs_rec) { const int nr = c.room_num_x * c.room_num_y; S.obs_rec[(size_t)e * RG_OBS_REC_WORDS(nr) + nr] = POS(E.px, E.py); }  // (the rest of the record: gen_service)
     S.dc_len[e] = 0; S.dc_head[e] = 0; S.dc_part[e] = 0; S.dc_own[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
     if (S.nx_state) (void)__hip_atomic_fetch_and(&S.nx_state[e], RG_NX_DROP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (as step_wave's new level)
     S.steps[e] = 0;
@@ -1158,6 +1165,7 @@ __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
     if (!valid) return;
     store_env(S, E);
     write_status(S, c, E);
+    if (S.obs_rec) { const int nr = c.room_num_x * c.room_num_y; S.obs_rec[(size_t)e * RG_OBS_REC_WORDS(nr) + nr] = POS(E.px, E.py); }  // (the rest of the record: gen_service)
     if (S.nx_state) (void)__hip_atomic_fetch_and(&S.nx_state[e], RG_NX_DROP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (as step_wave's new level)
     S.flags[e] = (S.flags[e] & (RG_FLAG_TERMINAL | RG_FLAG_DEAD)) | RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY | E.err;
     if (E.err) atomicOr(S.err_any, E.err);
@@ -1277,10 +1285,18 @@ __global__ void __launch_bounds__(WAVE) k_regen_huge(RgState SP, RgConfig c, int
 // and streamed to the env's DistCache slot with 16-byte stores.
 // Up to G = 64 / pow2ceil(H) requests are served at once: the wave is split into G groups of rows
 // (mini: 4 groups of 16 lanes), and the neighbour rows come from DPP whole-wave shifts (1 VALU op each).
+#ifndef RG_BFS_NO_ROW16
+#define RG_BFS_NO_ROW16 0  // (A/B aid: 1 = whole-wave shifts also for H <= 16)
+#endif
 template <int WW> struct RowBits { uint64_t w[WW]; };
 
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }  // lane i <- lane i-1
 __device__ __forceinline__ uint32_t wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }  // lane i <- lane i+1
+
+// ... the same inside a DPP row of 16 lanes, zeros shifted in at the row's ends (bound_ctrl): with H <= 16 a BFS group IS a DPP row, and the first / last grid
+// row's "no neighbour" comes for free -- no select behind the move, and the move folds into the instruction that consumes it
+__device__ __forceinline__ uint32_t row_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }  // lane i <- lane i-1 of its row, lane 0 <- 0
+__device__ __forceinline__ uint32_t row_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }  // lane i <- lane i+1 of its row, lane 15 <- 0
 
 template <int WW> __device__ __forceinline__ RowBits<WW> rb_shl1(const RowBits<WW> &a) {  // cell x-1 -> x
     RowBits<WW> r;
@@ -1448,6 +1464,8 @@ __device__ __forceinline__ void bfs_rows(const RgState &S, const RgConfig &c, ui
 // planes are updated with compile-time knowledge of the level's low bits and the eight high planes once per block with the OR of the
 // block's new cells (distances < 2048 = every cell of a 32 x 64 grid).  At the end each lane expands its row to 32 u16 and stores its
 // 64 bytes straight into the env's DistCache slot -- no LDS staging.
+// ROW16: H <= 16, a group of rows is one DPP row (row_shr1 / row_shl1 above); else whole-wave shifts and a select per level.
+template <bool ROW16>
 __device__ __forceinline__ void bfs_rows_w32(const RgState &S, const RgConfig &c, bool active, int env, int tx, int ty, int slot, int row) {
     const int W = 32, H = c.height, HW = W * H;
     const uint16_t *cell = S.cell + (size_t)env * HW;
@@ -1469,7 +1487,7 @@ __device__ __forceinline__ void bfs_rows_w32(const RgState &S, const RgConfig &c
         }
     }
     const bool up_ok = row > 0, dn_ok = row + 1 < H;
-    const uint32_t wu = up_ok ? wave_shr1(wk) : 0u, wd = dn_ok ? wave_shl1(wk) : 0u;
+    const uint32_t wu = ROW16 ? row_shr1(wk) : (up_ok ? wave_shr1(wk) : 0u), wd = ROW16 ? row_shl1(wk) : (dn_ok ? wave_shl1(wk) : 0u);  // (rows >= H hold no walkable cell)
     uint32_t vis = 0, fr = 0;
     uint32_t inject = (row_ok && row == ty) ? 1u << tx : 0u;  // level 0: the target cell itself, walkable or not
     uint32_t p0 = 0, p1 = 0, p2 = 0, ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1478,8 +1496,9 @@ __device__ __forceinline__ void bfs_rows_w32(const RgState &S, const RgConfig &c
         uint32_t acc = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            uint32_t fu = wave_shr1(fr), fd = wave_shl1(fr);
-            fu = up_ok ? fu : 0u; fd = dn_ok ? fd : 0u;
+            uint32_t fu, fd;
+            if (ROW16) { fu = row_shr1(fr); fd = row_shl1(fr); }
+            else { fu = wave_shr1(fr); fd = wave_shl1(fr); fu = up_ok ? fu : 0u; fd = dn_ok ? fd : 0u; }
             const uint32_t au = fu & wk, ad = fd & wk;
             // Left/Right | Down/Up | diagonals: source (x-+1, y-+1) needs walk(x, y-+1) and walk(x-+1, y)
             const uint32_t tgt = (fr << 1) | (fr >> 1) | fu | fd | (((au << 1) | (au >> 1)) & wu) | (((ad << 1) | (ad >> 1)) & wd);
@@ -1732,7 +1751,7 @@ __device__ __forceinline__ bool bfs_service(const RgState &S, const RgConfig &c,
         const int s = active ? src : 0;
         int env_s = __shfl(e, s), tx = __shfl(px, s), ty = __shfl(py, s), sl = __shfl(map_slot, s);
         // width class BW: 0: W = 32 | 1, 2: W <= 64 / 96 and H * W <= 4096 (rows of 2 / 3 32-bit words) | 3, 4: wider or larger (2 / 3 64-bit words)
-        if constexpr (BW == 0) bfs_rows_w32(S, c, active, env_s, tx, ty, sl, row);
+        if constexpr (BW == 0) { if (rows_pow2 == 16 && !RG_BFS_NO_ROW16) bfs_rows_w32<true>(S, c, active, env_s, tx, ty, sl, row); else bfs_rows_w32<false>(S, c, active, env_s, tx, ty, sl, row); }
         else if constexpr (BW == 1 || BW == 2) {
             const bool comp = bfs_rows_n32<BW + 1>(S, c, active, env_s, tx, ty, sl, row, grp_lanes, mcbase + s, (own_req >> s) & 1ull);
             const uint64_t cb = __ballot(comp);  // (uniform inside a group)
@@ -2174,6 +2193,8 @@ __device__ __forceinline__ bool dist_cache_lookup(const RgState &S, const Env &E
 
 // EnemyHandler::move_actives moves + actions::move_active_enemies attacks
 // (enemies.rs:366-424, rogue/mod.rs:339-397, actions.rs:82-119, fight.rs:41-72)
+// EnemyHandler::move_actives moves + actions::move_active_enemies attacks
+// (enemies.rs:366-424, rogue/mod.rs:339-397, actions.rs:82-119, fight.rs:41-72)
 __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &c, Env &E, int map_slot, uint32_t &react) {
     const int nrooms = c.room_num_x * c.room_num_y, W = c.width, e = E.e;
     const uint16_t *dist = S.dc_map + ((size_t)e * RG_DIST_SLOTS + (map_slot < 0 ? 0 : map_slot)) * S.hw;
@@ -2358,6 +2379,7 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
 #pragma unroll
         for (int k = 0; k < 12; k++) S.rng[k * n + e] = r[k];
         S.p_pos[e] = pp; S.p_hp[e] = hp; S.p_hpmax[e] = hpm; S.p_lvl[e] = lv;
+        if (S.obs_rec) S.obs_rec[(size_t)e * RG_OBS_REC_WORDS(nrooms) + nrooms] = pp;
         S.p_exp[e] = ex; S.food[e] = fd; S.quiet[e] = qu; S.pack_gold[e] = pg; S.dlevel[e] = dl; S.mon_cnt[e] = mc;
         for (int s0 = 0; s0 < nrooms; s0 += 4) {  // tables, four slots per round
             uint32_t rr[4], mw[4], me[4], gp[4], ga[4]; int32_t mh[4]; uint8_t rm[4];
@@ -2371,6 +2393,10 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
                 if (s0 + k < nrooms) {
                     const size_t g = (size_t)(s0 + k) * n + e;
                     S.room_rect[g] = rr[k]; S.room_meta[g] = rm[k]; S.mon_w0[g] = mw[k]; S.mon_hp[g] = mh[k]; S.mon_exp[g] = me[k]; S.gold_pos[g] = gp[k]; S.gold_amt[g] = ga[k];
+                    if (S.obs_rec) {  // the env's observation record follows its tables (rg_state.h obs_rec)
+                        uint32_t *rec = S.obs_rec + (size_t)e * RG_OBS_REC_WORDS(nrooms);
+                        rec[s0 + k] = mw[k]; rec[nrooms + 1 + s0 + k] = rr[k]; reinterpret_cast<uint8_t *>(&rec[2 * nrooms + 1])[s0 + k] = rm[k];
+                    }
                 }
         }
     }
@@ -2649,6 +2675,21 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         S.steps[e] = steps;
         S.flags[e] = flags;
         S.done[e] = terminal ? 1 : 0;
+        // The env's observation record (rg_state.h obs_rec; rg_obs.hip ObsTabs): the fused observation pass overlays a Redraw from these words -- one line
+        // per env instead of the env's column of the [slot][env] tables.  Here: the monsters as they stand after their turn (the wave's LDS table) and the
+        // player; the room half is written with the level's tables (gen_service, take_spares -- which also writes a taken env's monsters and player).
+        if (S.obs_rec && (flags & RG_FLAG_REDRAW) && !taken) {
+            uint32_t *rec = S.obs_rec + (size_t)e * RG_OBS_REC_WORDS(nrooms_k);
+            for (int s0 = 0; s0 < nrooms_k; s0 += 4) {
+                uint32_t m4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) m4[k] = E.mc[(s0 + k < nrooms_k ? s0 + k : s0) * WAVE];
+                if (s0 + 4 <= nrooms_k) *reinterpret_cast<uint4 *>(rec + s0) = make_uint4(m4[0], m4[1], m4[2], m4[3]);
+                else
+                    for (int k = 0; k < 4 && s0 + k < nrooms_k; k++) rec[s0 + k] = m4[k];
+            }
+            rec[nrooms_k] = POS(E.px, E.py);
+        }
         // reward = the gold delta of the status mirror (parallel.py:59-64).  The mirror's gold is E.gold wherever this key rewrote the status (a status
         // reaction, or the post-reset status), else what it was: known in registers -- reading it back from memory was a dependent round trip
         // (store -> load -> store, ~2 us) at the very end of every wave
@@ -2798,7 +2839,7 @@ int rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const u
     smem = (smem + 15) & ~(size_t)15;
     int mc_offset = (int)smem;
     smem += (size_t)c->room_num_x * c->room_num_y * WAVE * 4;  // LDS monster cache
-    smem += WIN_SLOTS * WAVE * 2;                              // ... and the lanes' 5x5 tile windows 
+    smem += WIN_SLOTS * WAVE * 2;                              // ... and the lanes' 5x5 tile windows
     const int epw = rgk_step_epw(S->n, (c->width <= 32 && gen_mode_of(c) == 0) ? 2 : 1);
     // parity >= 0: stair isolation with the list the last render / observation pass wrote into set `parity`
     const int nb = (S->n + epw - 1) / epw;

@@ -181,11 +181,13 @@ __device__ __forceinline__ void store_obs(float4 *p, float4 v) {
     f4v nv = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(nv, reinterpret_cast<f4v *>(p));
 }
-struct ObsTabs {  // per-env entity/room tables staged in LDS: every global load of an env is issued up front, in one round trip
-    uint32_t rect[RG_OBS_MAX_ROOMS], mon[RG_OBS_MAX_ROOMS], gold[RG_OBS_MAX_ROOMS];
-    uint8_t meta[RG_OBS_MAX_ROOMS];
-    uint32_t ppos, pad[3];
-};
+// Per-env overlay inputs staged in LDS, in the layout of the env's OBSERVATION RECORD (RgState::obs_rec, RG_OBS_REC_WORDS): words [0, nr) the monster
+// words, [nr] the player's position, [nr + 1, 2 nr + 1) the room rects, then the room metas one byte each.  The record is what an ordinary Redraw reads --
+// one 64-byte line per env, written by whoever writes the env's tables (k_step: monsters and player after every turn that redraws; the generator and the
+// spare hand-off: the rooms) -- instead of the env's column of four
+// [slot][env] tables: 16 lines of 64 bytes for 52 useful ones, 0.43 x 65 536 times per step (28 MB of the pass's 228; measured: 44.7 -> 40.3 us).
+// The gold overlay needs no table at all: the tile word carries Floor::items' membership bit (C_GOLD).
+struct ObsTabs { uint32_t w[RG_OBS_REC_WORDS(RG_OBS_MAX_ROOMS)]; };
 #define OBS_ENV_BYTES(hw) ((((size_t)(hw) + sizeof(ObsTabs)) + 15) & ~(size_t)15)
 
 // LDS-only workgroup barrier: unlike __syncthreads() it does not drain vmcnt, so the prefetched global loads of the next env stay in flight
@@ -223,20 +225,21 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
     // Persistent blocks, software-pipelined two envs deep: the flag word of the env after next and -- now that its flag word is known -- the
     // inputs of the next env (tile quad + entity tables if it redraws, its screen mirror if not) are requested before the current env is
     // encoded, so an env costs no exposed round trip and nothing is fetched that is not used.
-    struct Pre { uint4 v0; uint32_t rect, mon, gold, meta, ppos; };
+    struct Pre { uint4 v0; uint32_t rec; };  // (`rec`: the lane's word of the env's observation record)
+    const int rec_words = RG_OBS_REC_WORDS(nrooms);
+    const uint32_t *rec_all = S.obs_rec;  // (rgk_obs: rec_words <= tpe, one word per thread)
     const int stride = gridDim.x * epb;
     auto load_flag = [&](int base) -> uint32_t {
         const int e = base + le;
         return (le < epb && e < n) ? S.flags[e] : 0u;
     };
     auto prefetch = [&](int base, uint32_t fl) {
-        Pre p; p.v0 = make_uint4(0, 0, 0, 0); p.rect = p.mon = p.gold = p.meta = p.ppos = 0;
+        Pre p; p.v0 = make_uint4(0, 0, 0, 0); p.rec = 0;
         const int e = base + le;
         if (le < epb && e < n) {
             if (fl & RG_FLAG_REDRAW) {
                 if (lt < Q8) p.v0 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW)[lt];
-                if (lt < nrooms) { p.rect = S.room_rect[lt * n + e]; p.meta = S.room_meta[lt * n + e]; p.mon = S.mon_w0[lt * n + e]; p.gold = S.gold_pos[lt * n + e]; }
-                if (lt == tpe - 1) p.ppos = S.p_pos[e];
+                if (lt < rec_words) p.rec = rec_all[(size_t)e * rec_words + lt];
             } else if (lt < Q8) {
                 const uint2 m = reinterpret_cast<const uint2 *>(S.screen + (size_t)e * HW)[lt];
                 p.v0.x = m.x; p.v0.y = m.y;
@@ -258,12 +261,11 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
         const bool redraw = valid && (fl & RG_FLAG_REDRAW);
         const uint4 *cell4 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW);
         const uint4 v0 = cur.v0;
-        const uint32_t t_rect = cur.rect, t_mon = cur.mon, t_gold = cur.gold, t_meta = cur.meta, t_ppos = cur.ppos;
+        const uint32_t t_rec = cur.rec;
         lds_barrier();  // LUTs ready / previous iteration's LDS reads done
         if (valid) {
             if (redraw) {
-                if (lt < nrooms) { tb->rect[lt] = t_rect; tb->meta[lt] = (uint8_t)t_meta; tb->mon[lt] = t_mon; tb->gold[lt] = t_gold; }
-                if (lt == tpe - 1) tb->ppos = t_ppos;
+                if (lt < rec_words) tb->w[lt] = t_rec;
                 // the history plane is rewritten only when the visited set changed since it was last written (k_step: HIST_DIRTY), never on a
                 // stale Redraw
                 const bool upd_hist = !(fl & RG_FLAG_HIST_STALE) && (fl & RG_FLAG_HIST_DIRTY);
@@ -279,7 +281,8 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                         bool inner = idx >= W && idx < HW - W;  // rows 1..H-2 only (rogue/mod.rs:278-290)
                         uint32_t gl = ' ';
                         if (inner && (cw & C_VISIBLE)) gl = glyph_of(cw);
-                        if (inner && (cw & (C_VISIBLE | C_DRAWN))) gl |= 0x80u;  // bit 7: an object on this cell is drawn (draw_ranges)
+                        if (inner && (cw & (C_VISIBLE | C_DRAWN))) gl = ((cw & C_GOLD) ? (uint32_t)'*' : gl) | 0x80u;  // bit 7: an object on this cell is drawn (draw_ranges);
+                                                                                                                  // gold is drawn over a monster, under the player
                         g[t >> 2] |= gl << ((t & 3) * 8);
                         hb[t >> 2] |= ((cw & C_VISITED) ? 1u : 0u) << ((t & 3) * 8);
                     }
@@ -292,11 +295,12 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
             }
         }
         lds_barrier();
-        // ---- phase B: entity overlays from LDS only; draw priority monster < gold < player (core/src/lib.rs:271-283) ----
-        const uint32_t ppos = (valid && redraw) ? tb->ppos : 0;
+        // ---- phase B: entity overlays from LDS only; draw priority monster < gold < player (core/src/lib.rs:271-283): a monster never replaces the
+        //      '*' the decode put there (no other glyph is '*'), the player replaces anything ----
+        const uint32_t ppos = (valid && redraw) ? tb->w[nrooms] : 0;
         const int px = POS_X(ppos), py = POS_Y(ppos);
         if (valid && redraw && lt < nrooms) {
-            uint32_t w = tb->mon[lt];
+            uint32_t w = tb->w[lt];
             if ((w >> 24) & MF_ALIVE) {
                 int x = POS_X(w), y = POS_Y(w);
                 int dx = px - x, dy = py - y;
@@ -304,28 +308,21 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                 if (!show) {  // Floor::in_same_room (floor.rs:381-393)
                     int id = room_id_of(c, px, py);
                     if (id >= 0 && room_id_of(c, x, y) == id) {
-                        if ((tb->meta[id] & RM_KIND_MASK) == RK_EMPTY) show = true;
+                        if ((reinterpret_cast<const uint8_t *>(&tb->w[2 * nrooms + 1])[id] & RM_KIND_MASK) == RK_EMPTY) show = true;
                         else {
                             int x0, y0, x1, y1;
-                            unpack_rect(tb->rect[id], x0, y0, x1, y1);
+                            unpack_rect(tb->w[nrooms + 1 + id], x0, y0, x1, y1);
                             bool ina = px >= x0 && px < x1 && py >= y0 && py < y1, inb = x >= x0 && x < x1 && y >= y0 && y < y1;
                             show = ina == inb;
                         }
                     }
                 }
-                if (show && (scr[y * W + x] & 0x80u)) scr[y * W + x] = (uint8_t)(0x80u | mtile[(w >> 16) & 0xff]);
+                const uint32_t under = scr[y * W + x];
+                if (show && (under & 0x80u) && under != (0x80u | '*')) scr[y * W + x] = (uint8_t)(0x80u | mtile[(w >> 16) & 0xff]);
             }
         }
         lds_barrier();
-        if (valid && redraw) {
-            if (lt < nrooms) {
-                uint32_t g = tb->gold[lt];
-                if ((g & 0x10000u) && (g & 0xffff) != ppos) {  // the player's own cell is drawn by the player lane
-                    int x = POS_X(g), y = POS_Y(g);
-                    if (scr[y * W + x] & 0x80u) scr[y * W + x] = (uint8_t)(0x80u | '*');
-                }
-            } else if (lt == nrooms && (scr[py * W + px] & 0x80u)) scr[py * W + px] = (uint8_t)(0x80u | '@');
-        }
+        if (valid && redraw && lt == 0 && (scr[py * W + px] & 0x80u)) scr[py * W + px] = (uint8_t)(0x80u | '@');
         lds_barrier();
         if (with_hist) __syncthreads();  // the history plane is re-read from global memory below (written in phase A by other lanes)
         // ---- phase C: mirror write-back + encode.  One float4 (4 cells) per lane per plane, lanes contiguous: every wave-level store
@@ -466,10 +463,11 @@ void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st) {
 int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, int planes_sym, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     int hw = c->width * c->height;
     if (hw & 7) return 0;
-    if (c->room_num_x * c->room_num_y > RG_OBS_MAX_ROOMS) return 0;  // the fused kernel's LDS overlay tables hold 64 rooms (one thread per room + the player): unfused path
+    if (c->room_num_x * c->room_num_y > RG_OBS_MAX_ROOMS || !S->obs_rec) return 0;  // the fused kernel's LDS overlay tables hold 64 rooms (one thread per room + the player): unfused path
     int q8 = hw / 8;
     int tpe = q8 >= OBS_THREADS ? OBS_THREADS : ((q8 + 63) / 64) * 64;  // threads per env: a whole number of waves
     if (tpe > OBS_THREADS) tpe = OBS_THREADS;
+    if (RG_OBS_REC_WORDS(c->room_num_x * c->room_num_y) > tpe) return 0;  // the env's observation record is fetched one word per thread (a <= 512-cell grid with more than 28 rooms: unfused path)
     const int bthreads = tpe, epb = 1;  // one env per block: no cross-env barrier coupling (4 envs per 256-thread block measured 10-20 % slower)
     size_t smem = 512 + 128 + 64 + (size_t)epb * OBS_ENV_BYTES(hw);
     int blocks = (S->n + epb - 1) / epb;

@@ -124,6 +124,10 @@ struct RgState {
     int32_t sp_slots;
     // status mirror
     int32_t *status;    // [n][10]
+    // observation records [n][RG_OBS_REC_WORDS(rooms)] (rg_obs.hip ObsTabs): what the fused observation pass overlays on an ordinary Redraw, one line per env.
+    // Follows the env's tables: k_step writes the monster words and the player's position of every env whose key produced a Redraw, the generator's
+    // copy-out (gen_service) and the spare hand-off (take_spares) the rooms and the new level's monsters.  NULL: more rooms than the fused pass handles
+    uint32_t *obs_rec;
     // action-history log (RunTime::saved_inputs, core/src/lib.rs:288): the keys of the current and of the previous episode, NULL = off
     uint8_t *klog;      // [n][2][klog_cap]
     uint32_t *klog_len; // [2][n] keys accepted in episode buffer 0 / 1 (may exceed klog_cap: the tail is then not stored)

@@ -226,7 +226,7 @@ def test_urgent_spares_of_envs_that_die_fast(goldens):
                 assert np.array_equal(x, y), (t, what, [i for i in range(n) if not np.array_equal(x[i], y[i])][:8])
     cnt = (ctypes.c_uint64 * 8)()
     a.check(a.L.rg_counters(a.h, cnt, 0))
-    assert cnt[0] > 200000 and cnt[4] > 0.8 * cnt[0], list(cnt)   # resets; most of them took a spare (1024-env waves x one urgent build per wave and step keep up)
+    assert cnt[0] > 200000 and cnt[4] > 0.5 * cnt[0], list(cnt)   # resets; the bulk launch (4 x 4096 spares per 32 steps) + one urgent build per wave and step serve most of them, the rest generate inline
     a.close()
     b.close()
 
