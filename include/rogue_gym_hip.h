@@ -130,6 +130,10 @@ int rg_status_vec(rg_t *h, uint32_t status_flag, int32_t *out_host);
  * synchronous D2H of the mirrors; any pointer may be NULL.  screen / hist: u8 [n_env][H][W]; for a batch that mixes sizes the envs follow
  * each other in env order, env i taking H_i * W_i bytes (rg_env_dims). */
 int rg_fetch_states(rg_t *h, uint8_t *screen, uint8_t *hist, int32_t *status, uint32_t *flags);
+/* ParallelGameState::step (python/src/lib.rs:315-321) in one call and ONE stream wait, for small batches: keys from host memory (zipped with the envs like
+ * rg_step_prefix), then the mirror refresh, then one kernel writes status i32 [n][10], flags u32 [n] -- and, if given, screen / hist u8 [n][H*W] -- straight to
+ * their destinations, which must be device-visible (pinned host memory from rg_host_alloc, or device memory).  Errors as rg_sync.  Not for config groups. */
+int rg_step_fetch(rg_t *h, const uint8_t *keys_host, int n_keys, uint8_t *screen, uint8_t *hist, int32_t *status, uint32_t *flags);
 
 /* Device-side snapshots of the two big mirrors, for value-object callers that read mostly status / flags (parallel.py:59-64 uses gold and
  * is_terminal of every state, nothing else): rg_snapshot_take flushes the pending render and copies screen + hist device-to-device into

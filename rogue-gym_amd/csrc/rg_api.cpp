@@ -33,6 +33,7 @@ int rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const u
 void rgk_probe_clock(unsigned long long *out, int spin, hipStream_t st);
 void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, int spares, const uint32_t *mark, uint32_t target, uint32_t *err_any, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 void rgk_regen_gate(const uint32_t *mark, uint32_t target, uint32_t *err_any, hipStream_t st);
+void rgk_export(const RgState *S, uint32_t *err_any, void *o_screen, void *o_hist, void *o_status, void *o_flags, uint32_t *o_err, hipStream_t st);
 int rgk_regen_lanes_supported(const RgConfig *c, int maze_cap);
 int rgk_regen_lanes(const RgState *SP, const RgConfig *c, uint32_t *q, int32_t *list, int bulk, int waves, int slots, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st);
@@ -57,6 +58,8 @@ struct rg_handle {
     hipStream_t side2 = nullptr; // stream of the level-per-lane spare producer (LOW priority; its launches are long and far apart, the next-level structures' short and with every step)
     int lane_flip = 0;           // which of the two carries the next launch (each with its own claim list)
     uint64_t lane_last = 0;      // step_count of its last launch
+    uint8_t *pin_keys = nullptr;   // rg_step_fetch: the keys of the call in pinned, device-visible host memory (k_step reads them across PCIe: no copy call)
+    uint32_t *pin_err = nullptr;   // ... and where k_export leaves the error word
     bool lane_regen = false;     // the consumed spares are rebuilt one level per LANE (rg_regen_lanes.hip) instead of one per wave (k_regen); ROGUE_GYM_HIP_WAVE_REGEN=1 keeps the latter
     uint64_t step_count = 0;
     hipStream_t side = nullptr;  // stream of the background generator (LOW priority: the step kernel's blocks are placed first, k_regen takes what is left; rg_step_prefix)
@@ -455,6 +458,8 @@ static void destroy_handle(rg_handle *h) {
     if (h->side3) { (void)hipStreamSynchronize(h->side3); (void)hipStreamDestroy(h->side3); }
     for (int k = 0; k < RG_TIMED_KERNELS; k++) for (auto &e : h->ev[k]) (void)hipEventDestroy(e);
     if (h->obs_scratch) (void)hipFree(h->obs_scratch);
+    if (h->pin_keys) (void)hipHostFree(h->pin_keys);
+    if (h->pin_err) (void)hipHostFree(h->pin_err);
     free_all(h);
     delete h;
 }
@@ -724,6 +729,42 @@ int rg_fetch_states(rg_t *h, uint8_t *screen, uint8_t *hist, int32_t *status, ui
     if (status) HIPCHK(h, hipMemcpyAsync(status, h->S.status, n * 40, hipMemcpyDeviceToHost, h->stream));
     if (flags) HIPCHK(h, hipMemcpyAsync(flags, h->S.flags, n * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ParallelGameState::step (python/src/lib.rs:315-321) for a SMALL batch, where a step is launch and copy overhead and nothing else: rg_step_prefix +
+// rg_sync + rg_fetch_states were a key upload, four device-to-host copies, an error-word copy and five stream waits -- ~145 us per step whatever the batch
+// (profiles/r04_value_api.txt: 64 envs 0.44 M env-steps/s, below the CPU port's 0.60 M).  Here: the keys are read by k_step from pinned host memory, the
+// mirror refresh follows, ONE kernel (k_export) writes status, flags, the error word -- and the screens, to `screen` / `hist` if given -- straight to their
+// destinations, and the call waits for the handle's stream once.  The background generator's streams are not waited for (rg_sync / rg_destroy do).
+// status / flags (and screen / hist, each n_env * H * W bytes, or NULL for neither) must be device-visible: pinned host memory from rg_host_alloc, or
+// device memory (a snapshot).  Not for handles with config groups.  Errors are reported as by rg_sync.
+int rg_step_fetch(rg_t *h, const uint8_t *keys_host, int n_keys, uint8_t *screen, uint8_t *hist, int32_t *status, uint32_t *flags) {
+    if (refuse_mixed(h, "rg_step_fetch")) return 1;
+    if (!h->sub.empty()) { h->err = "rg_step_fetch: not for a handle with config groups (rg_step_prefix + rg_fetch_states)"; return 1; }
+    if (!status || !flags || (screen == nullptr) != (hist == nullptr)) { h->err = "rg_step_fetch: status and flags are required, screen and hist come together"; return 1; }
+    if (h->S.hw & 3) { h->err = "rg_step_fetch needs H*W divisible by 4"; return 1; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n_keys < 0) { h->err = "rg_step_fetch: negative key count"; return 1; }
+    if (n_keys > h->S.n) n_keys = h->S.n;
+    if (!h->pin_keys) {
+        HIPCHK(h, hipHostMalloc((void **)&h->pin_keys, (size_t)h->S.n + 16, hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc((void **)&h->pin_err, 16, hipHostMallocDefault));
+    }
+    memcpy(h->pin_keys, keys_host, (size_t)n_keys);
+    if (rg_step_prefix(h, h->pin_keys, n_keys, 1)) return 1;  // ("on device": device-visible)
+    if (flush_render(h)) return 1;
+    rgk_export(&h->S, h->d_err, screen, hist, status, flags, h->pin_err, h->stream);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint32_t err = h->pin_err[0];
+    if (err) {
+        if (err & RG_FLAG_ERR_INTERNAL) h->err = "internal capacity guard of the HIP stepper tripped (please report the config)";
+        else if (err & RG_FLAG_ERR_KEY) h->err = "Invalid input (key is not in the ai keymap)";
+        else if (err & RG_FLAG_ERR_DEAD) h->err = "Ignored input (action while the player is dead)";
+        else h->err = "Invalid tile in symbol image (symbol >= symbols - 1)";
+        return 1;
+    }
     return 0;
 }
 

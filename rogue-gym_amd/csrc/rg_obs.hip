@@ -399,6 +399,26 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ screen
     }
 }
 
+// rg_step_fetch: everything ParallelGameState::step hands back, written by ONE launch to wherever the caller wants it -- pinned host memory (the kernel's
+// stores cross PCIe themselves: no copy engine, no staging) or a device snapshot for the screens.  4-byte words, grid-stride: [screen][hist][status][flags],
+// and the error word (read and cleared: what rg_sync does with a 4-byte copy and a memset).
+__global__ void __launch_bounds__(256) k_export(const uint32_t *__restrict__ screen, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ status,
+                                                const uint32_t *__restrict__ flags, uint32_t *__restrict__ err_any, size_t w_scr, size_t w_status, size_t w_flags,
+                                                uint32_t *__restrict__ o_screen, uint32_t *__restrict__ o_hist, uint32_t *__restrict__ o_status,
+                                                uint32_t *__restrict__ o_flags, uint32_t *__restrict__ o_err) {
+    const size_t total = (o_screen ? 2 * w_scr : 0) + w_status + w_flags;
+    const size_t base = o_screen ? 2 * w_scr : 0;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        if (g < base) { if (g < w_scr) o_screen[g] = screen[g]; else o_hist[g - w_scr] = hist[g - w_scr]; }
+        else if (g < base + w_status) o_status[g - base] = status[g - base];
+        else o_flags[g - base - w_status] = flags[g - base - w_status];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t e = *err_any;
+        *o_err = e;
+        if (e) *err_any = 0;
+    }
+}
 __global__ void __launch_bounds__(256) k_scatter_rows(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int32_t *__restrict__ ext, int n, int row_bytes) {
     if ((row_bytes & 3) == 0) {
         const int rw = row_bytes >> 2;
@@ -503,6 +523,14 @@ void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *statu
         int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
         hipLaunchKernelGGL(k_encode_scalar, dim3(blocks), dim3(256), 0, st, screen, hist, status, flags, err_any, n, hw, rs, rst, symbols, planes_sym, sflag, with_hist, kind, out, ext);
     }
+}
+void rgk_export(const RgState *S, uint32_t *err_any, void *o_screen, void *o_hist, void *o_status, void *o_flags, uint32_t *o_err, hipStream_t st) {
+    const size_t n = (size_t)S->n, w_scr = n * (size_t)S->hw / 4, w_status = n * 10, w_flags = n;
+    const size_t total = (o_screen ? 2 * w_scr : 0) + w_status + w_flags;
+    int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_export, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, reinterpret_cast<const uint32_t *>(S->screen), reinterpret_cast<const uint32_t *>(S->hist),
+                       reinterpret_cast<const uint32_t *>(S->status), S->flags, err_any, w_scr, w_status, w_flags, static_cast<uint32_t *>(o_screen), static_cast<uint32_t *>(o_hist),
+                       static_cast<uint32_t *>(o_status), static_cast<uint32_t *>(o_flags), o_err);
 }
 // compact record of every env: {screen u8[hw], status i32[10], reward f32, flags u32, hist u8[hw] (optional)}, back to back -- the payload of the ONE
 // all-gather per step of the multi-GPU path; expanded on the consumer by rgk_encode with rs = record size

@@ -41,7 +41,7 @@ class RgDebugState(C.Structure):
 _lib = None
 
 _INT_FUNCS = (
-    "rg_create", "rg_dims", "rg_env_dims", "rg_env_symbols", "rg_set_stream", "rg_seed", "rg_reset", "rg_step", "rg_step_prefix", "rg_step_obs_gray", "rg_sync", "rg_screen", "rg_hist", "rg_status", "rg_flags",
+    "rg_create", "rg_dims", "rg_env_dims", "rg_env_symbols", "rg_set_stream", "rg_seed", "rg_reset", "rg_step", "rg_step_prefix", "rg_step_obs_gray", "rg_step_fetch", "rg_sync", "rg_screen", "rg_hist", "rg_status", "rg_flags",
     "rg_reward", "rg_done", "rg_set_stair_reward", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_encode_host_batch", "rg_obs_host",
     "rg_host_alloc", "rg_dev_alloc", "rg_snapshot_take", "rg_dev_read", "rg_dev_read_rows", "rg_compact_record_bytes", "rg_pack_compact", "rg_expand_compact", "rg_comm_unique_id", "rg_comm_init", "rg_comm_destroy", "rg_comm_count", "rg_allgather_compact", "rg_status_vec", "rg_history_enable", "rg_history_keys",
     "rg_dump_history", "rg_counters", "rg_counters_ex", "rg_probe_sclk", "rg_dump_config", "rg_config_canonical", "rg_config_resolved", "rg_config_schema", "rg_debug_fetch", "rg_debug_descend", "rg_timing_enable", "rg_timing_read", "rg_timing_read_all",
@@ -79,6 +79,7 @@ def load_library():
         "rg_step": [vp, vp, i32],
         "rg_step_prefix": [vp, vp, i32, i32],
         "rg_step_obs_gray": [vp, vp, i32, u32, i32, vp],
+        "rg_step_fetch": [vp, vp, i32, vp, vp, vp, vp],
         "rg_sync": [vp],
         "rg_screen": [vp, C.POINTER(vp)], "rg_hist": [vp, C.POINTER(vp)], "rg_status": [vp, C.POINTER(vp)], "rg_flags": [vp, C.POINTER(vp)],
         "rg_reward": [vp, C.POINTER(vp)], "rg_done": [vp, C.POINTER(vp)], "rg_set_stair_reward": [vp, C.c_float],
@@ -251,6 +252,7 @@ class _Handle:
         self.dev_pool = _DevPool(L, self.device)
         self.lazy = {}  # id -> weakref of the StateBatches whose screens still live only in their device snapshot (materialised before the handle goes)
         self.epoch = 0  # bumped by every call that changes the device-side states (a StateBatch remembers the epoch it was taken at)
+        self.fast_step = True  # rg_step_fetch applies (cleared by the first refusal: a handle with config groups)
 
     def check(self, rc):
         if rc:
@@ -287,6 +289,12 @@ class _Handle:
         """The current states of all envs as one StateBatch (one D2H copy into pinned memory)."""
         return StateBatch(self)
 
+    def step_keys_host(self, keys):
+        """rg_step_prefix + rg_sync: the general form of a value-object step (config groups, mixed sizes); StateBatch(keys=...) uses rg_step_fetch where it applies."""
+        self.check(self.L.rg_step_prefix(self.h, keys.ctypes.data, int(keys.shape[0]), 0))
+        self.epoch += 1
+        self.check(self.L.rg_sync(self.h))
+
     def states(self):
         return self.snapshot()
 
@@ -312,6 +320,7 @@ class _Handle:
         return buf.value.decode()
 
 
+_EAGER_MAX_BYTES = 1 << 16  # rg_step_fetch: batches of at most this many screen bytes get their screens written to pinned memory by the step itself
 _LAZY_MIN_BYTES = 1 << 20   # batches with at least this many screen bytes keep their screens on the device until they are looked at
 _LAZY_MAX_BYTES = 1 << 30   # device bytes all not-yet-read snapshots of a handle may pin together (65 536 mini envs: 8 batches); older ones move to the host
 _IMAGE_BATCH_LIMIT = 1 << 28  # bytes: above this a batch does not cache whole-batch images (one-hot images of large batches are GBs)
@@ -322,7 +331,8 @@ class StateBatch:
     instead of n Python objects: a read-only sequence whose items are PlayerState views, plus vector accessors (gold, dungeon_level,
     is_terminal) and whole-batch images computed by one kernel launch."""
 
-    def __init__(self, handle):
+    def __init__(self, handle, keys=None):
+        """keys: step the batch with these keys first (ParallelGameState.step), through rg_step_fetch where it applies -- one call, one stream wait."""
         self._hd = handle
         n, h, w = handle.n, handle.height, handle.width
         self.n, self.symbols = n, handle.symbols
@@ -331,7 +341,35 @@ class StateBatch:
         self.flags = _leased(handle.pool, (n,), np.uint32)
         self.mixed_sizes = handle.mixed_sizes
         self._snap = None
-        if self.mixed_sizes:  # envs of different width / height (ParallelGameState::new takes any config per env): ragged buffers, `screen` / `hist` are lists of per-env views
+        if keys is not None and not (handle.fast_step and not self.mixed_sizes and (h * w) % 4 == 0):
+            handle.step_keys_host(keys)
+            keys = None
+        if keys is not None:
+            # the step and its results in ONE call (rg_step_fetch): k_step reads the keys from pinned memory, one kernel writes status / flags -- and the
+            # screens of a small batch -- straight into the pinned arrays below; a larger batch keeps its screens in a device snapshot, as without keys
+            L = handle.L
+            if n * h * w <= _EAGER_MAX_BYTES:
+                self._screen = _leased(handle.pool, (n, h, w), np.uint8)
+                self._hist = _leased(handle.pool, (n, h, w), np.uint8)
+                scr, hst = self._screen.ctypes.data, self._hist.ctypes.data
+            else:
+                self._screen = self._hist = None
+                self._snap = _DevLease(handle.dev_pool, 2 * n * h * w)
+                scr, hst = self._snap.ptr, self._snap.ptr + n * h * w
+            rc = L.rg_step_fetch(handle.h, keys.ctypes.data, int(keys.shape[0]), C.c_void_p(scr), C.c_void_p(hst), self.status.ctypes.data, self.flags.ctypes.data)
+            if rc and b"config groups" in L.rg_last_error(handle.h):  # (refused before anything was stepped: the general path from now on)
+                handle.fast_step = False
+                self._snap = None
+                handle.step_keys_host(keys)
+                keys = None
+            else:
+                handle.epoch += 1
+                handle.check(rc)
+                if self._snap is not None:
+                    self._register_lazy()
+        if keys is not None:
+            pass
+        elif self.mixed_sizes:  # envs of different width / height (ParallelGameState::new takes any config per env): ragged buffers, `screen` / `hist` are lists of per-env views
             off = np.concatenate(([0], np.cumsum(handle.env_heights.astype(np.int64) * handle.env_widths)))
             rs, rh = _leased(handle.pool, (int(off[-1]),), np.uint8), _leased(handle.pool, (int(off[-1]),), np.uint8)
             self._screen = [rs[off[i]:off[i + 1]].reshape(handle.env_heights[i], handle.env_widths[i]) for i in range(n)]
@@ -348,22 +386,26 @@ class StateBatch:
             self._snap = _DevLease(handle.dev_pool, 2 * n * h * w)
             handle.check(handle.L.rg_snapshot_take(handle.h, C.c_void_p(self._snap.ptr)))
             handle.check(handle.L.rg_fetch_states(handle.h, None, None, self.status.ctypes.data, self.flags.ctypes.data))  # (synchronises the stream)
-            key, lazy = id(self), handle.lazy
-            lazy[key] = weakref.ref(self, lambda _r, key=key, lazy=lazy: lazy.pop(key, None))
-            # Every lazy batch pins 2 * n * H * W bytes of HBM until it is collected or looked at: a caller that keeps the states of a whole rollout
-            # (128 steps of 65 536 mini envs = 17 GB) must not exhaust the device silently.  Beyond _LAZY_MAX_BYTES the OLDEST batches get their host
-            # copies now (what every batch cost before the lazy path existed) and hand their device buffer back.
-            live = [b for b in (r() for r in list(lazy.values())) if b is not None and b._snap is not None]
-            total = sum(b._snap.nbytes for b in live)
-            for b in live:
-                if total <= _LAZY_MAX_BYTES:
-                    break
-                if b is not self:
-                    total -= b._snap.nbytes
-                    b._materialise()
+            self._register_lazy()
         self._epoch = handle.epoch
         self._items = {}
         self._images = {}
+
+    def _register_lazy(self):
+        handle = self._hd
+        key, lazy = id(self), handle.lazy
+        lazy[key] = weakref.ref(self, lambda _r, key=key, lazy=lazy: lazy.pop(key, None))
+        # Every lazy batch pins 2 * n * H * W bytes of HBM until it is collected or looked at: a caller that keeps the states of a whole rollout
+        # (128 steps of 65 536 mini envs = 17 GB) must not exhaust the device silently.  Beyond _LAZY_MAX_BYTES the OLDEST batches get their host
+        # copies now (what every batch cost before the lazy path existed) and hand their device buffer back.
+        live = [b for b in (r() for r in list(lazy.values())) if b is not None and b._snap is not None]
+        total = sum(b._snap.nbytes for b in live)
+        for b in live:
+            if total <= _LAZY_MAX_BYTES:
+                break
+            if b is not self:
+                total -= b._snap.nbytes
+                b._materialise()
 
     def _materialise(self):
         """Host copies of the whole snapshot (one D2H of screen + history into pinned memory); the device buffer goes back to the pool."""
@@ -661,10 +703,7 @@ class ParallelGameState:
         """One key per env.  Like ThreadConductor::step the keys are zipped with the envs (thread_impls.rs:62-64): surplus keys are dropped,
         and with fewer keys than envs only that prefix is stepped (the reference would then wait forever for the others' replies)."""
         keys = _keys_array(input)
-        self._h.check(self._h.L.rg_step_prefix(self._h.h, keys.ctypes.data, int(keys.shape[0]), 0))
-        self._h.epoch += 1
-        self._h.check(self._h.L.rg_sync(self._h.h))
-        return self._h.snapshot()
+        return StateBatch(self._h, keys=keys)
 
     def reset(self):
         self._h.check(self._h.L.rg_reset(self._h.h))

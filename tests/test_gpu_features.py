@@ -935,3 +935,48 @@ def test_fused_step_and_observation_equals_the_two_calls(goldens, flag, with_his
 def inner_handle(cfgs, max_steps):
     from rogue_gym_python import _rogue_gym as inner
     return inner._Handle(cfgs, max_steps, auto_reset=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,device_screens", [(64, False), (1024, True)], ids=["64 envs, screens to pinned memory", "1024 envs, screens to a device snapshot"])
+def test_step_fetch_equals_step_sync_fetch(goldens, n, device_screens):
+    """rg_step_fetch (ParallelGameState::step for small batches in one call and one stream wait: keys read from pinned memory, one kernel writes status, flags and
+    the screens to their destinations) against rg_step_prefix + rg_sync + rg_fetch_states on a second handle: screen, history, status and flags of every env
+    after every step, incl. auto-resets (40-step episodes), a key prefix shorter than the batch, and the error of an unmapped key reported as by rg_sync."""
+    import torch
+    from rogue_gym_python import _rogue_gym as inner
+    cfgs = [json.dumps(dict(goldens["configs"]["mini"], seed=i % 500)) for i in range(n)]
+    a, b = inner_handle(cfgs, 40), inner_handle(cfgs, 40)
+    L = a.L
+    status = inner._leased(a.pool, (n, 10), np.int32)
+    flags = inner._leased(a.pool, (n,), np.uint32)
+    if device_screens:
+        snap = torch.empty((2, n, 16, 32), dtype=torch.uint8, device="cuda")
+        scr_ptr, hist_ptr = snap.data_ptr(), snap.data_ptr() + n * 512
+    else:
+        scr, hist = inner._leased(a.pool, (n, 16, 32), np.uint8), inner._leased(a.pool, (n, 16, 32), np.uint8)
+        scr_ptr, hist_ptr = scr.ctypes.data, hist.ctypes.data
+    rng = np.random.RandomState(5)
+    table = np.frombuffer(b"hjklyubnHJKL>s.", np.uint8)
+    for t in range(200):
+        m = n if t % 7 else n - 5   # (a prefix: the last five envs get no key that step)
+        keys = np.ascontiguousarray(table[rng.randint(0, len(table), m)])
+        a.check(L.rg_step_fetch(a.h, keys.ctypes.data, m, C.c_void_p(scr_ptr), C.c_void_p(hist_ptr), status.ctypes.data, flags.ctypes.data))
+        b.check(L.rg_step_prefix(b.h, keys.ctypes.data, m, 0))
+        b.check(L.rg_sync(b.h))
+        bs, bh, bst, bfl = b.fetch()
+        if device_screens:
+            torch.cuda.synchronize()
+            sa, ha = snap[0].cpu().numpy(), snap[1].cpu().numpy()
+        else:
+            sa, ha = scr, hist
+        for x, y, what in ((sa, bs, "screen"), (ha, bh, "hist"), (status, bst, "status"), (flags, bfl, "flags")):
+            assert np.array_equal(np.asarray(x).reshape(np.asarray(y).shape), y), (t, what)
+    bad = np.full(n, ord("h"), np.uint8)
+    bad[3] = ord("Q")   # not in KeyMap::ai
+    assert L.rg_step_fetch(a.h, bad.ctypes.data, n, None, None, status.ctypes.data, flags.ctypes.data) != 0
+    assert b"Invalid input" in L.rg_last_error(a.h)
+    good = np.full(n, ord("h"), np.uint8)
+    a.check(L.rg_step_fetch(a.h, good.ctypes.data, n, None, None, status.ctypes.data, flags.ctypes.data))  # (the error word was cleared)
+    a.close()
+    b.close()
