@@ -220,6 +220,19 @@ def _leased(pool, shape, dtype):
     return np.frombuffer(raw, dtype=dtype).reshape(shape)
 
 
+def _leased_many(pool, specs):
+    """Several arrays over ONE leased pinned buffer (a lease costs a few microseconds of Python; a small batch's step has four): 16-byte aligned sections."""
+    sizes = [(int(np.prod(sh)) * np.dtype(dt).itemsize + 15) & ~15 for sh, dt in specs]
+    lease = _Lease(pool, sum(sizes))
+    raw = (C.c_uint8 * sum(sizes)).from_address(lease.ptr)
+    raw._lease = lease
+    whole, out, off = np.frombuffer(raw, dtype=np.uint8), [], 0
+    for (sh, dt), sz in zip(specs, sizes):
+        out.append(whole[off:off + int(np.prod(sh)) * np.dtype(dt).itemsize].view(dt).reshape(sh))
+        off += sz
+    return out
+
+
 class _Handle:
     """Owns one rg_t."""
 
@@ -337,9 +350,13 @@ class StateBatch:
         n, h, w = handle.n, handle.height, handle.width
         self.n, self.symbols = n, handle.symbols
         # pinned, pooled buffers; each array owns its lease, so an array (or any slice of it) a caller keeps outlives this batch safely
-        self.status = _leased(handle.pool, (n, 10), np.int32)
-        self.flags = _leased(handle.pool, (n,), np.uint32)
         self.mixed_sizes = handle.mixed_sizes
+        eager = keys is not None and handle.fast_step and not self.mixed_sizes and (h * w) % 4 == 0 and n * h * w <= _EAGER_MAX_BYTES
+        if eager:  # (one lease for the four arrays of a small batch's step)
+            self.status, self.flags, self._screen, self._hist = _leased_many(handle.pool, [((n, 10), np.int32), ((n,), np.uint32), ((n, h, w), np.uint8), ((n, h, w), np.uint8)])
+        else:
+            self.status = _leased(handle.pool, (n, 10), np.int32)
+            self.flags = _leased(handle.pool, (n,), np.uint32)
         self._snap = None
         if keys is not None and not (handle.fast_step and not self.mixed_sizes and (h * w) % 4 == 0):
             handle.step_keys_host(keys)
@@ -348,9 +365,7 @@ class StateBatch:
             # the step and its results in ONE call (rg_step_fetch): k_step reads the keys from pinned memory, one kernel writes status / flags -- and the
             # screens of a small batch -- straight into the pinned arrays below; a larger batch keeps its screens in a device snapshot, as without keys
             L = handle.L
-            if n * h * w <= _EAGER_MAX_BYTES:
-                self._screen = _leased(handle.pool, (n, h, w), np.uint8)
-                self._hist = _leased(handle.pool, (n, h, w), np.uint8)
+            if eager:
                 scr, hst = self._screen.ctypes.data, self._hist.ctypes.data
             else:
                 self._screen = self._hist = None
