@@ -243,7 +243,7 @@ def main():
     ap.add_argument("--preroll-steps", type=int, default=1500, help="untimed steps of the MEASURED batch before the warm-up: reach the steady-state episode mix "
                     "the metric is defined on (the first --steps of them are timed and reported as preroll.cold_start); 0 = off.  1.5 x max_steps: "
                     "not on a multiple of max_steps, where the survivors of the synchronised first episodes all reset at once")
-    ap.add_argument("--time-every", type=int, default=7, help="time every N-th launch of each kernel with a HIP-event pair (every 5th when steps < 64, every one when < 16); odd on purpose: "
+    ap.add_argument("--time-every", type=int, default=0, help="time every N-th launch of each kernel with a HIP-event pair (default: every 7th; every 5th when steps < 64, every one when < 16); odd on purpose: "
                     "an even stride could lock onto a period of the workload")
     ap.add_argument("--gather-steps", type=int, default=50, help="extra steps timed WITH the observation all-gather (N>1)")
     args = ap.parse_args()
@@ -336,9 +336,9 @@ def main():
         hz.step()
     # HIP-event pairs handed to a launch cost stream time: measured in round 4 at ~10 us per step with every 3rd launch of both kernels timed (a
     # 20-step window: 131-143 us per step against 120-129 without, tools/tmp/window_fit2.py).  So few samples for short runs: every 5th launch = 4 pairs
-    # per kernel for the driver's 20 steps.  The strides are odd out of caution only: since round 4 the generator runs beside EVERY k_step, there are no
+    # per kernel for the driver's 20 steps (round 5, same box: 651-656 M with the four pairs per kernel, 666-676 M with none; two pairs cost the same as four).  The strides are odd out of caution only: since round 4 the generator runs beside EVERY k_step, there are no
     # two kinds of launch left to alternate between.
-    every = 1 if K < 16 else (5 if K < 64 else args.time_every)
+    every = args.time_every if args.time_every > 0 else (1 if K < 16 else (5 if K < 64 else 7))
     hz.timing(every)  # HIP-event pairs on the launch stream around every `every`-th launch of each kernel
     env.counters(reset=True)
     barrier()
