@@ -600,16 +600,19 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
         TimedLaunch t(h, 4, true);
         if (h->lane_regen) {
             // Two producers.  Beside EVERY step (gate + k_regen on `side`), one level per wave: the next-level structures -- wanted within two steps -- and
-            // the urgent spares (an env down to its last ready one).  Every 32nd step, one level per LANE (rg_regen_lanes.hip): every spare consumed since,
-            // ~10 000 of the 4 x 65 536.  A round of 64 levels takes a wave 300-450 us whatever the launch's size, i.e. three to five steps: launched beside
-            // every fourth step, one of them was still running behind ANY short window of steps (the driver's 20: +24 us per step); the launches
-            // alternate between two streams of their own.
+            // the urgent spares (an env down to its last ready one).  Every 16th step, one level per LANE (rg_regen_lanes.hip): every spare consumed since,
+            // ~5 000 of the 4 x 65 536.  A round of 64 levels takes a wave 300-450 us whatever the launch's size, i.e. three to five steps: launched beside
+            // every fourth step, one of them was still running behind ANY short window of steps (the driver's 20: +24 us per step).  Rarer launches leave
+            // more envs to the urgent path, whose 45-us wave-per-level builds beside k_step cost the step more than the bulk launches do (1500 steps, one
+            // box: every 8th / 16th 675-676 M, 24th 667 M, 32nd 664 M, 64th 647 M, 128th 622 M; an urgent build only for envs with NO spare left: 654 M at
+            // 16 -- a reset that finds no spare generates inline, 45 us in an index-order wave).  The launches alternate between two streams of their own.
             static const int lane_waves = RG_DEV_ENV("ROGUE_GYM_HIP_LANE_WAVES") ? atoi(RG_DEV_ENV("ROGUE_GYM_HIP_LANE_WAVES")) : 256;
-            static const int lane_every = RG_DEV_ENV("ROGUE_GYM_HIP_LANE_EVERY") ? atoi(RG_DEV_ENV("ROGUE_GYM_HIP_LANE_EVERY")) : 32;
+            static const int lane_every = RG_DEV_ENV("ROGUE_GYM_HIP_LANE_EVERY") ? atoi(RG_DEV_ENV("ROGUE_GYM_HIP_LANE_EVERY")) : 16;
             static const bool time_lanes = RG_DEV_ENV("ROGUE_GYM_HIP_TIME_LANES") != nullptr;  // (development: the event pair of rg_timing's kernel 4 goes to the level-per-lane launch)
             const bool lanes_now = h->regen_bulk > 0 || h->step_count - h->lane_last >= (uint64_t)(lane_every > 0 ? lane_every : 1);
             // (spares = 2: next-level structures + the urgent spares -- envs down to their last ready one; rg_kernels.hip regen_body)
-            rgk_regen(&h->SP, &h->cfg, 0, 2, h->S.launch_mark, (uint32_t)h->S.stair_gen + 1u, h->d_err, h->side, time_lanes ? nullptr : t.start_ev(), time_lanes ? nullptr : t.stop_ev());
+            static const int urgent_mode = RG_DEV_ENV("ROGUE_GYM_HIP_URGENT_AT0") ? 3 : 2;
+            rgk_regen(&h->SP, &h->cfg, 0, urgent_mode, h->S.launch_mark, (uint32_t)h->S.stair_gen + 1u, h->d_err, h->side, time_lanes ? nullptr : t.start_ev(), time_lanes ? nullptr : t.stop_ev());
             if (time_lanes && !lanes_now) t.cancel();
             if (lanes_now) {
                 h->lane_last = h->step_count;

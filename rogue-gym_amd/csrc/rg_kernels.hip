@@ -1196,19 +1196,19 @@ __device__ __forceinline__ void regen_body(const RgState &SP, const RgConfig &c,
     // launch, one step later; a spare is wanted an episode after it was consumed.
     // (spares == 0: the consumed spares are rebuilt by the level-per-lane producer, rg_regen_lanes.hip; this launch serves the next-level structures only)
     // spares == 1: the wave-per-level producer of the one-slot layout (ROGUE_GYM_HIP_WAVE_REGEN, > 32 rooms).  spares == 2: the consumed spares are rebuilt
-    // 64 levels per wave by rg_regen_lanes.hip, a launch every 32 steps (a round takes 300-450 us whatever its size: a launch beside every few steps left one
+    // 64 levels per wave by rg_regen_lanes.hip, a launch every 16 steps (a round takes 300-450 us whatever its size: a launch beside every few steps left one
     // running behind every short window of steps); what this launch adds is the URGENT case -- an env that is down to its last ready spare (fixed-seed envs
     // that die within a dozen steps do so episode after episode) gets one built here, beside the next step.
     int es = e;  // the spare-view entry to build
     bool want = false;
     if (valid && spares == 1) want = __hip_atomic_load(&SP.sp_ready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
-    else if (valid && spares == 2) {
+    else if (valid && spares >= 2) {  // (spares == 3, development: only an env with NO ready spare left)
         int live_slots = 0, free_slot = -1;
         for (int sl = SP.sp_slots - 1; sl >= 0; sl--) {
             const uint32_t st = __hip_atomic_load(&SP.sp_ready[(size_t)sl * SP.n + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (st == 0u) free_slot = sl; else live_slots++;  // (ready, or claimed by a producer)
         }
-        want = live_slots <= 1 && free_slot >= 0;
+        want = live_slots <= (spares == 3 ? 0 : 1) && free_slot >= 0;
         if (want) es = free_slot * SP.n + e;
     }
     // ... or ONE next-level structure (gen_service), which goes first: it is wanted within two or three steps, a spare an episode later
