@@ -513,6 +513,34 @@ def test_full_size_default_and_symbol_obs(goldens):
         torch.cuda.empty_cache()
 
 
+def test_batch_sizes_where_the_wave_count_is_capped(goldens):
+    """on a W > 32 config (one step wave per SIMD) rgk_step_epw caps the index-order blocks at 1008 -- and for n = 64 513..65 472 that gave 65
+    envs per 64-lane wave: env b * 65 + 64 of every block was never stepped.  65 000 envs of the 80x24 dungeon: every env receives its keys (the launch's
+    key counter), and the envs at the old blocks' 65th places play like the oracle."""
+    cfg = goldens["configs"]["default"]
+    n = 65000
+    rng = np.random.RandomState(29)
+    hip = HipBatch(cfg, list(range(n)), max_steps=1000)
+    keys = rand_keys(rng, ACTION_KEYS, n, 12)
+    cnt = (ctypes.c_uint64 * 8)()
+    hip.h.check(hip.h.L.rg_counters(hip.h.h, cnt, 1))
+    for k in keys:
+        hip.step(k)
+    hip.sync()
+    hip.h.check(hip.h.L.rg_counters(hip.h.h, cnt, 0))
+    assert cnt[6] == n * len(keys), (cnt[6], n * len(keys))   # [6] keys processed
+    screen, hist, status, flags = hip.fetch()
+    sample = [b * 65 + 64 for b in range(0, 1000, 25)] + [0, 63, 64, 65, n - 1]
+    oracles = make_oracles(cfg, sample)
+    for k in keys:
+        for j, o in enumerate(oracles):
+            o.step_autoreset(int(k[sample[j]]))
+    for j, o in enumerate(oracles):
+        i = sample[j]
+        assert np.array_equal(screen[i], o.screen()), "env %d" % i
+        assert [int(v) for v in status[i]] == [int(v) for v in o.status_arr()], "env %d" % i
+
+
 def test_custom_enemy_presets(goldens):
     """Full GameConfig coverage: custom monster statuses mixed with builtin presets, custom appear rates."""
     from parity_util import custom_enemy_config
