@@ -252,6 +252,8 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
               dev_alloc(h, &h->d_err, 4) && dev_alloc(h, &h->d_keys, n);
     // the envs' observation records (rg_state.h obs_rec): for the grids the fused observation pass handles
     if (ok && nr <= RG_OBS_MAX_ROOMS) ok = dev_alloc(h, &S.obs_rec, n * (size_t)RG_OBS_REC_WORDS(nr));
+    if (ok && nr <= RG_OVL_MAX && getenv("ROGUE_GYM_HIP_NO_MIRROR_UPDATE") == nullptr)  // (the A side: every Redraw drawn from the tiles by the observation pass)
+        ok = dev_alloc(h, &S.ovl, (nr + 1) * n) && hipMemset(S.ovl, 0xff, (nr + 1) * n * 2) == hipSuccess;
     h->spares = auto_reset != 0 && getenv("ROGUE_GYM_HIP_NO_SPARES") == nullptr;
     // which producer refills the consumed spares: one level per LANE (rg_regen_lanes.hip; two spares per env, rg_state.h sp_slots) where it applies,
     // else -- or with ROGUE_GYM_HIP_WAVE_REGEN=1 -- one level per wave (k_regen, one spare per env)

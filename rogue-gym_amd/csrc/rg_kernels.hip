@@ -1012,6 +1012,7 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
                     uint32_t *rec = S.obs_rec + (size_t)real_e * RG_OBS_REC_WORDS(nrooms);
                     rec[r] = T->mon_w0[r]; rec[nrooms + 1 + r] = T->room_rect[r]; reinterpret_cast<uint8_t *>(&rec[2 * nrooms + 1])[r] = T->room_meta[r];
                 }
+                if (S.ovl) S.ovl[(size_t)r * real_n + real_e] = (uint16_t)(((T->mon_w0[r] >> 24) & MF_ALIVE) ? ((T->mon_w0[r] & 0xffffu) | 0x40u) : 0xffffu);  // (| OVL_UNKNOWN)  // (the player's: the caller)
             }
             if (GM < 2) break;
         }
@@ -1134,6 +1135,7 @@ __global__ void __launch_bounds__(WAVE) k_build(RgState S, RgConfig c) {
     store_env(S, E);
     write_status(S, c, E);
     if (S.obs_rec) { const int nr = c.room_num_x * c.room_num_y; S.obs_rec[(size_t)e * RG_OBS_REC_WORDS(nr) + nr] = POS(E.px, E.py); }  // (the rest of the record: gen_service)
+    if (S.ovl) S.ovl[(size_t)(c.room_num_x * c.room_num_y) * S.n + e] = (uint16_t)(POS(E.px, E.py) | 0x40u);  // (| OVL_UNKNOWN)
     S.dc_len[e] = 0; S.dc_head[e] = 0; S.dc_part[e] = 0; S.dc_own[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
     if (S.nx_state) (void)__hip_atomic_fetch_and(&S.nx_state[e], RG_NX_DROP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (as step_wave's new level)
     S.steps[e] = 0;
@@ -1166,6 +1168,7 @@ __global__ void __launch_bounds__(WAVE) k_debug_descend(RgState S, RgConfig c) {
     store_env(S, E);
     write_status(S, c, E);
     if (S.obs_rec) { const int nr = c.room_num_x * c.room_num_y; S.obs_rec[(size_t)e * RG_OBS_REC_WORDS(nr) + nr] = POS(E.px, E.py); }  // (the rest of the record: gen_service)
+    if (S.ovl) S.ovl[(size_t)(c.room_num_x * c.room_num_y) * S.n + e] = (uint16_t)(POS(E.px, E.py) | 0x40u);  // (| OVL_UNKNOWN)
     if (S.nx_state) (void)__hip_atomic_fetch_and(&S.nx_state[e], RG_NX_DROP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (as step_wave's new level)
     S.flags[e] = (S.flags[e] & (RG_FLAG_TERMINAL | RG_FLAG_DEAD)) | RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY | E.err;
     if (E.err) atomicOr(S.err_any, E.err);
@@ -2307,6 +2310,118 @@ __device__ __forceinline__ bool monsters_move(const RgState &S, const RgConfig &
     return false;
 }
 
+// What a cell shows without overlays (rg_obs.hip's decode, core/src/lib.rs:264-285 + rogue/mod.rs:278-300): the glyph, bit 7 = an object on it is drawn
+__device__ __forceinline__ uint32_t base_glyph(const RgConfig &c, uint32_t v, int y) {
+    const bool inner = y >= 1 && y < c.height - 1;
+    uint32_t gl = ' ';
+    if (inner && (v & C_VISIBLE)) gl = glyph_of(v);
+    if (inner && (v & (C_VISIBLE | C_DRAWN))) gl = ((v & C_GOLD) ? (uint32_t)'*' : gl) | 0x80u;
+    return gl;
+}
+// The incremental form of draw_screen for an ordinary Redraw (step_wave).  S.ovl remembers, per monster slot and for the player, where the overlay stood at the
+// env's last Redraw and whether it SHOWED then (OVL_SHOW; OVL_UNKNOWN after a Redraw that was drawn from the tiles): a sleeping monster that shows as it did,
+// on a cell the turn did not touch, costs nothing -- no tile load, no store.  Stores go to the cells that really change: the turn's written-back window cells,
+// overlays that moved / appeared / disappeared, the player's old and new cell (a byte store is a partial-line write: twelve of them per lane cost k_step 7 us).
+#define OVL_SHOW 0x80u     // (the y field of a position holds 0..63: its two top bits are free)
+#define OVL_UNKNOWN 0x40u
+#define OVL_NONE 0xffffu
+// Returns false -- nothing written -- when a cell it would have to write lies outside the window: its tile is not at hand, and a load here would wait for every
+// store of the turn; the Redraw then goes to the observation pass as before.
+__device__ __forceinline__ bool mirror_update(const RgState &S, const RgConfig &c, const Env &E, const Win &w, int mc_offset, uint32_t react, int rid0) {
+    const int W = c.width, nrooms = c.room_num_x * c.room_num_y, n = E.n;
+    // (the env index through an opaque move: the addresses below are then computed HERE -- left alone, the compiler computes `S.ovl + ... + e`, `S.hist + e * hw`
+    // at the top of the kernel, spills them, and reloads them here one by one, each reload waiting for every store the turn has issued: 5 us per wave)
+    int e = E.e;
+    asm volatile("" : "+v"(e));
+    uint8_t *scr = S.screen + (size_t)e * S.hw;
+    // (the lane's LDS columns from the lane id, here: a pointer carried from the top of the wave is one more spilled register to reload)
+    int ln = threadIdx.x;
+    asm volatile("" : "+v"(ln));
+    const lds_u32 *mc = (const lds_u32 *)(g_smem + mc_offset) + ln;
+    const lds_u32 *ovl_l = (const lds_u32 *)(g_smem + mc_offset + nrooms * WAVE * 4 + WIN_SLOTS * WAVE * 2) + ln;
+    const uint32_t ds = ovl_l[0] & 0x1ffffffu;
+    const int px = E.px, py = E.py, rid = room_id_of(c, px, py);
+    auto in_win = [&](int x, int y) { const int i = x - w.ox, j = y - w.oy; return i >= -2 && i <= 2 && j >= -2 && j <= 2; };
+    auto dirty_at = [&](int x, int y) { return in_win(x, y) && ((ds >> WIN_K(x - w.ox, y - w.oy)) & 1u); };
+    // (the two candidate rooms were fetched with the window: the one of the cell the turn started on, rid0, and the one of the cell the key pointed at)
+    const int rsel = rid == rid0 ? 0 : 2;
+    const uint32_t r_rect = ovl_l[(RG_OVL_MAX + 2 + rsel) * WAVE], r_meta = ovl_l[(RG_OVL_MAX + 3 + rsel) * WAVE] & 0xffu;
+    const __attribute__((address_space(3))) uint8_t *mt = (const __attribute__((address_space(3))) uint8_t *)(ovl_l - ln + (RG_OVL_MAX + 6) * WAVE);
+    // pass 1: per slot, what is to be done -- 3 bits each in one register (bit 0 restore the old cell, bit 1 draw the monster, bit 2 it shows now); loops,
+    // not unrolled code with register arrays: this runs between the monsters' turn and the tail, where every register it takes is one the allocator spills --
+    // and a spill's reload is a LOAD: it waits for every store the turn has issued (measured: five reloads, 5 us per wave)
+    uint32_t actp = 0;
+    bool far = false;
+#pragma nounroll
+    for (int s0 = 0; s0 < nrooms; s0++) {
+        const uint32_t p = ovl_l[(1 + s0) * WAVE], m = mc[s0 * WAVE];
+        const bool alive = (m >> 24) & MF_ALIVE, had = p != OVL_NONE;
+        const uint32_t pp = p & 0xff3fu, pn = m & 0xffffu;
+        bool show = false;
+        if (alive) {
+            const int x = POS_X(pn), y = POS_Y(pn), dx = px - x, dy = py - y;
+            show = dx * dx + dy * dy <= 2;
+            if (!show && rid >= 0 && room_id_of(c, x, y) == rid) {  // Floor::in_same_room (floor.rs:381-393)
+                if ((r_meta & RM_KIND_MASK) == RK_EMPTY) show = true;
+                else {
+                    int x0, y0, x1, y1;
+                    unpack_rect(r_rect, x0, y0, x1, y1);
+                    const bool ina = px >= x0 && px < x1 && py >= y0 && py < y1, inb = x >= x0 && x < x1 && y >= y0 && y < y1;
+                    show = ina == inb;
+                }
+            }
+        }
+        const bool unknown = had && (p & OVL_UNKNOWN), showed = had && (p & OVL_SHOW);
+        const bool same = had && alive && pp == pn && !unknown && !dirty_at(POS_X(pn), POS_Y(pn));
+        uint32_t a = 0;
+        if (same) { if (showed && !show) a = 1u; else if (!showed && show) a = 2u; }
+        else { if (had && (showed || unknown)) a |= 1u; if (show) a |= 2u; }
+        a |= show ? 4u : 0u;
+        actp |= a << (3 * s0);
+        if (((a & 1u) && !in_win(POS_X(pp), POS_Y(pp))) || ((a & 2u) && !in_win(POS_X(pn), POS_Y(pn)))) far = true;
+        // where the overlay stands now and how it shows -- right whoever draws this Redraw (below, or the observation pass from the tiles)
+        const uint32_t now = alive ? (pn | (show ? OVL_SHOW : 0u)) : OVL_NONE;
+        if (now != p) S.ovl[(size_t)s0 * n + e] = (uint16_t)now;
+    }
+    const uint32_t pl = ovl_l[(1 + nrooms) * WAVE];
+    const uint32_t plp = pl & 0xff3fu;
+    const bool pl_moved = pl == OVL_NONE || (pl & OVL_UNKNOWN) || plp != POS(px, py) || dirty_at(px, py);
+    if (pl_moved) S.ovl[(size_t)nrooms * n + e] = (uint16_t)POS(px, py);
+    if (far || (pl_moved && pl != OVL_NONE && !in_win(POS_X(plp), POS_Y(plp)))) return false;
+    // 1. the cells the turn wrote back: what they show by themselves (overlays on them are redrawn below: such a slot is never `same`)
+    for (uint32_t d = ds; d;) {
+        const int k = __ffs((int)d) - 1;
+        d &= d - 1;
+        const int j = k / 5, i = k - j * 5, x = w.ox + i - 2, y = w.oy + j - 2;
+        scr[y * W + x] = (uint8_t)(base_glyph(c, WV(w, k), y) & 0x7fu);
+    }
+    if (react & R_HIST_CHANGED) S.hist[(size_t)e * S.hw + py * W + px] = 1;  // (the one way a cell becomes VISITED: the player steps on it, move_player)
+    // 2. the player's old cell, the cells monsters left or stopped showing on
+    if (pl_moved && pl != OVL_NONE) {
+        const int x = POS_X(plp), y = POS_Y(plp);
+        scr[y * W + x] = (uint8_t)(base_glyph(c, WV(w, WIN_K(x - w.ox, y - w.oy)), y) & 0x7fu);  // (one turn: the old cell is the window's centre or next to it)
+    }
+#pragma nounroll
+    for (int s0 = 0; s0 < nrooms; s0++)
+        if ((actp >> (3 * s0)) & 1u) {
+            const uint32_t pp = ovl_l[(1 + s0) * WAVE] & 0xff3fu;
+            const int x = POS_X(pp), y = POS_Y(pp);
+            scr[y * W + x] = (uint8_t)(base_glyph(c, WV(w, WIN_K(x - w.ox, y - w.oy)), y) & 0x7fu);
+        }
+    // 3. the monsters that (newly) show: draw priority monster < gold < player (core/src/lib.rs:271-283)
+#pragma nounroll
+    for (int s0 = 0; s0 < nrooms; s0++)
+        if ((actp >> (3 * s0)) & 2u) {
+            const uint32_t m = mc[s0 * WAVE];
+            const int x = POS_X(m), y = POS_Y(m);
+            const uint32_t under = base_glyph(c, WV(w, WIN_K(x - w.ox, y - w.oy)), y);
+            if ((under & 0x80u) && under != (0x80u | '*')) scr[y * W + x] = mt[(m >> 16) & 0xff];
+        }
+    // 4. the player
+    if (pl_moved && (base_glyph(c, WV(w, WIN_K(px - w.ox, py - w.oy)), py) & 0x80u)) scr[py * W + px] = '@';
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_step: one key for every env
 // ---------------------------------------------------------------------------------------------
@@ -2380,6 +2495,7 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
         for (int k = 0; k < 12; k++) S.rng[k * n + e] = r[k];
         S.p_pos[e] = pp; S.p_hp[e] = hp; S.p_hpmax[e] = hpm; S.p_lvl[e] = lv;
         if (S.obs_rec) S.obs_rec[(size_t)e * RG_OBS_REC_WORDS(nrooms) + nrooms] = pp;
+        if (S.ovl) S.ovl[(size_t)nrooms * n + e] = (uint16_t)(pp | 0x40u);
         S.p_exp[e] = ex; S.food[e] = fd; S.quiet[e] = qu; S.pack_gold[e] = pg; S.dlevel[e] = dl; S.mon_cnt[e] = mc;
         for (int s0 = 0; s0 < nrooms; s0 += 4) {  // tables, four slots per round
             uint32_t rr[4], mw[4], me[4], gp[4], ga[4]; int32_t mh[4]; uint8_t rm[4];
@@ -2397,6 +2513,7 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
                         uint32_t *rec = S.obs_rec + (size_t)e * RG_OBS_REC_WORDS(nrooms);
                         rec[s0 + k] = mw[k]; rec[nrooms + 1 + s0 + k] = rr[k]; reinterpret_cast<uint8_t *>(&rec[2 * nrooms + 1])[s0 + k] = rm[k];
                     }
+                    if (S.ovl) S.ovl[(size_t)(s0 + k) * n + e] = (uint16_t)(((mw[k] >> 24) & MF_ALIVE) ? ((mw[k] & 0xffffu) | 0x40u) : 0xffffu);  // (| OVL_UNKNOWN)
                 }
         }
     }
@@ -2425,6 +2542,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     int gold0 = 0;       // the status mirror's gold before this key
     bool live = false;   // this lane processes a key this call
     bool ui_dead = false, terminal = false;
+    bool inc_done = false;  // the turn applied its Redraw to the screen mirror itself (mirror_update)
     bool taken = false;  // terminal + auto-reset + spare ready: the spare becomes the live state at the end of the wave (take_spares)
     uint32_t n_bfs = 0, n_inline = 0, n_taken = 0, n_cont = 0;  // workload counters (S.stats)
     uint32_t key = 0, nxs = RG_NX_NONE;
@@ -2432,6 +2550,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     // LDS monster cache: column `lane` of [nrooms][64] words behind the generation / BFS staging area
     const int nrooms_k = c.room_num_x * c.room_num_y;
     E.mc = (lds_u32 *)(g_smem + mc_offset) + lane;
+    const uint32_t glyph_r = S.ovl ? c.mon[lane & 31].tile : 0u;  // (the monster glyphs by type, for the wave's LDS table: requested with the first round of loads)
     if (valid_in) {
         // ONE round of independent loads: the step's inputs, the env's scalars and its monster words together.  (Whether the lane plays at all is
         // only known from the first few -- loading the env behind that decision was a second dependent round trip in every wave; a lane that turns
@@ -2486,8 +2605,42 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     bool need_gen = false, descends = false;
     Win w;  // the 5x5 tiles around the player: one round of loads serves the whole player action
     w.v = (lds_u16 *)(g_smem + mc_offset + nrooms_k * WAVE * 4) + lane;
+    // [0]: the dirty mask of the turn's window write-back (bit 31: a whole-room fill happened), [1 .. RG_OVL_MAX + 1]: where overlays stood at the env's last
+    // Redraw (S.ovl) -- parked here from the first load round to the incremental mirror update at the end of the turn
+    lds_u32 *ovl_l = (lds_u32 *)(g_smem + mc_offset + nrooms_k * WAVE * 4 + WIN_SLOTS * WAVE * 2) + lane;
+    ovl_l[0] = 0;
+    if (S.ovl && lane < RG_MAX_ENEMY_KINDS + 6)
+        ((__attribute__((address_space(3))) uint8_t *)(g_smem + mc_offset + nrooms_k * WAVE * 4 + WIN_SLOTS * WAVE * 2 + (RG_OVL_MAX + 6) * WAVE * 4))[lane] = (uint8_t)glyph_r;
+    if (S.ovl) {
+        // where the overlays of the env's screen mirror stand, straight into LDS (global_load_lds: no register, no wait -- they are read at the end of the
+        // turn).  Unconditional for every lane and slot (an idle lane reads env 0's): LDS-DMA calls under divergent control flow are what the compiler
+        // merges into one instruction with a per-lane M0 (profiles/r05_experiments.txt).
+        typedef const __attribute__((address_space(1))) void *gptr;
+        typedef __attribute__((address_space(3))) void *lptr;
+        lds_u32 *base = (lds_u32 *)(g_smem + mc_offset + nrooms_k * WAVE * 4 + WIN_SLOTS * WAVE * 2);
+        const size_t es = valid_in ? (size_t)e : 0;
+#pragma unroll
+        for (int s0 = 0; s0 <= RG_OVL_MAX; s0++)
+            __builtin_amdgcn_global_load_lds((gptr)(S.ovl + (size_t)(s0 <= nrooms_k ? s0 : 0) * S.n + es), (lptr)(base + (1 + s0) * WAVE), 2, 0, 0);
+    }
     // (a stair wave's lanes press '>' on the staircase by construction: nothing of the old level is looked at again, so no window)
     w.inb = 0;
+    if (S.ovl) {
+        // With the window: kind and rect of the room(s) the player can stand in after this key -- the cell he is on and the one the key points at -- straight
+        // into LDS (the end of the turn picks; Floor::in_same_room), and the monster glyphs by type.  Nothing the mirror update needs is loaded at the
+        // end of the turn: a load there waits for every store the turn has issued (vmcnt is in order): measured 6 us per wave.
+        typedef const __attribute__((address_space(1))) void *gptr;
+        typedef __attribute__((address_space(3))) void *lptr;
+        lds_u32 *base = (lds_u32 *)(g_smem + mc_offset + nrooms_k * WAVE * 4 + WIN_SLOTS * WAVE * 2);
+        const size_t es = valid_in ? (size_t)e : 0;
+        const bool mv = live && (act == ACT_MOVE || act == ACT_MOVE_UNTIL);
+        const int ra = room_id_of(c, E.px, E.py), rb = mv ? room_id_of(c, E.px + dir_dx(dir), E.py + dir_dy(dir)) : ra;
+        const size_t aa = (size_t)(ra >= 0 ? ra : 0) * S.n + es, ab = (size_t)(rb >= 0 ? rb : 0) * S.n + es;
+        __builtin_amdgcn_global_load_lds((gptr)(S.room_rect + aa), (lptr)(base + (RG_OVL_MAX + 2) * WAVE), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(S.room_meta + aa), (lptr)(base + (RG_OVL_MAX + 3) * WAVE), 1, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(S.room_rect + ab), (lptr)(base + (RG_OVL_MAX + 4) * WAVE), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(S.room_meta + ab), (lptr)(base + (RG_OVL_MAX + 5) * WAVE), 1, 0, 0);
+    }
     if (live && stair_role != 1) win_load(c, E.cell, w, E.px, E.py);
     else { w.inb = 0; w.dirty = 0; w.ox = w.oy = 0; }
     pf.mark(26);
@@ -2595,6 +2748,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             pf.mark(3);
             // whole-room reveals / hides by the wave, then the lanes' changed window cells (the final word on those cells); both before any
             // monster or BFS read of the grid
+            ovl_l[0] = w.dirty | ((fr.leave | fr.enter) ? 0x80000000u : 0u);  // (for the incremental mirror update: valid when the key took ONE turn)
             fill_service(S, c, lane, e, fr);
             win_flush(c, E.cell, w);
             pf.mark(27);
@@ -2633,6 +2787,17 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             steps += 1;
             terminal = (react & R_GRAVE) || steps >= c.max_steps;
             need_gen = terminal && c.auto_reset;  // ThreadConductor::step (thread_impls.rs:69-79)
+            // ---- the screen mirror kept current by the turn itself (VERDICT r4 task 4a) ----
+            // An ordinary Redraw -- one turn, no whole-room reveal, no new level, history plane in step -- changes the screen in two places only: the window
+            // cells the turn wrote back, and the overlays (monsters, player: where they stood at the last Redraw -- S.ovl -- and where they stand now).  The
+            // lane writes those bytes of the mirror (and of the history plane) itself and raises no Redraw: the observation pass then treats the env like
+            // the 57 % that did not redraw -- mirror -> f32, no tile decode, no overlay phases, no mirror write-back (its Redraw path is issue-bound, not
+            // byte-bound: profiles/r05_experiments.txt).  Everything else keeps the Redraw flag and is drawn from the tiles as before.
+            if (S.ovl && (react & R_REDRAW) && !descends && !need_gen && iter == 1 &&
+                !(old_flags & (RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | RG_FLAG_HIST_DIRTY)) && !(ovl_l[0] >> 31)) {
+                if (mirror_update(S, c, E, w, mc_offset, react, room_id_of(c, w.ox, w.oy))) flags &= ~(RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY);
+                inc_done = true;  // (the overlays' positions and how they show are recorded either way)
+            }
         }
     }
     pf.mark(6);
@@ -2678,6 +2843,14 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         // The env's observation record (rg_state.h obs_rec; rg_obs.hip ObsTabs): the fused observation pass overlays a Redraw from these words -- one line
         // per env instead of the env's column of the [slot][env] tables.  Here: the monsters as they stand after their turn (the wave's LDS table) and the
         // player; the room half is written with the level's tables (gen_service, take_spares -- which also writes a taken env's monsters and player).
+        if (S.ovl && !taken && !inc_done && ((react & R_REDRAW) || descends || (terminal && c.auto_reset))) {
+            // a Redraw the observation / render pass draws from the tiles: where the overlays stand as of it; how they show is not known here (OVL_UNKNOWN)
+            for (int s0 = 0; s0 < nrooms_k; s0++) {
+                const uint32_t mw = E.mc[s0 * WAVE];
+                S.ovl[(size_t)s0 * S.n + e] = (uint16_t)(((mw >> 24) & MF_ALIVE) ? ((mw & 0xffffu) | OVL_UNKNOWN) : OVL_NONE);
+            }
+            S.ovl[(size_t)nrooms_k * S.n + e] = (uint16_t)(POS(E.px, E.py) | OVL_UNKNOWN);
+        }
         if (S.obs_rec && (flags & RG_FLAG_REDRAW) && !taken) {
             uint32_t *rec = S.obs_rec + (size_t)e * RG_OBS_REC_WORDS(nrooms_k);
             for (int s0 = 0; s0 < nrooms_k; s0 += 4) {
@@ -2840,6 +3013,7 @@ int rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const u
     int mc_offset = (int)smem;
     smem += (size_t)c->room_num_x * c->room_num_y * WAVE * 4;  // LDS monster cache
     smem += WIN_SLOTS * WAVE * 2;                              // ... and the lanes' 5x5 tile windows
+    smem += (RG_OVL_MAX + 6) * WAVE * 4 + 64;                       // ... and the parked overlay positions, dirty mask, the player's room (step_wave: incremental mirror update)
     const int epw = rgk_step_epw(S->n, (c->width <= 32 && gen_mode_of(c) == 0) ? 2 : 1);
     // parity >= 0: stair isolation with the list the last render / observation pass wrote into set `parity`
     const int nb = (S->n + epw - 1) / epw;

@@ -128,6 +128,9 @@ struct RgState {
     // Follows the env's tables: k_step writes the monster words and the player's position of every env whose key produced a Redraw, the generator's
     // copy-out (gen_service) and the spare hand-off (take_spares) the rooms and the new level's monsters.  NULL: more rooms than the fused pass handles
     uint32_t *obs_rec;
+    // [rooms + 1][n]: where the overlays of the env's screen mirror stand -- the monsters' and (last row) the player's position as of the env's last Redraw,
+    // 0xFFFF = none: what k_step's incremental mirror update restores before it draws the overlays anew.  NULL: more than RG_OVL_MAX rooms.
+    uint16_t *ovl;
     // action-history log (RunTime::saved_inputs, core/src/lib.rs:288): the keys of the current and of the previous episode, NULL = off
     uint8_t *klog;      // [n][2][klog_cap]
     uint32_t *klog_len; // [2][n] keys accepted in episode buffer 0 / 1 (may exceed klog_cap: the tail is then not stored)

@@ -198,6 +198,40 @@ def test_spare_hand_off_at_full_batch(goldens):
     b.close()
 
 
+@pytest.mark.parametrize("name,n", [("mini", 65536), ("default", 16384)], ids=["mini", "default 80x24 (9 rooms: the tile-drawn path only)"])
+def test_mirror_kept_by_the_turn_equals_the_mirror_drawn_from_the_tiles(goldens, name, n):
+    """An ordinary Redraw (one turn, no whole-room reveal, no new level, history plane in step) is applied to the screen and history mirrors by k_step itself
+    -- the window cells it wrote back, the overlays where they stood (S.ovl) and where they stand -- and raises no Redraw flag; everything else is drawn from
+    the tiles by the observation / render pass.  Against a handle that draws EVERY Redraw from the tiles (ROGUE_GYM_HIP_NO_MIRROR_UPDATE): screen, history,
+    status and the public flag bits of every env, every second step, run keys and 50-step episodes (resets, descents, rooms entered and left) included."""
+    import os
+
+    from rogue_gym_python import _rogue_gym as inner
+
+    steps = 160
+    cfgs = [json.dumps(dict(goldens["configs"][name], seed=i % 9000)) for i in range(n)]
+    a = inner._Handle(cfgs, 50, auto_reset=True)
+    os.environ["ROGUE_GYM_HIP_NO_MIRROR_UPDATE"] = "1"
+    try:
+        b = inner._Handle(cfgs, 50, auto_reset=True)
+    finally:
+        del os.environ["ROGUE_GYM_HIP_NO_MIRROR_UPDATE"]
+    rng = np.random.RandomState(31)
+    table = np.frombuffer(b"hjklyubnhjklyubnhjklyubnHJKL>s.", np.uint8)
+    public = 0x00FF7F03  # terminal, dead, message bits, error bits (the mirror bookkeeping bits differ by construction)
+    for t in range(steps):
+        keys = np.ascontiguousarray(table[rng.randint(0, len(table), n)])
+        for h in (a, b):
+            h.check(h.L.rg_step(h.h, keys.ctypes.data, 0))
+        if t % 2 == 1:
+            xa, xb = a.fetch(), b.fetch()
+            for x, y, what in zip(xa[:3], xb[:3], ("screen", "hist", "status")):
+                assert np.array_equal(x, y), (t, what, [i for i in range(n) if not np.array_equal(x[i], y[i])][:8])
+            assert np.array_equal(xa[3] & public, xb[3] & public), (t, "flags")
+    a.close()
+    b.close()
+
+
 def test_urgent_spares_of_envs_that_die_fast(goldens):
     """The bulk of the consumed spares is rebuilt every 16th step (one level per lane, rg_regen_lanes.hip); an env that is down to its last ready spare gets
     one built beside the very next step by the wave-per-level producer (k_regen, spares == 2).  Episodes of 3 steps consume a spare every 3 steps -- five
