@@ -22,7 +22,7 @@ WEAPONS = ["mace", "long-sword", "bow", "arrow", "dagger", "two-handed-sword", "
 ARMORS = ["leather armor", "ring mail", "studded leather armor", "scale mail", "chain mail", "splint mail", "banded mail", "plate mail"]
 
 
-def random_config(rng):
+def random_config(rng, max_rooms=0):
     """One random config; may still be refused by the validator (min_room_size vs the room grid): the caller skips those."""
     if rng.rand() < 0.35:
         w, h = [(32, 16), (80, 24), (64, 32), (40, 20), (96, 40), (160, 48), (128, 24)][rng.randint(0, 7)]
@@ -36,6 +36,9 @@ def random_config(rng):
     if narrow_many:
         w, h, rx = 32, int(rng.randint(30, 49)), 8
         ry = h // int(rng.randint(5, 7))
+    while max_rooms and rx * ry > max_rooms:  # (--max-rooms: e.g. 4 = the grids whose screen mirror the turn keeps current itself)
+        if rx >= ry: rx -= 1
+        else: ry -= 1
     rooms = rx * ry
     d = {"style": "rogue", "room_num_x": rx, "room_num_y": ry,
          "dark_level": int(rng.choice([1, 2, 3, 5, 10, 1000])), "maze_rate_inv": int(rng.choice([1, 2, 4, 15, 1000])),
@@ -179,6 +182,7 @@ def main():
     ap.add_argument("--envs", type=int, default=48)
     ap.add_argument("--steps", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-rooms", type=int, default=0, help="cap rooms per level (0 = no cap)")
     ap.add_argument("--minutes", type=float, default=0.0, help="keep drawing configs until this much time has passed (overrides --configs)")
     args = ap.parse_args()
     from parity_util import lockstep
@@ -190,7 +194,7 @@ def main():
     done = skipped = failed = 0
     recent = []
     while (time.time() - t0 < args.minutes * 60) if args.minutes > 0 else (done < args.configs):
-        cfg = random_config(rng)
+        cfg = random_config(rng, args.max_rooms)
         text = json.dumps(cfg)
         buf = (inner.C.c_char * 65536)()
         if L.rg_config_canonical(text.encode(), buf, len(buf)):  # refused (e.g. min_room_size does not fit): not a parity case
