@@ -8,7 +8,7 @@
                             // 40 x 9 = 360 rooms.  Three generator instances (rg_kernels.hip): <= 32 rooms, <= 64, <= 384.
 // words of an env's observation record (rg_obs.hip ObsTabs): nr monster words, the player's position, nr room rects, nr room-meta bytes; a multiple of 4 (16-byte stores)
 #define RG_OBS_REC_WORDS(nr) ((((nr) * 2 + 1 + ((nr) + 3) / 4) + 3) & ~3)
-#define RG_OVL_MAX 4          // rooms (= monsters) up to which k_step keeps the screen mirror current itself (rg_state.h ovl)
+#define RG_OVL_MAX 9          // rooms (= monsters) up to which k_step keeps the screen mirror current itself (rg_state.h ovl)
 #define RG_OBS_MAX_ROOMS 64 // the fused observation kernel stages its overlay tables in LDS for up to 64 rooms; larger grids take the unfused render + encode
 #define RG_MAX_ENEMY_KINDS 26
 #define RG_MAX_W 160        // core/src/lib.rs:134-140

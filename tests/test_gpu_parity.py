@@ -198,7 +198,7 @@ def test_spare_hand_off_at_full_batch(goldens):
     b.close()
 
 
-@pytest.mark.parametrize("name,n", [("mini", 65536), ("default", 16384)], ids=["mini", "default 80x24 (9 rooms: the tile-drawn path only)"])
+@pytest.mark.parametrize("name,n", [("mini", 65536), ("default", 16384)], ids=["mini", "default 80x24 (nine rooms)"])
 def test_mirror_kept_by_the_turn_equals_the_mirror_drawn_from_the_tiles(goldens, name, n):
     """An ordinary Redraw (one turn, no whole-room reveal, no new level, history plane in step) is applied to the screen and history mirrors by k_step itself
     -- the window cells it wrote back, the overlays where they stood (S.ovl) and where they stand -- and raises no Redraw flag; everything else is drawn from
