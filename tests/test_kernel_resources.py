@@ -68,3 +68,37 @@ def test_register_and_scratch_budget_of_the_built_kernels():
             assert m["private_segment_fixed_size"] <= 128, ("scratch memory in", k, m)
             continue
         assert m["private_segment_fixed_size"] <= 48, ("scratch memory in", k, m)  # (a 20-byte frame no instruction touches, or k_step_w32's five parked registers)
+
+
+def test_lds_dma_loads_name_their_lds_row_with_a_uniform_m0():
+    """k_step parks a few per-env words in LDS with global_load_lds (no destination register, no wait): the LDS row of such a load is M0, wave-uniform by
+    contract.  With those loads under divergent control flow the compiler once merged two of them into one instruction whose M0 came from v_readfirstlane of a
+    PER-LANE value -- half the lanes wrote into the wrong row (profiles/r05_experiments.txt).  So: in the built code objects, no LDS-DMA load of a step kernel
+    has a v_readfirstlane among the instructions that set up its M0."""
+    objdump = os.path.join(LLVM, "llvm-objdump")
+    tools = [os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler")]
+    if not os.path.exists(SO) or not os.path.exists(objdump) or not all(os.path.exists(t) for t in tools):
+        pytest.skip("library or LLVM tools not available")
+    seen = 0
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.run([tools[0], "-O", "binary", "--only-section=.hip_fatbin", SO, fat], check=True)
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+        for i, s0 in enumerate(starts):
+            part, co = os.path.join(d, "b%d.bin" % i), os.path.join(d, "b%d.co" % i)
+            open(part, "wb").write(blob[s0:(starts[i + 1] if i + 1 < len(starts) else len(blob))])
+            subprocess.run([tools[1], "--unbundle", "--type=o", "--input=" + part, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            asm = subprocess.run([objdump, "-d", co], check=True, capture_output=True, text=True).stdout.splitlines()
+            ins = [ln.split("//")[0].strip() for ln in asm if ln.startswith("\t")]
+            for k, ln in enumerate(ins):
+                if "global_load_lds" in ln:
+                    seen += 1
+                    # back to the s_mov that set M0 for this load: nothing on the way may be a readfirstlane
+                    j = k - 1
+                    while j >= 0 and k - j < 24 and not (ins[j].startswith("s_mov_b32 m0") or "m0," in ins[j]):
+                        j -= 1
+                    window = ins[max(0, j - 3):k]
+                    assert not any("v_readfirstlane" in w for w in window), (i, k, window[-8:])
+    assert seen >= 9, seen   # (the step kernels' parked loads are there at all)
