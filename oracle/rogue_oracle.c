@@ -869,6 +869,11 @@ static int move_enemy(orc_env *e, int cx, int cy, int tx, int ty, skip_fn skip, 
     for (int d = 0; d < 9; d++) {
         int nx = cx + DX[d], ny = cy + DY[d];
         if (skip(e, nx, ny)) continue;
+        /* A neighbour outside the grid (a chaser on column 0 / W-1: the single cell of an Empty room, rooms.rs:226, may lie there): the reference's
+         * `*dist_map.get_p(next)` (rect-iter Get2D::get_p = try_get_p(..).expect(..)) PANICS on it -- the worker thread dies -- so there is no result to
+         * reproduce.  Here (and in the HIP stepper's monsters_move) such a neighbour is simply not a candidate.  (Found by the ASan build, round 6: the
+         * unguarded read landed on the allocator's header word, 0, which the tests below happened to treat the same way.) */
+        if (!INB(e, nx, ny)) continue;
         uint32_t nd = dist[IDX(e, nx, ny)];
         if (nd == 0 && can_move_impl(e, cx, cy, d, 1)) return MR_REACH;
         if (MUT(48) && !can_move_impl(e, cx, cy, d, 1)) continue; /* M48 App. C-10: candidates checked for legality (no corner cutting) */

@@ -190,6 +190,7 @@ const char *rg_last_error(const rg_t *h) { return h ? h->err.c_str() : g_create_
 // sha256[:16] of the sources this library was built from (__graft_entry__.source_id); the marker makes it readable from the file without dlopen
 const char *rg_build_id(void) { static const char id[] = "RGBUILDID:" RG_BUILD_ID; return id + 10; }
 
+static void destroy_handle(rg_handle *h);  // (synchronises and destroys the background streams before it frees: every failure path of create_homog goes through it)
 // what differs between the envs of one config group: the seed, or the range a fresh seed is drawn from
 struct EnvSeed { bool has_seed, has_range; uint64_t lo, hi; unsigned __int128 r0, r1; };
 
@@ -258,7 +259,10 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
     // which producer refills the consumed spares: one level per LANE (rg_regen_lanes.hip; two spares per env, rg_state.h sp_slots) where it applies,
     // else -- or with ROGUE_GYM_HIP_WAVE_REGEN=1 -- one level per wave (k_regen, one spare per env)
     h->lane_regen = h->spares && getenv("ROGUE_GYM_HIP_WAVE_REGEN") == nullptr && rgk_regen_lanes_supported(&h->cfg, maze_cap) > 0;
-    S.sp_slots = h->lane_regen ? (RG_DEV_ENV("ROGUE_GYM_HIP_SP_SLOTS") ? atoi(RG_DEV_ENV("ROGUE_GYM_HIP_SP_SLOTS")) : 4) : 1;
+    // ROGUE_GYM_HIP_SP_SLOTS = 1..8 (default 4): spare level-1 states kept per env.  Each costs a copy of the env's grid and tables (80x24: 3.9 KB -- 1 GB for
+    // four at 65 536 envs); fewer slots = more resets that find none and generate inline, never another result.
+    const char *slots_env = getenv("ROGUE_GYM_HIP_SP_SLOTS");
+    S.sp_slots = h->lane_regen ? (slots_env ? atoi(slots_env) : 4) : 1;
     if (S.sp_slots < 1 || S.sp_slots > 8) S.sp_slots = 4;
     const size_t ns = n * (size_t)S.sp_slots;  // entries of the spare view
     ok = ok && dev_alloc(h, &S.sp_ready, ns) && dev_alloc(h, &h->d_probe, 4) && dev_alloc(h, &S.launch_mark, 4);
@@ -315,25 +319,25 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
         if (ok && (hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, lanes_low ? lo : (lo + hi) / 2) != hipSuccess || hipStreamCreateWithPriority(&h->side3, hipStreamNonBlocking, lanes_low ? lo : (lo + hi) / 2) != hipSuccess)) { h->err = "failed to create the background generation stream"; ok = false; }
     }
     ok = ok && dev_alloc(h, &h->d_SP, 1) && hipMemcpy(h->d_SP, &h->SP, sizeof(RgState), hipMemcpyHostToDevice) == hipSuccess;
-    if (!ok) { g_create_err = h->err.empty() ? "device allocation failed" : h->err; free_all(h); delete h; return 1; }
+    if (!ok) { g_create_err = h->err.empty() ? "device allocation failed" : h->err; destroy_handle(h); return 1; }
     // screen rows 0 and H-1 are never drawn: PlayerState::new fills the map with b' ' (python/src/lib.rs:41-50)
-    if (hipMemset(S.screen, ' ', n * hw) != hipSuccess) { g_create_err = "hipMemset failed"; free_all(h); delete h; return 1; }
-    if (upload_seeds(h, n)) { g_create_err = h->err; free_all(h); delete h; return 1; }
+    if (hipMemset(S.screen, ' ', n * hw) != hipSuccess) { g_create_err = "hipMemset failed"; destroy_handle(h); return 1; }
+    if (upload_seeds(h, n)) { g_create_err = h->err; destroy_handle(h); return 1; }
     h->S.stair_gen = h->stair_gen++;  // k_build produces the stair set of the first k_step
     rgk_build(&h->S, &h->cfg, h->stream);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) { g_create_err = std::string("k_build: ") + hipGetErrorString(e); free_all(h); delete h; return 1; }
+    if (e != hipSuccess) { g_create_err = std::string("k_build: ") + hipGetErrorString(e); destroy_handle(h); return 1; }
     h->render_pending = true;
     if (h->spares) {
         // first spares.  rg_create waits for them: left in the background, this one-off generation of EVERY env's spare (~2 ms at 65 536 envs)
         // competes with the first few hundred steps for issue slots (the driver's 20-step bench ran k_step at 141 us instead of ~100 us).
-        if (h->lane_regen && !(dev_alloc(h, &h->lane_q, 8) && dev_alloc(h, &h->lane_list, 2 * ns))) { g_create_err = h->err; free_all(h); delete h; return 1; }
+        if (h->lane_regen && !(dev_alloc(h, &h->lane_q, 8) && dev_alloc(h, &h->lane_list, 2 * ns))) { g_create_err = h->err; destroy_handle(h); return 1; }
         if (h->lane_regen) (void)rgk_regen_lanes(&h->SP, &h->cfg, h->lane_q, h->lane_list, 1, 0, h->S.sp_slots, h->side2, nullptr, nullptr);  // (bulk: every spare; no gate)
         else rgk_regen(&h->SP, &h->cfg, 1, 1, nullptr, 0, h->d_err, h->side, nullptr, nullptr);
         e = hipGetLastError();
         if (e == hipSuccess && !RG_DEV_ENV("ROGUE_GYM_HIP_ASYNC_FIRST_SPARES")) { e = hipStreamSynchronize(h->side); if (e == hipSuccess) e = hipStreamSynchronize(h->side2); if (e == hipSuccess) e = hipStreamSynchronize(h->side3); }  // (dev knob: the round-1 behaviour)
-        if (e != hipSuccess) { g_create_err = std::string("k_regen: ") + hipGetErrorString(e); free_all(h); delete h; return 1; }
+        if (e != hipSuccess) { g_create_err = std::string("k_regen: ") + hipGetErrorString(e); destroy_handle(h); return 1; }
         h->regen_bulk = 1;  // (the first steady-state launch too: whatever the creation launch left, e.g. when it ran in the background)
         bool all_fixed = true;
         for (uint8_t m : h->reseed) all_fixed = all_fixed && m == 0;
@@ -752,10 +756,9 @@ int rg_step_fetch(rg_t *h, const uint8_t *keys_host, int n_keys, uint8_t *screen
     HIPCHK(h, hipSetDevice(h->device));
     if (n_keys < 0) { h->err = "rg_step_fetch: negative key count"; return 1; }
     if (n_keys > h->S.n) n_keys = h->S.n;
-    if (!h->pin_keys) {
-        HIPCHK(h, hipHostMalloc((void **)&h->pin_keys, (size_t)h->S.n + 16, hipHostMallocDefault));
-        HIPCHK(h, hipHostMalloc((void **)&h->pin_err, 16, hipHostMallocDefault));
-    }
+    // (one test per buffer: a failed second allocation must not leave the first behind as "both are there")
+    if (!h->pin_keys) HIPCHK(h, hipHostMalloc((void **)&h->pin_keys, (size_t)h->S.n + 16, hipHostMallocDefault));
+    if (!h->pin_err) HIPCHK(h, hipHostMalloc((void **)&h->pin_err, 16, hipHostMallocDefault));
     memcpy(h->pin_keys, keys_host, (size_t)n_keys);
     if (rg_step_prefix(h, h->pin_keys, n_keys, 1)) return 1;  // ("on device": device-visible)
     if (flush_render(h)) return 1;

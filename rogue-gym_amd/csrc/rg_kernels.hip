@@ -2433,7 +2433,6 @@ __device__ __forceinline__ bool mirror_update(const RgState &S, const RgConfig &
 __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__restrict__ SPd, const RgConfig &c, int lane, int e, bool taken, bool &on_stairs) {
     const uint64_t tm = __ballot(taken);
     if (!tm) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // pairs with k_regen's hand-off (sc1 payload, drained, then sp_ready = 1); measured free (round 4)
     const RgState &SP = *SPd;
     const int HW = S.hw, n = S.n, nrooms = c.room_num_x * c.room_num_y;
     // the spare taken: the first of the env's spares that is ready (rg_state.h sp_slots; a slot only ever leaves READY through this env's own take, so
@@ -2443,6 +2442,10 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
     if (taken)
         for (int sl = S.sp_slots - 1; sl >= 0; sl--)
             if (__hip_atomic_load(&S.sp_ready[(size_t)sl * n + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) es = sl * n + e;
+    // The acquire BEHIND the flag loads that pick the slot and in front of every payload load: pairs with the producers' hand-off (sc1 payload, drained, then
+    // sp_ready = 1).  In front of the lookup (round 5) a slot that turned READY between the fence and its flag load could be picked and its payload -- whose
+    // SoA lines it shares with its neighbours' -- read from a line cached before the hand-off.  Measured free (round 4).
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // grids: the wave streams each taken env's 2 * HW bytes with 16-byte accesses (mini: one access per lane and env), FOUR envs per round: all their
     // loads are in flight before the first store, so a wave with several terminal lanes (the episodes of a batch created together end together) pays one
     // memory round trip per four resets.  (Round 3's slowest waves spent 15-20 us here, two envs per round.  Spelled out without arrays: the array form
@@ -2748,7 +2751,9 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             pf.mark(3);
             // whole-room reveals / hides by the wave, then the lanes' changed window cells (the final word on those cells); both before any
             // monster or BFS read of the grid
-            ovl_l[0] = w.dirty | ((fr.leave | fr.enter) ? 0x80000000u : 0u);  // (for the incremental mirror update: valid when the key took ONE turn)
+            // (for the incremental mirror update.  A lane's own turn is the loop's FIRST iteration unless it runs (MoveUntil); the later iterations -- driven by some
+            // other lane's run -- must not overwrite what it parked)
+            if (iter == 0) ovl_l[0] = w.dirty | ((fr.leave | fr.enter) ? 0x80000000u : 0u);
             fill_service(S, c, lane, e, fr);
             win_flush(c, E.cell, w);
             pf.mark(27);
@@ -2793,7 +2798,8 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             // lane writes those bytes of the mirror (and of the history plane) itself and raises no Redraw: the observation pass then treats the env like
             // the 57 % that did not redraw -- mirror -> f32, no tile decode, no overlay phases, no mirror write-back (its Redraw path is issue-bound, not
             // byte-bound: profiles/r05_experiments.txt).  Everything else keeps the Redraw flag and is drawn from the tiles as before.
-            if (S.ovl && (react & R_REDRAW) && !descends && !need_gen && iter == 1 &&
+            // (one turn per key = every action but a run: a per-LANE property -- one running lane in the wave no longer sends the other 63 to the tile-drawn Redraw)
+            if (S.ovl && (react & R_REDRAW) && !descends && !need_gen && act != ACT_MOVE_UNTIL &&
                 !(old_flags & (RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | RG_FLAG_HIST_DIRTY)) && !(ovl_l[0] >> 31)) {
                 if (mirror_update(S, c, E, w, mc_offset, react, room_id_of(c, w.ox, w.oy))) flags &= ~(RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY);
                 inc_done = true;  // (the overlays' positions and how they show are recorded either way)

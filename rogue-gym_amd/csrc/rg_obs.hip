@@ -414,9 +414,10 @@ __global__ void __launch_bounds__(256) k_export(const uint32_t *__restrict__ scr
         else o_flags[g - base - w_status] = flags[g - base - w_status];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint32_t e = *err_any;
+        // (an exchange: the background producers OR their error bits into this word while this kernel runs, and a bit raised between a read and a clear
+        // would never be reported)
+        const uint32_t e = atomicExch(err_any, 0u);
         *o_err = e;
-        if (e) *err_any = 0;
     }
 }
 __global__ void __launch_bounds__(256) k_scatter_rows(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int32_t *__restrict__ ext, int n, int row_bytes) {

@@ -283,6 +283,8 @@ class Shadow:
             nxt = (cur[0] + DIRS[d][0], cur[1] + DIRS[d][1])
             if skip(nxt):
                 continue
+            if not self.inside(*nxt):  # `*dist_map.get_p(next)` panics outside the grid (a chaser on column 0 / W-1): no result to reproduce; not a candidate
+                continue
             ndist = dist_map[self.idx(*nxt)]
             if ndist == 0 and self.can_move_impl(cur, d, True):
                 return "reach"
