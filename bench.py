@@ -167,6 +167,28 @@ class Harness:
             v["duration_share"] = v["avg_us"] * v["launches"] / total
         return out
 
+    def step_percentiles(self, steps):
+        """`steps` steps with an event pair on EVERY launch (their own window: the pairs cost stream time, so never the timed region): percentiles of the GPU
+        time of a step -- begin of its k_step to end of its observation pass -- and of the two kernels, in microseconds.  What a learner that waits on every
+        step sees, next to the mean the headline is (the level-per-lane producer's rounds show up here, not in the mean)."""
+        import numpy as np
+        steps = min(steps, 4000)
+        self.timing(1)
+        for _ in range(steps):
+            self.step()
+        out = {"steps": steps}
+        buf, got = (C.c_float * 4096)(), C.c_int()
+        for name, k in (("step", -1), ("k_step", 0), ("k_obs", 2)):
+            self.env._h.check(self.env._h.L.rg_timing_read_samples(self.env._h.h, k, buf, 4096, C.byref(got)))
+            if got.value:
+                a = np.sort(np.frombuffer(buf, np.float32, got.value).astype(np.float64)) * 1e3
+                out[name] = {"p50": float(a[len(a) // 2]), "p90": float(a[int(len(a) * 0.9)]), "p99": float(a[int(len(a) * 0.99)]), "max": float(a[-1]), "mean": float(a.mean()),
+                             "samples": int(got.value)}
+        self.timing(0)
+        if "step" in out:
+            out["p99_over_p50"] = out["step"]["p99"] / out["step"]["p50"]
+        return out
+
     def sclk(self):
         mhz = C.c_double()
         self.env._h.check(self.env._h.L.rg_probe_sclk(self.env._h.h, C.byref(mhz)))
@@ -396,6 +418,33 @@ def main():
             dist.all_reduce(lw, op=dist.ReduceOp.MAX)
         long_window = {"steps": 1000, "ms_per_step": float(lw.item()) / 1000 * 1e3, "value": n * world * 1000 / float(lw.item())}
 
+    # what one step costs a caller that waits on every step: percentiles over their own 1 000-step window (event pair on every launch)
+    step_us = hz.step_percentiles(1000)
+
+    # BASELINE.json's metric reads "whole node at 65 536 envs ... 1/2/4/8 GPU": `value` keeps 65 536 envs PER GPU (weak scaling, the contract's default); this
+    # leg is the other reading -- 65 536 envs IN TOTAL, 65 536 / N per GPU -- so that the line answers both.  A second, smaller batch on every rank (seeds = the
+    # global env index again), its own pre-roll, 200 timed steps, max over ranks.
+    strong = None
+    if world > 1:
+        total = 65536 if args.workload == "mini" else WORKLOADS[args.workload][1]
+        per = max(64, total // world)
+        sz = Harness(torch, args.workload, per, rank, local_rank)
+        for _ in range(600 + 20):
+            sz.step()
+        barrier()
+        s0 = time.perf_counter()
+        for _ in range(200):
+            sz.step()
+        barrier()
+        sdt = torch.tensor([time.perf_counter() - s0], dtype=torch.float64)
+        dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
+        sz.env.check_errors()
+        sz.close()
+        del sz
+        strong = {"scaling": "strong", "envs_total": per * world, "envs_per_gpu": per, "steps": 200, "preroll": 600, "warmup": 20, "ms_per_step": float(sdt.item()) / 200 * 1e3,
+                  "value": per * world * 200 / float(sdt.item()), "unit": "env-steps/s",
+                  "note": "the same workload with the batch SPLIT over the GPUs; k_step is a per-wave latency chain, so a smaller shard is not proportionally faster (DESIGN.md section 6)"}
+
     # optional: the north-star's observation all-gather (ONE collective of the packed compact records, expanded by HIP kernels on the consumer).
     # Two legs: through torch.distributed (all_gather_into_tensor, backend nccl = RCCL) and through the C-ABI's own communicator
     # (rg_comm_init / rg_allgather_compact: pack into the rank's slice + ncclAllGather in place on the handle's stream).  Neither can take the
@@ -456,6 +505,8 @@ def main():
                 cnt, urank = env.comm_count()   # what RCCL itself says (ncclCommCount / ncclCommUserRank)
                 gather["ranks"] = {"rccl_comm_count": cnt, "rccl_user_rank_of_rank0": urank, "world_size": world,
                                    "torch_data_group_size": dist.get_world_size(data_group) if data_group is not None else None}
+                if out is not None:
+                    out["rccl_saw_n_ranks"] = bool(cnt == world)
                 leg("value_cabi")
             gather_legs.append(("value_cabi", cabi))
     else:
@@ -532,6 +583,9 @@ def main():
                                 "bytes to the dominant kernel); frac_end_to_end = the same bytes / ms_per_step; per_kernel has every kernel's own algorithmic share. "
                                 "k_step is latency / instruction-issue / divergence-bound, k_obs is the HBM-side kernel, k_regen (background level generation: spare level-1 "
                                 "states and next-level structures, one launch beside every k_step) is scalar-unit-bound." % (hz.algo_bytes, n, dom)},
+            "step_us": step_us,
+            "strong_scaling": strong,   # N > 1: 65 536 envs in TOTAL (65 536 / N per GPU) beside the weak-scaling `value`
+            "rccl_saw_n_ranks": None if world == 1 else False,   # N > 1: set by the C-ABI all-gather leg iff ncclCommCount == WORLD_SIZE
             "workload_rates": {"per": "whole job, per second (rank 0's counters x n_gpus)",
                                **{k + "_per_s": v * world / dt_max for k, v in counts.items()},
                                "per_batch_step": {k: v / K for k, v in counts.items()}},
@@ -584,6 +638,8 @@ def main():
                                    "algo_bytes_per_env_step": x.algo_bytes, "achieved_end_to_end_GBps": x.algo_bytes * x.n / (xdt / ksteps) / 1e9,
                                    "frac_end_to_end": x.algo_bytes * x.n / (xdt / ksteps) / 1e9 / HBM_PEAK_GBPS, "per_kernel": pk,
                                    "rates_per_s": {k: v / xdt for k, v in cn.items()}}
+                    if name == "default":
+                        extra[name]["step_us"] = x.step_percentiles(500)
                     x.close()
                     del x
                     if name == "default" and not args.no_cpu_baseline:  # the CPU number beside config 3 too (bounded: ~6 s)

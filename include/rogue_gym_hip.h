@@ -227,6 +227,11 @@ int rg_timing_read(rg_t *h, double ms[4], uint64_t launches[4]);
 /* The same for the first n <= 5 kernels {.., 4: k_regen -- the background generator, stamped on its own low-priority stream}: summed milliseconds and
  * number of SAMPLED launches per kernel, and (launches != NULL) how many launches of the kernel there were in all since the last read / enable. */
 int rg_timing_read_all(rg_t *h, int n, double *ms, uint64_t *sampled, uint64_t *launches);
+/* The individual samples behind those sums, for latency percentiles (bench.py `step_us`): the duration in ms of every sampled launch of `kernel`
+ * (rg_timing_read_all's order) since rg_timing_enable, oldest first, at most `cap` of them, *n = how many.  kernel = -1: one value per STEP -- from the
+ * begin of its k_step to the end of its observation pass (kernel 2), for the steps in which both were sampled (rg_timing_enable(h, 1): all).  Call it
+ * before rg_timing_read / rg_timing_read_all, which reset the samples.  Not for handles with config groups. */
+int rg_timing_read_samples(rg_t *h, int kernel, float *ms, int cap, int *n);
 
 /* GameState::dump_config (python/src/lib.rs:252-254): canonical JSON of env i's effective config. */
 int rg_dump_config(const rg_t *h, int env, char *buf, size_t cap);

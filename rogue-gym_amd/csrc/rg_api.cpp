@@ -255,6 +255,9 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
     if (ok && nr <= RG_OBS_MAX_ROOMS) ok = dev_alloc(h, &S.obs_rec, n * (size_t)RG_OBS_REC_WORDS(nr));
     if (ok && nr <= RG_OVL_MAX && getenv("ROGUE_GYM_HIP_NO_MIRROR_UPDATE") == nullptr)  // (the A side: every Redraw drawn from the tiles by the observation pass)
         ok = dev_alloc(h, &S.ovl, (nr + 1) * n) && hipMemset(S.ovl, 0xff, (nr + 1) * n * 2) == hipSuccess;
+    // the envs' window records (rg_state.h win_rec; zero = invalid).  ROGUE_GYM_HIP_NO_WINDOW_RECORDS: every turn loads its window from the tiles (the A side)
+    if (ok && getenv("ROGUE_GYM_HIP_NO_WINDOW_RECORDS") == nullptr) ok = dev_alloc(h, &S.win_rec, n * RG_WREC_WORDS);
+    S.win_check = RG_DEV_ENV("ROGUE_GYM_HIP_WINREC_CHECK") != nullptr;
     h->spares = auto_reset != 0 && getenv("ROGUE_GYM_HIP_NO_SPARES") == nullptr;
     // which producer refills the consumed spares: one level per LANE (rg_regen_lanes.hip; two spares per env, rg_state.h sp_slots) where it applies,
     // else -- or with ROGUE_GYM_HIP_WAVE_REGEN=1 -- one level per wave (k_regen, one spare per env)
@@ -306,7 +309,7 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
              dev_alloc(h, &P.mon_w0, nr * ns) && dev_alloc(h, &P.mon_hp, nr * ns) && dev_alloc(h, &P.mon_exp, nr * ns) &&
              dev_alloc(h, &P.mon_cnt, ns) && dev_alloc(h, &P.gold_pos, nr * ns) && dev_alloc(h, &P.gold_amt, nr * ns) &&
              dev_alloc(h, &P.edge_a, ne * n) && dev_alloc(h, &P.edge_b, ne * n) && dev_alloc(h, &P.maze_stack, (size_t)maze_cap * n) &&
-             dev_alloc(h, &P.on_stairs, ns);
+             dev_alloc(h, &P.on_stairs, ns) && (!S.win_rec || dev_alloc(h, &P.win_rec, ns * RG_WREC_WORDS));  // (the spares' window records: their own array, never the live one)
         P.prof = nullptr;
         int lo = 0, hi = 0;
         if (ok && (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, RG_DEV_ENV("ROGUE_GYM_HIP_SIDE_HIPRIO") ? hi : lo) != hipSuccess)) {
@@ -1196,6 +1199,19 @@ int rg_timing_read_all(rg_t *h, int n, double *ms, uint64_t *sampled, uint64_t *
     return 0;
 }
 int rg_timing_read(rg_t *h, double ms[4], uint64_t launches[4]) { return rg_timing_read_all(h, 4, ms, launches, nullptr); }
+int rg_timing_read_samples(rg_t *h, int kernel, float *ms, int cap, int *n) {
+    if (!ms || !n || cap < 0 || kernel < -1 || kernel >= RG_TIMED_KERNELS) { h->err = "rg_timing_read_samples: invalid arguments"; return 1; }
+    if (!h->sub.empty()) { h->err = "rg_timing_read_samples: not for a handle with config groups"; return 1; }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->side) { HIPCHK(h, hipStreamSynchronize(h->side)); HIPCHK(h, hipStreamSynchronize(h->side2)); HIPCHK(h, hipStreamSynchronize(h->side3)); }
+    const int ka = kernel < 0 ? 0 : kernel, kb = kernel < 0 ? 2 : kernel;  // (a step: k_step's begin .. the observation pass's end)
+    size_t pairs = (h->ev_used[ka] < h->ev_used[kb] ? h->ev_used[ka] : h->ev_used[kb]) / 2;
+    if (pairs > (size_t)cap) pairs = (size_t)cap;
+    for (size_t i = 0; i < pairs; i++) HIPCHK(h, hipEventElapsedTime(&ms[i], h->ev[ka][2 * i], h->ev[kb][2 * i + 1]));
+    *n = (int)pairs;
+    return 0;
+}
 
 int rg_dump_config(const rg_t *h, int env, char *buf, size_t cap) {
     if (env < 0 || env >= h->S.n) return 1;

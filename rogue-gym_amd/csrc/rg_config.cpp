@@ -145,6 +145,7 @@ std::string finish(RgParsed *p) {
     int mx = -1;
     for (int i = 0; i < c.n_enemies; i++) if (p->presets[i].tile - 'A' > mx) mx = p->presets[i].tile - 'A';
     c.symbols = mx < 0 ? 17 : mx + 17 + 1;
+    rg_config_derive(&c);
     return "";
 }
 

@@ -57,7 +57,15 @@ struct RgConfig {
     int32_t symbols;                              // symbol_max + 1 (core/src/lib.rs:150-155)
     uint32_t max_steps;
     int32_t auto_reset;
+    // derived (rg_config_derive; not part of rg_config_equal's comparison, which sees parsed configs): the assigned-area size width / room_num_x, height /
+    // room_num_y (rooms.rs:192-209) and the correctly rounded reciprocals room_id_of / assigned_area divide by (rg_device.h small_div_inv)
+    int32_t rsx, rsy;
+    float inv_rsx, inv_rsy, inv_rnx;
 };
+static inline void rg_config_derive(RgConfig *c) {
+    c->rsx = c->width / c->room_num_x; c->rsy = c->height / c->room_num_y;
+    c->inv_rsx = 1.0f / (float)c->rsx; c->inv_rsy = 1.0f / (float)c->rsy; c->inv_rnx = 1.0f / (float)c->room_num_x;
+}
 
 struct RgParsed {
     RgConfig cfg;

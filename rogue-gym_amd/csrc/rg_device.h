@@ -43,6 +43,10 @@ __device__ __forceinline__ uint32_t tile_to_sym(uint32_t t) {
 // (v_rcp_f32 instead of the IEEE-rounded reciprocal would also be exact for n < 2^21 and saves ~10 instructions per call: measured neutral,
 // k_build 54.1 vs 54.4 us per level, 524 vs 524 M env-steps/s -- round 3)
 __device__ __forceinline__ int small_div(int n, int d) { return (int)(((float)n + 0.5f) * __frcp_rn((float)d)); }
+// ... with the correctly rounded reciprocal of a CONFIG constant taken from RgConfig (rg_config_derive: 1.0f / d on the host is the same IEEE value): the device has
+// no scalar float unit, so a reciprocal of a wave-uniform divisor is VALU work whose result sits in a VECTOR register -- hoisted to the top of the kernel and
+// held through the whole turn (six registers in k_step_w32, round 5)
+__device__ __forceinline__ int small_div_inv(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
 
 #define POS(x, y) ((uint32_t)(((x) << 8) | (y)))
 #define POS_X(p) ((int)(((p) >> 8) & 0xff))
@@ -56,8 +60,8 @@ __device__ __forceinline__ bool in_bounds(const RgConfig &c, int x, int y) { ret
 
 // Room::assigned_area of room id i (rooms.rs:192-209), half-open
 __device__ __forceinline__ void assigned_area(const RgConfig &c, int i, int &x0, int &y0, int &x1, int &y1) {
-    int rsx = small_div(c.width, c.room_num_x), rsy = small_div(c.height, c.room_num_y);
-    int cy = small_div(i, c.room_num_x), cx = i - cy * c.room_num_x;
+    int rsx = c.rsx, rsy = c.rsy;
+    int cy = small_div_inv(i, c.inv_rnx), cx = i - cy * c.room_num_x;
     x0 = cx * rsx; x1 = x0 + rsx;
     y0 = cy == 0 ? 1 : cy * rsy;
     y1 = (cy + 1) * rsy;
@@ -65,9 +69,9 @@ __device__ __forceinline__ void assigned_area(const RgConfig &c, int i, int &x0,
 }
 // Floor::cd_to_room_id (floor.rs:194-200): areas are disjoint, so arithmetic replaces the scan
 __device__ __forceinline__ int room_id_of(const RgConfig &c, int x, int y) {
-    int rsx = small_div(c.width, c.room_num_x), rsy = small_div(c.height, c.room_num_y);
+    const int rsy = c.rsy;
     if (y < 1 || x < 0) return -1;
-    int cx = small_div(x, rsx), cy = small_div(y, rsy);
+    int cx = small_div_inv(x, c.inv_rsx), cy = small_div_inv(y, c.inv_rsy);
     if (cx >= c.room_num_x || cy >= c.room_num_y) return -1;
     if ((cy + 1) * rsy == c.height && y == c.height - 1) return -1;
     return cy * c.room_num_x + cx;

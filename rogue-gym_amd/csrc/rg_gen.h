@@ -16,6 +16,8 @@ struct Rng { uint32_t x, y, z, w; };
 // compiler keeps the RNG, the loop counters and the decisions on the scalar unit.  A value that comes back from memory is uniform in fact but
 // not provably so; uni() tells the compiler.
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// set bits of a wave mask below this lane (v_mbcnt: two instructions, no (1 << lane) - 1 mask held in two registers)
+__device__ __forceinline__ int lanes_below(uint64_t m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 
 __device__ __forceinline__ void rng_seed(Rng &r, uint64_t lo, uint64_t hi) {

@@ -180,7 +180,7 @@ __device__ __forceinline__ uint64_t rect_ballot(const RgConfig &c, const Env &E,
 // position of the nth (0-based) set bit of a ballot mask (nth < popcount)
 __device__ __forceinline__ int nth_set64(uint64_t m, int nth) {
     const int lane = threadIdx.x;
-    const bool mine = ((m >> lane) & 1ull) && __popcll(m & ((1ull << lane) - 1ull)) == nth;
+    const bool mine = ((m >> lane) & 1ull) && lanes_below(m) == nth;
     return __ffsll((long long)__ballot(mine)) - 1;
 }
 // nth cell (row-major) of the rectangle with one of `bits` set, skipping `excl`; count must have come from the same test
@@ -1016,6 +1016,20 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
             }
             if (GM < 2) break;
         }
+        if (S.win_rec) {
+            // the env's window record (rg_state.h win_rec) for its first key on this level: the 5x5 around the player's placement from the staging grid -- lane k
+            // holds cell k, word m of the record is assembled in lane m.  (The spare view's records are the spares': take_spares moves them with the level.)
+            const int k = lane < 25 ? lane : 0, x = U.px + k % 5 - 2, y = U.py + k / 5 - 2;
+            const bool in = lane < 25 && in_bounds(c, x, y);
+            const uint32_t v = in ? (uint32_t)U.lc[y * c.width + x] : 0u;
+            const uint32_t inb = (uint32_t)__ballot(in);
+            const int m = lane < 13 ? lane : 0;
+            uint32_t word = (uint32_t)__shfl((int)v, 2 * m) | ((uint32_t)__shfl((int)v, 2 * m + 1) << 16);  // (lane 12: cell 24 | cell "25" = 0)
+            if (lane == 12) word |= POS(U.px, U.py) << 16;
+            if (lane == 13) word = inb | RG_WREC_VALID;
+            if (lane > 13) word = 0;
+            if (lane < RG_WREC_WORDS) st_pub<WT>(&S.win_rec[(size_t)real_e * RG_WREC_WORDS + lane], word);
+        }
         {
             uint16_t *dst = S.cell + (size_t)real_e * HW;
             const uint16_t *srcp = reinterpret_cast<const uint16_t *>(slot);
@@ -1085,7 +1099,7 @@ __device__ __forceinline__ void stair_publish(const RgState &S, int lane, int e,
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&S.stair_cnt[(S.stair_gen + 1) % 3], (uint32_t)__popcll(m));
         base = uni(base);
-        if (mine && on) S.stair_list[(size_t)w * S.n + base + __popcll(m & ((1ull << lane) - 1ull))] = e;
+        if (mine && on) S.stair_list[(size_t)w * S.n + base + lanes_below(m)] = e;
     }
 }
 __device__ __forceinline__ void stair_recycle(const RgState &S) {  // one thread of the launch: the counter nobody reads or writes right now
@@ -1760,6 +1774,9 @@ __device__ __forceinline__ bool bfs_service(const RgState &S, const RgConfig &c,
             const uint64_t cb = __ballot(comp);  // (uniform inside a group)
             if (served_by >= 0) my_complete = (cb >> (served_by * rows_pow2)) & 1ull;
         } else bfs_rows<BW - 1, false>(S, c, lds, active, env_s, tx, ty, sl, row);
+#ifdef RG_EXP_BFS_ONE_ROUND
+        break;  // (experiment build only -- wrong pictures: a wave's surplus requests cost it nothing, as if other waves had built them; profiles/r06_experiments.txt)
+#endif
     }
     return my_complete;
 }
@@ -1940,6 +1957,43 @@ __device__ __forceinline__ void win_flush(const RgConfig &c, uint16_t *cell, Win
             if ((w.dirty >> WIN_K(i, j)) & 1u) cell[(w.oy + j) * c.width + w.ox + i] = (uint16_t)WV(w, WIN_K(i, j));
     w.dirty = 0;
 }
+__device__ __forceinline__ int clamp3(int v, int lo, int hi) { return min(max(v, lo), hi); }  // (v_med3_i32)
+// ---- the window travels with the env (rg_state.h win_rec) ----
+// LDS behind the parked overlay words of a step wave: the re-centred window the tail assembles [25][64] u16, the (up to) ten cells that enter it when the
+// player moves one cell -- a column of five and a row of five, fetched by LDS-DMA right after the move -- [10][64] u32
+// LDS of a step wave: every per-lane column FIRST, at compile-time offsets -- window, parked overlay words + glyph bytes, window-record staging, monster
+// cache (its length is the config's) -- so that a column's address is lane * 4 (or * 2) + an immediate of the DS instruction: ONE live register for all of
+// them, where run-time offsets behind the generator's staging area (rounds 2-5) took a VGPR per column from the top of the wave to its tail.  The staging
+// area (generator grid + tables, BFS planes of wide grids) follows at `stage_off`, a kernel argument.
+#define STEP_LDS_WIN 0
+#define STEP_LDS_OVL (STEP_LDS_WIN + WIN_SLOTS * WAVE * 2)
+#define STEP_LDS_WREC (STEP_LDS_OVL + (RG_OVL_MAX + 6) * WAVE * 4 + 64)
+#define STEP_LDS_MC (STEP_LDS_WREC + WREC_LDS_BYTES)
+#define WREC_LDS_NEW 0
+#define WREC_LDS_DMA (WIN_SLOTS * WAVE * 2)
+#define WREC_LDS_BYTES (WREC_LDS_DMA + 10 * WAVE * 4)
+#define WREC_COL_HI 0x1084210u  // window cells of column i = +2 (k % 5 == 4), ... i = -2, row j = +2 (k >= 20), row j = -2
+#define WREC_COL_LO 0x0108421u
+#define WREC_ROW_HI 0x1f00000u
+#define WREC_ROW_LO 0x000001fu
+// the window from the env's record: 13 words in registers -> the lane's LDS column; centred on the player (the record's validity test, step_wave)
+__device__ __forceinline__ void win_from_rec(Win &w, const uint4 &q0, const uint4 &q1, const uint4 &q2, const uint4 &q3, int px, int py) {
+    w.ox = px; w.oy = py; w.dirty = 0;
+    const uint32_t q[13] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x};
+#pragma unroll
+    for (int k = 0; k < 25; k++) WSET(w, k, (k & 1) ? q[k >> 1] >> 16 : q[k >> 1] & 0xffffu);
+    const uint32_t inb = q3.y & 0x1ffffffu;
+    bool st = false;
+#pragma unroll
+    for (int j = -RG_NX_NEAR; j <= RG_NX_NEAR; j++)
+#pragma unroll
+        for (int i = -RG_NX_NEAR; i <= RG_NX_NEAR; i++) {
+            const int k = WIN_K(i, j);
+            const uint32_t val = (k & 1) ? q[k >> 1] >> 16 : q[k >> 1] & 0xffffu;
+            st = st || (((inb >> k) & 1u) && (val & C_SURF_MASK) == S_STAIR);
+        }
+    w.inb = (w.inb & WIN_STAIR) | inb | (st ? WIN_STAIR : 0u);
+}
 __device__ __forceinline__ uint32_t win_get(const Win &w, int k) { return WV(w, k); }  // run-time index
 __device__ __forceinline__ void win_set(Win &w, int k, uint32_t val) {
     WSET(w, k, val);
@@ -1976,7 +2030,10 @@ struct FillReq { uint32_t leave, enter; };  // packed half-open rects, 0 = none:
 
 // actions::move_player + get_item (actions.rs:168-231).  Returns `done` (true = a MoveUntil run stops here).
 // The window is centred on the player's position before the move.
-__device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c, Env &E, Win &w, int d, uint32_t &react, FillReq &fr) {
+// rooms_l: the lane's column of the wave's parked words (step_wave) when rect and meta of the room of the cell the key starts on ([RG_OVL_MAX + 2 / + 3]) and of
+// the cell it points at ([+ 4 / + 5]) were fetched into LDS with the first round of loads -- for the mirror update -- and this is the key's first turn: the two
+// door branches then read them there instead of paying a memory round trip each (divergent branches: the wave runs them one after the other).  Else nullptr.
+__device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c, Env &E, Win &w, int d, uint32_t &react, FillReq &fr, const lds_u32 *rooms_l) {
     const int nrooms = c.room_num_x * c.room_num_y, n = E.n, e = E.e;
     const int dx = dir_dx(d), dy = dir_dy(d);
     // The lanes of a wave take different branches here -- an attack (monster hp / exp), a step through a door (room meta + rect of the room left
@@ -1997,7 +2054,8 @@ __device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c,
     const int rid_o = (WV(w, WIN_K(0, 0)) & C_DOOR) ? room_id_of(c, E.px, E.py) : -1;   // Floor::leaves_room's room
     // ---- Floor::player_out at the old cell (field-of-view, floor.rs:201-312) ----
     if (rid_o >= 0) {  // Floor::leaves_room (floor.rs:249-261)
-        const uint32_t meta_o = S.room_meta[rid_o * n + e], rect_o = S.room_rect[rid_o * n + e];
+        const uint32_t meta_o = rooms_l ? rooms_l[(RG_OVL_MAX + 3) * WAVE] & 0xffu : (uint32_t)S.room_meta[rid_o * n + e];
+        const uint32_t rect_o = rooms_l ? rooms_l[(RG_OVL_MAX + 2) * WAVE] : S.room_rect[rid_o * n + e];
         if ((meta_o & RM_VISITED) && (meta_o & RM_DARK)) {
             int x0, y0, x1, y1;
             if ((meta_o & RM_KIND_MASK) == RK_EMPTY) assigned_area(c, rid_o, x0, y0, x1, y1);
@@ -2023,7 +2081,8 @@ __device__ __forceinline__ bool move_player(const RgState &S, const RgConfig &c,
     if (here & C_DOOR) {
         const int rid_n = room_id_of(c, nx, ny);
         if (rid_n >= 0) {
-            const uint32_t meta_n = S.room_meta[rid_n * n + e], rect_n = S.room_rect[rid_n * n + e];
+            const uint32_t meta_n = rooms_l ? rooms_l[(RG_OVL_MAX + 5) * WAVE] & 0xffu : (uint32_t)S.room_meta[rid_n * n + e];
+            const uint32_t rect_n = rooms_l ? rooms_l[(RG_OVL_MAX + 4) * WAVE] : S.room_rect[rid_n * n + e];
             if (!(meta_n & RM_VISITED)) {  // Floor::enters_room (floor.rs:231-247)
                 S.room_meta[rid_n * n + e] = (uint8_t)(meta_n | RM_VISITED);
                 if ((meta_n & RM_KIND_MASK) == RK_NORMAL && !(meta_n & RM_DARK)) {
@@ -2327,7 +2386,7 @@ __device__ __forceinline__ uint32_t base_glyph(const RgConfig &c, uint32_t v, in
 #define OVL_NONE 0xffffu
 // Returns false -- nothing written -- when a cell it would have to write lies outside the window: its tile is not at hand, and a load here would wait for every
 // store of the turn; the Redraw then goes to the observation pass as before.
-__device__ __forceinline__ bool mirror_update(const RgState &S, const RgConfig &c, const Env &E, const Win &w, int mc_offset, uint32_t react, int rid0) {
+__device__ __forceinline__ bool mirror_update(const RgState &S, const RgConfig &c, const Env &E, const Win &w, uint32_t react, int rid0) {
     const int W = c.width, nrooms = c.room_num_x * c.room_num_y, n = E.n;
     // (the env index through an opaque move: the addresses below are then computed HERE -- left alone, the compiler computes `S.ovl + ... + e`, `S.hist + e * hw`
     // at the top of the kernel, spills them, and reloads them here one by one, each reload waiting for every store the turn has issued: 5 us per wave)
@@ -2337,8 +2396,8 @@ __device__ __forceinline__ bool mirror_update(const RgState &S, const RgConfig &
     // (the lane's LDS columns from the lane id, here: a pointer carried from the top of the wave is one more spilled register to reload)
     int ln = threadIdx.x;
     asm volatile("" : "+v"(ln));
-    const lds_u32 *mc = (const lds_u32 *)(g_smem + mc_offset) + ln;
-    const lds_u32 *ovl_l = (const lds_u32 *)(g_smem + mc_offset + nrooms * WAVE * 4 + WIN_SLOTS * WAVE * 2) + ln;
+    const lds_u32 *mc = (const lds_u32 *)(g_smem + STEP_LDS_MC) + ln;
+    const lds_u32 *ovl_l = (const lds_u32 *)(g_smem + STEP_LDS_OVL) + ln;
     const uint32_t ds = ovl_l[0] & 0x1ffffffu;
     const int px = E.px, py = E.py, rid = room_id_of(c, px, py);
     auto in_win = [&](int x, int y) { const int i = x - w.ox, j = y - w.oy; return i >= -2 && i <= 2 && j >= -2 && j <= 2; };
@@ -2422,6 +2481,66 @@ __device__ __forceinline__ bool mirror_update(const RgState &S, const RgConfig &
     return true;
 }
 
+// The env's window record for its next key (rg_state.h win_rec), written by the turn itself (step_wave, first iteration of the turn loop, right behind the
+// player's action: the monsters move no tile).  keep = false: the key is a run -- the record is marked invalid and the next turn loads its window from the
+// tiles.  The player stands within one cell of the window's centre: the new window is the old one shifted by that step -- LDS to LDS, this lane's column --
+// plus the column / row that entered, fetched mid-turn (step_wave) and corrected for the move's whole-room fills (leaves_room clears VISIBLE in its
+// rectangle, then enters_room sets DRAWN | VISIBLE in its: set / clear, the same result whether the fetch saw the fill or not).  Loops over LDS, no register arrays.
+__device__ __forceinline__ void win_rec_store(const RgState &S, const RgConfig &c, const Env &E, const Win &w, const FillReq &fr, bool keep, bool current) {
+    uint32_t *rec = S.win_rec + (size_t)E.e * RG_WREC_WORDS;
+    if (!keep) { rec[13] = 0; return; }
+    const int px = E.px, py = E.py, dxm = px - w.ox, dym = py - w.oy, sh = dxm + 5 * dym;
+    if (current && sh == 0 && w.dirty == 0) return;  // the record in memory is this window already
+    const int ln = threadIdx.x;
+    uint8_t *wr = g_smem + STEP_LDS_WREC;
+    lds_u16 *nw = (lds_u16 *)(wr + WREC_LDS_NEW) + ln;
+    const lds_u32 *dma = (const lds_u32 *)(wr + WREC_LDS_DMA) + ln;
+    // new cell k = old cell k + sh wherever that lies inside the old window
+    const uint32_t inside = 0x1ffffffu & ~(dxm > 0 ? WREC_COL_HI : (dxm < 0 ? WREC_COL_LO : 0u)) & ~(dym > 0 ? WREC_ROW_HI : (dym < 0 ? WREC_ROW_LO : 0u));
+    const uint32_t old_inb = w.inb & 0x1ffffffu;
+    uint32_t inb = (sh >= 0 ? old_inb >> sh : old_inb << -sh) & inside;
+    const lds_u16 *src = w.v + sh * WAVE;
+#pragma unroll
+    for (int k = 0; k < 25; k++) nw[k * WAVE] = ((inside >> k) & 1u) ? src[k * WAVE] : (uint16_t)0;
+    if (sh != 0) {  // the cells that entered: in-grid bit and value
+#pragma unroll
+        for (int t = 0; t < 10; t++) {
+            const bool col = t < 5;
+            if (col ? dxm != 0 : dym != 0) {
+                const int i = col ? 2 * dxm : t - 5 - 2, j = col ? t - 2 : 2 * dym;
+                const int x = px + i, y = py + j;
+                if (in_bounds(c, x, y)) {
+                    nw[WIN_K(i, j) * WAVE] = (uint16_t)dma[t * WAVE];
+                    inb |= 1u << WIN_K(i, j);
+                }
+            }
+        }
+        if (fr.leave | fr.enter) {  // (rare: a door was passed) the move's whole-room fills on the cells that entered
+            int lx0, ly0, lx1, ly1, ex0, ey0, ex1, ey1;
+            unpack_rect(fr.leave, lx0, ly0, lx1, ly1);
+            unpack_rect(fr.enter, ex0, ey0, ex1, ey1);
+#pragma nounroll
+            for (int k = 0; k < 25; k++) {
+                if (((inside | ~inb) >> k) & 1u) continue;
+                const int x = px + k % 5 - 2, y = py + k / 5 - 2;
+                uint32_t v = nw[k * WAVE];
+                if (x >= lx0 && x < lx1 && y >= ly0 && y < ly1) v &= ~C_VISIBLE;
+                if (x >= ex0 && x < ex1 && y >= ey0 && y < ey1) v |= C_DRAWN | C_VISIBLE;
+                nw[k * WAVE] = (uint16_t)v;
+            }
+        }
+    }
+    uint4 *r4 = reinterpret_cast<uint4 *>(rec);
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        uint32_t q[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) q[m] = (uint32_t)nw[(8 * g + 2 * m) * WAVE] | ((uint32_t)nw[(8 * g + 2 * m + 1) * WAVE] << 16);
+        r4[g] = make_uint4(q[0], q[1], q[2], q[3]);
+    }
+    r4[3] = make_uint4((uint32_t)nw[24 * WAVE] | (POS(px, py) << 16), inb | RG_WREC_VALID, 0u, 0u);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_step: one key for every env
 // ---------------------------------------------------------------------------------------------
@@ -2494,6 +2613,12 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
         const int32_t hp = SP.p_hp[es], hpm = SP.p_hpmax[es], lv = SP.p_lvl[es];
         const uint32_t ex = SP.p_exp[es], fd = SP.food[es], qu = SP.quiet[es], pg = SP.pack_gold[es], dl = SP.dlevel[es], mc = SP.mon_cnt[es];
         on_stairs = SP.on_stairs[es] != 0;
+        if (S.win_rec) {  // the spare's window record (written with the spare: gen_service / k_regen_lanes)
+            const uint4 *sr = reinterpret_cast<const uint4 *>(SP.win_rec + (size_t)es * RG_WREC_WORDS);
+            uint4 *dr = reinterpret_cast<uint4 *>(S.win_rec + (size_t)e * RG_WREC_WORDS);
+            const uint4 a0 = sr[0], a1 = sr[1], a2 = sr[2], a3 = sr[3];
+            dr[0] = a0; dr[1] = a1; dr[2] = a2; dr[3] = a3;
+        }
 #pragma unroll
         for (int k = 0; k < 12; k++) S.rng[k * n + e] = r[k];
         S.p_pos[e] = pp; S.p_hp[e] = hp; S.p_hpmax[e] = hpm; S.p_lvl[e] = lv;
@@ -2532,10 +2657,10 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
 // One wave's share of a step: lane i plays the key of env `e` (any env index -- the lanes of a wave need not hold consecutive envs), `valid`
 // lanes only; the other lanes still take part in the wave-cooperative services.
 template <int BW, int GM>
-__device__ __forceinline__ void step_wave(const RgState &S, const RgState *__restrict__ SPd, const RgConfig &c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset,
+__device__ __forceinline__ void step_wave(const RgState &S, const RgState *__restrict__ SPd, const RgConfig &c, const uint8_t *__restrict__ keys, int use_spares, int stage_off,
                                           const int e, const bool valid_in, const int stair_role) {
     // stair_role: 0 = no stair isolation, 1 = this wave serves listed (on-stairs) envs, 2 = index-order wave: listed envs are somebody else's
-    uint16_t *lds_grid = reinterpret_cast<uint16_t *>(g_smem);
+    uint16_t *lds_grid = reinterpret_cast<uint16_t *>(g_smem + stage_off);  // (behind the per-lane columns: STEP_LDS_*)
     const int lane = threadIdx.x;
     Prof pf; pf.start(S.prof);
     Env E;
@@ -2552,9 +2677,14 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     bool listed = false;  // the env is in the stair set this launch reads (its player stands on the stairs)
     // LDS monster cache: column `lane` of [nrooms][64] words behind the generation / BFS staging area
     const int nrooms_k = c.room_num_x * c.room_num_y;
-    E.mc = (lds_u32 *)(g_smem + mc_offset) + lane;
+    E.mc = (lds_u32 *)(g_smem + STEP_LDS_MC) + lane;
     const uint32_t glyph_r = S.ovl ? c.mon[lane & 31].tile : 0u;  // (the monster glyphs by type, for the wave's LDS table: requested with the first round of loads)
+    uint4 wq0 = make_uint4(0, 0, 0, 0), wq1 = wq0, wq2 = wq0, wq3 = wq0;  // the env's window record (rg_state.h win_rec)
     if (valid_in) {
+        if (S.win_rec) {  // ... requested first: one line per env, with the scalars -- not behind them like the window's 25 scattered cells
+            const uint4 *rp = reinterpret_cast<const uint4 *>(S.win_rec + (size_t)e * RG_WREC_WORDS);
+            wq0 = rp[0]; wq1 = rp[1]; wq2 = rp[2]; wq3 = rp[3];
+        }
         // ONE round of independent loads: the step's inputs, the env's scalars and its monster words together.  (Whether the lane plays at all is
         // only known from the first few -- loading the env behind that decision was a second dependent round trip in every wave; a lane that turns
         // out to be somebody else's (stair_role 2), dead or past max_steps just drops what it loaded.)
@@ -2607,20 +2737,20 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     pf.mark(0);
     bool need_gen = false, descends = false;
     Win w;  // the 5x5 tiles around the player: one round of loads serves the whole player action
-    w.v = (lds_u16 *)(g_smem + mc_offset + nrooms_k * WAVE * 4) + lane;
+    w.v = (lds_u16 *)(g_smem + STEP_LDS_WIN) + lane;
     // [0]: the dirty mask of the turn's window write-back (bit 31: a whole-room fill happened), [1 .. RG_OVL_MAX + 1]: where overlays stood at the env's last
     // Redraw (S.ovl) -- parked here from the first load round to the incremental mirror update at the end of the turn
-    lds_u32 *ovl_l = (lds_u32 *)(g_smem + mc_offset + nrooms_k * WAVE * 4 + WIN_SLOTS * WAVE * 2) + lane;
+    lds_u32 *ovl_l = (lds_u32 *)(g_smem + STEP_LDS_OVL) + lane;
     ovl_l[0] = 0;
     if (S.ovl && lane < RG_MAX_ENEMY_KINDS + 6)
-        ((__attribute__((address_space(3))) uint8_t *)(g_smem + mc_offset + nrooms_k * WAVE * 4 + WIN_SLOTS * WAVE * 2 + (RG_OVL_MAX + 6) * WAVE * 4))[lane] = (uint8_t)glyph_r;
+        ((__attribute__((address_space(3))) uint8_t *)(g_smem + STEP_LDS_OVL + (RG_OVL_MAX + 6) * WAVE * 4))[lane] = (uint8_t)glyph_r;
     if (S.ovl) {
         // where the overlays of the env's screen mirror stand, straight into LDS (global_load_lds: no register, no wait -- they are read at the end of the
         // turn).  Unconditional for every lane and slot (an idle lane reads env 0's): LDS-DMA calls under divergent control flow are what the compiler
         // merges into one instruction with a per-lane M0 (profiles/r05_experiments.txt).
         typedef const __attribute__((address_space(1))) void *gptr;
         typedef __attribute__((address_space(3))) void *lptr;
-        lds_u32 *base = (lds_u32 *)(g_smem + mc_offset + nrooms_k * WAVE * 4 + WIN_SLOTS * WAVE * 2);
+        lds_u32 *base = (lds_u32 *)(g_smem + STEP_LDS_OVL);
         const size_t es = valid_in ? (size_t)e : 0;
 #pragma unroll
         for (int s0 = 0; s0 <= RG_OVL_MAX; s0++)
@@ -2634,7 +2764,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         // end of the turn: a load there waits for every store the turn has issued (vmcnt is in order): measured 6 us per wave.
         typedef const __attribute__((address_space(1))) void *gptr;
         typedef __attribute__((address_space(3))) void *lptr;
-        lds_u32 *base = (lds_u32 *)(g_smem + mc_offset + nrooms_k * WAVE * 4 + WIN_SLOTS * WAVE * 2);
+        lds_u32 *base = (lds_u32 *)(g_smem + STEP_LDS_OVL);
         const size_t es = valid_in ? (size_t)e : 0;
         const bool mv = live && (act == ACT_MOVE || act == ACT_MOVE_UNTIL);
         const int ra = room_id_of(c, E.px, E.py), rb = mv ? room_id_of(c, E.px + dir_dx(dir), E.py + dir_dy(dir)) : ra;
@@ -2644,8 +2774,23 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         __builtin_amdgcn_global_load_lds((gptr)(S.room_rect + ab), (lptr)(base + (RG_OVL_MAX + 4) * WAVE), 4, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr)(S.room_meta + ab), (lptr)(base + (RG_OVL_MAX + 5) * WAVE), 1, 0, 0);
     }
-    if (live && stair_role != 1) win_load(c, E.cell, w, E.px, E.py);
+    // The window: from the env's record when it is current (flag set, centred on the player) -- it came with the scalars -- else from the tiles, one more
+    // dependent round of loads (the first turn after a new level, a reset, a run; ROGUE_GYM_HIP_NO_WINDOW_RECORDS: always)
+    const bool has_win = live && stair_role != 1;
+    const bool rec_ok = has_win && (wq3.y & RG_WREC_VALID) && (wq3.x >> 16) == POS(E.px, E.py);
+    if (rec_ok) win_from_rec(w, wq0, wq1, wq2, wq3, E.px, E.py);
+    else if (has_win) win_load(c, E.cell, w, E.px, E.py);
     else { w.inb = 0; w.dirty = 0; w.ox = w.oy = 0; }
+#ifdef RG_DEV_KNOBS
+    if (S.win_check && rec_ok) {  // development library: a record that is used must be what win_load would have fetched
+        for (int k = 0; k < 25; k++) {
+            const int x = E.px + k % 5 - 2, y = E.py + k / 5 - 2;
+            const bool in = in_bounds(c, x, y);
+            const uint32_t val = in ? (uint32_t)E.cell[y * c.width + x] : 0u;
+            if (val != WV(w, k) || in != (((w.inb >> k) & 1u) != 0)) E.err |= RG_FLAG_ERR_INTERNAL;
+        }
+    }
+#endif
     pf.mark(26);
     if (live && act == ACT_DOWNSTAIR) {
         if (stair_role == 1 || (WV(w, WIN_K(0, 0)) & C_SURF_MASK) == S_STAIR) {
@@ -2714,7 +2859,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
                     break;
                 case ACT_MOVE:
                 case ACT_MOVE_UNTIL: {
-                    bool done = move_player(S, c, E, w, dir, react, fr);
+                    bool done = move_player(S, c, E, w, dir, react, fr, (S.ovl && iter == 0) ? (const lds_u32 *)ovl_l : nullptr);
                     if (act == ACT_MOVE) { do_turn = true; running = false; break; }
                     uint32_t v = win_get(w, WIN_K(E.px - w.ox, E.py - w.oy));
                     uint32_t tile = (v & C_VISIBLE) ? glyph_of(v) : ' ';
@@ -2729,6 +2874,26 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
                 }
             }
             if constexpr (BW == 1 || BW == 2) { if (__any(opened) && S.dc_walk) snapshot_walk_service(S, c, lane, e, opened); }
+            if (S.win_rec && iter == 0) {  // (a lane's own turn is the loop's first iteration; a run -- the later ones -- leaves no record)
+                // The window of the NEXT key is this one moved by the player's step: the column and / or row of five cells that enter it are requested now,
+                // straight into LDS (no register), and consumed a few microseconds on, behind the monsters' prepass (win_rec_store).  Nothing in this turn
+                // writes them except a whole-room fill, applied to them there.  Unconditional for every lane, clamped into the grid -- an idle lane fetches
+                // cell 0 of its env -- LDS-DMA under divergent control flow is what the compiler merges into one instruction with a per-lane M0.
+                typedef const __attribute__((address_space(1))) void *gptr;
+                typedef __attribute__((address_space(3))) void *lptr;
+                lds_u32 *dma = (lds_u32 *)(g_smem + STEP_LDS_WREC + WREC_LDS_DMA);
+                const int W1 = c.width - 1, H1 = c.height - 1;
+                const int cx = has_win ? E.px : 0, cy = has_win ? E.py : 0;
+                const int xc = clamp3(has_win ? 3 * E.px - 2 * w.ox : 0, 0, W1);            // column px + 2 (px - ox), clamped
+                const int yr = clamp3(has_win ? 3 * E.py - 2 * w.oy : 0, 0, H1) * c.width;  // row py + 2 (py - oy)
+                const uint16_t *gc = S.cell + (size_t)(valid_in ? e : 0) * S.hw;
+#pragma unroll
+                for (int t = 0; t < 5; t++)
+                    __builtin_amdgcn_global_load_lds((gptr)(gc + (clamp3(cy + t - 2, 0, H1) * c.width + xc)), (lptr)(dma + t * WAVE), 2, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 5; t++)
+                    __builtin_amdgcn_global_load_lds((gptr)(gc + (yr + clamp3(cx + t - 2, 0, W1))), (lptr)(dma + (5 + t) * WAVE), 2, 0, 0);
+            }
             pf.mark(28);
             if (do_turn) turn_passed(c, E, react);  // actions::after_turn (actions.rs:67-80)
             pf.mark(29);
@@ -2749,6 +2914,10 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
                 }
             }
             pf.mark(3);
+            // The env's window record for its next key: HERE -- the player's action is over, the cells fetched above have landed behind the prepass's own waits
+            // (at the tail of the wave their LDS reads waited for every store of the turn: vmcnt is in order, +3.9 us per wave) -- and before the window
+            // write-back clears the dirty mask.  A lane that dies later in this turn gets its new level's record from take_spares / gen_service.
+            if (S.win_rec && iter == 0 && has_win && !descends) win_rec_store(S, c, E, w, fr, act != ACT_MOVE_UNTIL, rec_ok);
             // whole-room reveals / hides by the wave, then the lanes' changed window cells (the final word on those cells); both before any
             // monster or BFS read of the grid
             // (for the incremental mirror update.  A lane's own turn is the loop's FIRST iteration unless it runs (MoveUntil); the later iterations -- driven by some
@@ -2757,6 +2926,9 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             fill_service(S, c, lane, e, fr);
             win_flush(c, E.cell, w);
             pf.mark(27);
+#ifdef RG_EXP_NO_BFS
+            need_bfs = false;  // (experiment build only -- wrong pictures: what the launch would cost with every dist map built elsewhere; profiles/r06_experiments.txt)
+#endif
             uint64_t m = __ballot(need_bfs);
             if (need_bfs) n_bfs++;
             if (m) {  // serve the requesting lanes with the whole wave, several maps per round
@@ -2801,12 +2973,18 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             // (one turn per key = every action but a run: a per-LANE property -- one running lane in the wave no longer sends the other 63 to the tile-drawn Redraw)
             if (S.ovl && (react & R_REDRAW) && !descends && !need_gen && act != ACT_MOVE_UNTIL &&
                 !(old_flags & (RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | RG_FLAG_HIST_DIRTY)) && !(ovl_l[0] >> 31)) {
-                if (mirror_update(S, c, E, w, mc_offset, react, room_id_of(c, w.ox, w.oy))) flags &= ~(RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY);
+                if (mirror_update(S, c, E, w, react, room_id_of(c, w.ox, w.oy))) flags &= ~(RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY);
                 inc_done = true;  // (the overlays' positions and how they show are recorded either way)
             }
         }
     }
     pf.mark(6);
+    // The tail addresses everything from an OPAQUE copy of the env index: the load round at the top of the wave and the stores down here use the same
+    // `field + e` addresses, and the compiler otherwise keeps those 64-bit per-lane addresses (two registers each, a dozen of them) alive through the whole
+    // turn -- i.e. spills them, and a spill's reload down here is a LOAD that waits for every store of the turn.  Recomputed in place: two VALU ops each.
+    int et = e;
+    asm volatile("" : "+v"(et));
+    E.e = et;
     if (S.stats) {
         // per-BLOCK rows (one atomicAdd per wave and counter on a SHARED 64-byte line -- 7 000 same-line atomics per launch -- cost the kernel 20 us,
         // measured in round 2).  On the block's own line a no-return atomic is a fire-and-forget add; the plain `+=` of rounds 2-3 was a load the
@@ -2815,37 +2993,39 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
                                  wave_sum(n_bfs), wave_sum(n_inline), wave_sum(n_taken), (uint32_t)__popcll(__ballot(live && (react & R_REDRAW))),
                                  (uint32_t)__popcll(__ballot(live)), (BW == 1 || BW == 2) ? wave_sum(n_cont) : 0u};
         const uint32_t n_nx = (uint32_t)__popcll(__ballot(descends && nxs == RG_NX_HIT));  // [8]: descents that loaded their next-level structure
-        if (lane < RG_STAT_COLS) {
-            uint32_t mine = lane == 8 ? n_nx : 0u;
+        int ln = threadIdx.x;
+        asm volatile("" : "+v"(ln));  // (the counter's address from an opaque lane id: computed at the top of the kernel it was spilled, and its reload here waited for every store of the turn)
+        if (ln < RG_STAT_COLS) {
+            uint32_t mine = ln == 8 ? n_nx : 0u;
 #pragma unroll
-            for (int k = 0; k < 8; k++) mine = lane == k ? cnt[k] : mine;
-            if (mine) atomicAdd(&S.stats[(size_t)blockIdx.x * RG_STAT_COLS + lane], (unsigned long long)mine);  // (no return value: nothing waits for it)
+            for (int k = 0; k < 8; k++) mine = ln == k ? cnt[k] : mine;
+            if (mine) atomicAdd(&S.stats[(size_t)blockIdx.x * RG_STAT_COLS + ln], (unsigned long long)mine);  // (no return value: nothing waits for it)
         }
     }
     if (valid && err) {
-        S.flags[e] = (old_flags & ~RG_FLAG_ERR_MASK) | err;
-        S.reward[e] = 0.f;
-        S.done[e] = (old_flags & RG_FLAG_TERMINAL) ? 1 : 0;
+        S.flags[et] = (old_flags & ~RG_FLAG_ERR_MASK) | err;
+        S.reward[et] = 0.f;
+        S.done[et] = (old_flags & RG_FLAG_TERMINAL) ? 1 : 0;
         atomicOr(S.err_any, err);
     } else if (valid && !live) {  // steps > max_steps / no key for this env: silent no-op
-        S.reward[e] = 0.f; S.done[e] = (old_flags & RG_FLAG_TERMINAL) ? 1 : 0;
+        S.reward[et] = 0.f; S.done[et] = (old_flags & RG_FLAG_TERMINAL) ? 1 : 0;
     } else if (valid) {
         if (terminal && c.auto_reset) {
             if (taken) {  // the status of a freshly built RunTime (GameConfig::build: level 1, Player::new + init_items, core/src/lib.rs:193-228)
                 E.dlevel = 1; E.gold = c.init_gold; E.hp = E.hpmax = c.init_hp; E.plvl = 1; E.exp = 0; E.food = c.hunger_time;
             }
             write_status(S, c, E);
-            S.dc_len[e] = 0; S.dc_head[e] = 0; S.dc_part[e] = 0; S.dc_own[e] = 0;  // a rebuilt RunTime owns a fresh DistCache
+            S.dc_len[et] = 0; S.dc_head[et] = 0; S.dc_part[et] = 0; S.dc_own[et] = 0;  // a rebuilt RunTime owns a fresh DistCache
             steps = 0;
             flags = RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY;
-            klog_new_episode(S, e);
+            klog_new_episode(S, et);
         }
         if (E.err) { flags |= E.err; atomicOr(S.err_any, E.err); }
         if (terminal) flags |= RG_FLAG_TERMINAL;
         if (!taken) store_env(S, E);  // (a taken env's live scalars are the spare's: copied below)
-        S.steps[e] = steps;
-        S.flags[e] = flags;
-        S.done[e] = terminal ? 1 : 0;
+        S.steps[et] = steps;
+        S.flags[et] = flags;
+        S.done[et] = terminal ? 1 : 0;
         // The env's observation record (rg_state.h obs_rec; rg_obs.hip ObsTabs): the fused observation pass overlays a Redraw from these words -- one line
         // per env instead of the env's column of the [slot][env] tables.  Here: the monsters as they stand after their turn (the wave's LDS table) and the
         // player; the room half is written with the level's tables (gen_service, take_spares -- which also writes a taken env's monsters and player).
@@ -2853,12 +3033,12 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             // a Redraw the observation / render pass draws from the tiles: where the overlays stand as of it; how they show is not known here (OVL_UNKNOWN)
             for (int s0 = 0; s0 < nrooms_k; s0++) {
                 const uint32_t mw = E.mc[s0 * WAVE];
-                S.ovl[(size_t)s0 * S.n + e] = (uint16_t)(((mw >> 24) & MF_ALIVE) ? ((mw & 0xffffu) | OVL_UNKNOWN) : OVL_NONE);
+                S.ovl[(size_t)s0 * S.n + et] = (uint16_t)(((mw >> 24) & MF_ALIVE) ? ((mw & 0xffffu) | OVL_UNKNOWN) : OVL_NONE);
             }
-            S.ovl[(size_t)nrooms_k * S.n + e] = (uint16_t)(POS(E.px, E.py) | OVL_UNKNOWN);
+            S.ovl[(size_t)nrooms_k * S.n + et] = (uint16_t)(POS(E.px, E.py) | OVL_UNKNOWN);
         }
         if (S.obs_rec && (flags & RG_FLAG_REDRAW) && !taken) {
-            uint32_t *rec = S.obs_rec + (size_t)e * RG_OBS_REC_WORDS(nrooms_k);
+            uint32_t *rec = S.obs_rec + (size_t)et * RG_OBS_REC_WORDS(nrooms_k);
             for (int s0 = 0; s0 < nrooms_k; s0 += 4) {
                 uint32_t m4[4];
 #pragma unroll
@@ -2878,12 +3058,12 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         // The reported level is the status mirror's, which follows E.dlevel (a descent is a status reaction; a reset rewrites it with level 1): it rises in
         // exactly the steps that descend and do not end in an auto-reset -- both known in registers, no level array, no extra pass.
         const float bonus = (descends && !(terminal && c.auto_reset)) ? S.stair_reward : 0.f;
-        S.reward[e] = (float)(gold_after - gold_before > 0 ? gold_after - gold_before : 0) + bonus;
+        S.reward[et] = (float)(gold_after - gold_before > 0 ? gold_after - gold_before : 0) + bonus;
     }
     // the stair set for the NEXT k_step: where does this env's player stand now?  A level generated in this turn reported it (place_player), a taken
     // spare carries it, otherwise it is the tile under the player in the window (centred on where the last move started; the player is within one cell)
     bool on_next = false;
-    if (valid && !live) on_next = S.stair_mark[(size_t)(S.stair_gen & 1) * S.n + e] != 0;  // (an env that did not play stands where it stood: its byte again, not a register held through the turn)
+    if (valid && !live) on_next = S.stair_mark[(size_t)(S.stair_gen & 1) * S.n + et] != 0;  // (an env that did not play stands where it stood: its byte again, not a register held through the turn)
     if (live) on_next = ((descends || (terminal && c.auto_reset && !taken)) ? E.on_stairs != 0
                                                                               : (win_get(w, WIN_K(E.px - w.ox, E.py - w.oy)) & C_SURF_MASK) == S_STAIR);
     if (S.nx_state) {
@@ -2896,21 +3076,21 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         // write these words at the same time.
         const bool fresh = live && (descends || (terminal && c.auto_reset));
         const bool ask = live && !fresh && (w.inb & WIN_STAIR) && (nxs == RG_NX_NONE || nxs == RG_NX_STALE);
-        if (fresh && nxs != RG_NX_NONE) (void)__hip_atomic_fetch_and(&S.nx_state[e], RG_NX_DROP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // CLAIMED -> DROP, else -> NONE
+        if (fresh && nxs != RG_NX_NONE) (void)__hip_atomic_fetch_and(&S.nx_state[et], RG_NX_DROP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // CLAIMED -> DROP, else -> NONE
         if (__any(ask)) {
             if (ask) {
-                uint32_t *q = S.nx_rng + e;
+                uint32_t *q = S.nx_rng + et;
                 const size_t n = (size_t)S.n;
                 st_pub<true>(&q[0], E.rd.x); st_pub<true>(&q[n], E.rd.y); st_pub<true>(&q[2 * n], E.rd.z); st_pub<true>(&q[3 * n], E.rd.w);
                 st_pub<true>(&q[8 * n], E.ri.x); st_pub<true>(&q[9 * n], E.ri.y); st_pub<true>(&q[10 * n], E.ri.z); st_pub<true>(&q[11 * n], E.ri.w);
-                st_pub<true>(&S.nx->level[e], E.dlevel);
+                st_pub<true>(&S.nx->level[et], E.dlevel);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (ask) __hip_atomic_store(&S.nx_state[e], RG_NX_ASKED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ask) __hip_atomic_store(&S.nx_state[et], RG_NX_ASKED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    take_spares(S, SPd, c, lane, e, taken, on_next);
-    stair_publish(S, lane, e, valid, on_next);
+    take_spares(S, SPd, c, lane, et, taken, on_next);
+    stair_publish(S, lane, et, valid, on_next);
     pf.mark(7);
     pf.finish();
 }
@@ -2947,7 +3127,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         bool v; int e; \
         if (stair) { e = list[i0]; v = lane == 0 && e < S.n_keys && keys[e] == '>'; } \
         else { v = lane < epw && i0 + lane < items; e = v ? i0 + lane : 0; } \
-        if (!stair || __any(v)) step_wave<BWV, GMV>(S, SPd, c, keys, use_spares, mc_offset, e, v, parity >= 0 ? (stair ? 1 : 2) : 0); \
+        if (!stair || __any(v)) step_wave<BWV, GMV>(S, SPd, c, keys, use_spares, stage_off, e, v, parity >= 0 ? (stair ? 1 : 2) : 0); \
         if (!stair || items <= STAIR_BLOCKS) break; \
         __syncthreads(); \
         uint32_t t = 0; \
@@ -2955,7 +3135,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         i0 = STAIR_BLOCKS + (int)uni(t); \
     }
 template <int BW>
-__global__ void __launch_bounds__(WAVE) k_step(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset, int epw,
+__global__ void __launch_bounds__(WAVE) k_step(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int stage_off, int epw,
                                                int parity) {
     // this block's work: ONE call site of the turn code, whatever the role.  Stair block b looks at entry b of the stair list; entries beyond the first
     // STAIR_BLOCKS are handed out one at a time through a counter, so that a block busy with a descent (60 us) never has a second one queued behind
@@ -2969,12 +3149,12 @@ __global__ void __launch_bounds__(WAVE) k_step(RgState S, const RgState *__restr
 // for the whole launch, as many index-order blocks started only when the first waves ended (33-38 us) and finished last (84 us against 57-67 us
 // for every other wave).  The wider instances spill under the cap (15-136 VGPRs: a measured loss) and keep their natural allocation.
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_step_w32(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset, int epw, int parity) {
+k_step_w32(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int stage_off, int epw, int parity) {
     RG_STEP_BLOCK_BODY(0, 0)
 }
 // More than 64 rooms (only possible on wide grids: 65 rooms need W >= 65): the generic row-width class with the 384-room generator.  Its LDS
 // monster table (a column of `rooms` words per lane) exceeds the 64 KB default, see rgk_step.
-__global__ void __launch_bounds__(WAVE) k_step_huge(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int mc_offset,
+__global__ void __launch_bounds__(WAVE) k_step_huge(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int stage_off,
                                                     int epw, int parity) {
     RG_STEP_BLOCK_BODY(4, 2)
 }
@@ -3011,22 +3191,21 @@ int rgk_step_epw(int n, int slots_per_simd) {
 }
 int rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     int hw = c->width * c->height;
-    size_t smem = GEN_SLOT_BYTES(hw, c->room_num_x * c->room_num_y);  // the generator's staging grid + tables (inline descents, spare misses), shared with ...
+    size_t stage = GEN_SLOT_BYTES(hw, c->room_num_x * c->room_num_y);  // the generator's staging grid + tables (inline descents, spare misses), shared with ...
     const bool n32 = c->width <= 96 && hw <= 4096;  // BFS rows as 32-bit words in registers (bfs_rows_n32): no LDS planes
     const size_t bfs_hi = n32 ? 0 : (size_t)10 * ((c->width + 63) / 64) * WAVE * 8;  // ... the BFS high distance planes
-    if (bfs_hi > smem) smem = bfs_hi;
-    smem = (smem + 15) & ~(size_t)15;
-    int mc_offset = (int)smem;
-    smem += (size_t)c->room_num_x * c->room_num_y * WAVE * 4;  // LDS monster cache
-    smem += WIN_SLOTS * WAVE * 2;                              // ... and the lanes' 5x5 tile windows
-    smem += (RG_OVL_MAX + 6) * WAVE * 4 + 64;                       // ... and the parked overlay positions, dirty mask, the player's room (step_wave: incremental mirror update)
+    if (bfs_hi > stage) stage = bfs_hi;
+    stage = (stage + 15) & ~(size_t)15;
+    // the per-lane columns first (STEP_LDS_*: window, parked overlay words, window-record staging, monster cache), then the staging area
+    const int stage_off = STEP_LDS_MC + c->room_num_x * c->room_num_y * WAVE * 4;
+    const size_t smem = (size_t)stage_off + stage;
     const int epw = rgk_step_epw(S->n, (c->width <= 32 && gen_mode_of(c) == 0) ? 2 : 1);
     // parity >= 0: stair isolation with the list the last render / observation pass wrote into set `parity`
     const int nb = (S->n + epw - 1) / epw;
     const dim3 grid(parity >= 0 ? STAIR_BLOCKS + nb : nb), block(WAVE);
     // (ev0 / ev1: optional events stamped with this dispatch's own begin and end -- rg_timing; ev1 alone: the completion event k_regen's stream waits for)
-#define RG_LAUNCH_STEP(K) do { if (ev0 || ev1) hipExtLaunchKernelGGL(K, grid, block, (uint32_t)smem, st, ev0, ev1, 0, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity); \
-                               else hipLaunchKernelGGL(K, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, mc_offset, epw, parity); } while (0)
+#define RG_LAUNCH_STEP(K) do { if (ev0 || ev1) hipExtLaunchKernelGGL(K, grid, block, (uint32_t)smem, st, ev0, ev1, 0, *S, SP_dev, *c, keys, use_spares, stage_off, epw, parity); \
+                               else hipLaunchKernelGGL(K, grid, block, smem, st, *S, SP_dev, *c, keys, use_spares, stage_off, epw, parity); } while (0)
     if (gen_mode_of(c) == 2) {
         // the LDS monster table of a > 64-room dungeon (256 B per room and wave) goes beyond the 64 KB a kernel gets by default: raise the kernel's limit once
         // (the attribute is per DEVICE: a process may hold handles on several; a failure stays in hipGetLastError, which rg_step_prefix checks right after)

@@ -105,6 +105,11 @@ def test_bench_two_ranks_on_one_device():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 30 and out["value"] > 0
     assert out["config"]["envs_per_gpu"] == 8192 and "allgather" in out and out["allgather"]["value"] > 0, out.get("allgather")
+    # both readings of BASELINE.json's metric in one line: `value` = 8192 envs per GPU here (weak), `strong_scaling` = 65 536 envs in total, split
+    ss = out["strong_scaling"]
+    assert ss["scaling"] == "strong" and ss["envs_total"] == 65536 and ss["envs_per_gpu"] == 32768 and ss["value"] > 0, ss
+    assert out["rccl_saw_n_ranks"] is False   # (the one-device stand-in has no RCCL communicator: the field says so)
+    assert out["step_us"]["step"]["p50"] > 0 and out["step_us"]["step"]["max"] >= out["step_us"]["step"]["p99"] >= out["step_us"]["step"]["p50"], out["step_us"]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_gpus2_one_device.json"), "w") as f:
         f.write(line + "\n")

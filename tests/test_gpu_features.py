@@ -509,8 +509,11 @@ def test_index_order_mapping_without_stair_waves_is_bit_exact(goldens):
     {"ROGUE_GYM_HIP_WAVE_REGEN": "1"},
     {"DEV": "1", "ROGUE_GYM_HIP_LANE_WAVES": "3", "ROGUE_GYM_HIP_LANE_EVERY": "3"},
     {"ROGUE_GYM_HIP_SP_SLOTS": "1"},
+    {"DEV": "1", "ROGUE_GYM_HIP_WINREC_CHECK": "1"},
+    {"ROGUE_GYM_HIP_NO_WINDOW_RECORDS": "1"},
 ], ids=["dev build: round-2/3 generator scheduling", "dev build: sparse generator launches", "24 envs per step wave", "spares one level per wave (k_regen)",
-        "dev build: three level-per-lane waves every third step", "one spare per env"])
+        "dev build: three level-per-lane waves every third step", "one spare per env",
+        "dev build: every window record that is used is compared with the tiles", "no window records"])
 def test_results_do_not_depend_on_where_the_background_generator_runs(knobs):
     """When and where the spare levels are regenerated (behind which kernel, how often, at which priority, how many envs per generator wave) and how many
     envs a step wave holds decide only whether an auto-reset finds its spare or generates inline -- never what the env looks like afterwards: the

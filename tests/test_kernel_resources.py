@@ -54,7 +54,11 @@ def test_register_and_scratch_budget_of_the_built_kernels():
         # 613.3 M steps/s, profiles/r04_experiments.txt.  A spill inside the turn's loops is what this guards against: it showed as 15+ registers.
         # Round 5, with the mirror update at the end of the turn: ten parked values.  A reload there is a LOAD behind every store of the turn: the update's
         # own addresses are computed in place for that reason, profiles/r05_experiments.txt.)
-        assert m["vgpr_spill_count"] <= 12, (k, m)
+        # Round 6: the parked values were mostly ADDRESSES -- `field + e` for the SoA fields the tail stores, LDS columns at run-time offsets, the block's counter
+        # row -- computed once at the top of the wave (GVN) and held for 30 000 instructions; the tail now addresses from an opaque copy of the env index, the
+        # LDS columns sit at compile-time offsets, reciprocals of config constants come from RgConfig: 68 bytes of scratch -> 16, none of it reloaded behind
+        # the turn's stores (the one parked pair is the address of the glyph table load, read back before the first store).
+        assert m["vgpr_spill_count"] <= 5 and m["private_segment_fixed_size"] <= 20, (k, m)
     obs = [k for k in md if re.search(r"k_obsILi0ELb0E", k)]       # k_obs<gray, no config groups>: the kernel of the headline workload
     assert obs, sorted(md)
     for k in obs:
@@ -67,7 +71,7 @@ def test_register_and_scratch_budget_of_the_built_kernels():
         if "huge" in k:  # the > 64-room instances (not a performance path): the compiler reserves a 68-byte frame for k_regen_huge that no instruction touches
             assert m["private_segment_fixed_size"] <= 128, ("scratch memory in", k, m)
             continue
-        assert m["private_segment_fixed_size"] <= 48, ("scratch memory in", k, m)  # (a 20-byte frame no instruction touches, or k_step_w32's five parked registers)
+        assert m["private_segment_fixed_size"] <= 20, ("scratch memory in", k, m)  # (a 20-byte frame no instruction touches, or k_step_w32's parked address)
 
 
 def test_lds_dma_loads_name_their_lds_row_with_a_uniform_m0():
