@@ -116,7 +116,7 @@ def cpu_baseline(cfg, desc, budget_s=10.0):
 class Harness:
     """One workload on this rank: env batch + pre-generated action tensor."""
 
-    def __init__(self, torch, workload, n, rank, local_rank):
+    def __init__(self, torch, workload, n, rank, local_rank, persistent_obs=False):
         from rogue_gym.envs import DungeonType, HipVecRogueEnv, ImageSetting, StatusFlag
 
         cfg_name, n_default, obs_kind, self.algo_bytes, (self.step_bytes, self.obs_bytes), self.desc = WORKLOADS[workload]
@@ -127,7 +127,7 @@ class Harness:
         cfgs = [json.dumps(dict(self.cfg, seed=first + i)) for i in range(self.n)]
         self.env = HipVecRogueEnv(cfgs, max_steps=1000,
                                   image_setting=ImageSetting(DungeonType.GRAY if obs_kind == "gray" else DungeonType.SYMBOL, StatusFlag.EMPTY, False),
-                                  device=local_rank)
+                                  device=local_rank, persistent_obs=persistent_obs)
         dev = self.env.device
         gen = torch.Generator(device=dev).manual_seed(rank)  # action source is not part of parity
         # pre-generated action tensor (512 rows whatever --steps is: a table of only steps + warmup rows -- 25 for the driver's command -- turns the
@@ -259,6 +259,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mini")
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="default: the workload's own size (65 536 for mini)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--persistent-obs", action="store_true", help="A/B aid: the measured batch with its observation tensor bound (rg_obs_bind: in-place updates); the line then "
+                    "says so in `config.workload` and is not the headline metric")
     ap.add_argument("--no-extra", action="store_true", help="skip the short extra_workloads runs (default / nohide-symbol)")
     ap.add_argument("--no-repeats", action="store_true", help="skip the 4 further runs of K steps (median)")
     ap.add_argument("--clock-warm-s", type=float, default=1.5, help="untimed fixed-duration stepping of a SCRATCH batch before anything else (0 = off)")
@@ -332,7 +334,7 @@ def main():
         scratch.close()
         del scratch
 
-    hz = Harness(torch, args.workload, args.envs_per_gpu, rank, local_rank)
+    hz = Harness(torch, args.workload, args.envs_per_gpu, rank, local_rank, persistent_obs=args.persistent_obs)
     n, env = hz.n, hz.env
     preroll = None
     if args.preroll_steps > 0:
@@ -539,7 +541,7 @@ def main():
             traffic_src = "profiles/pmc_traffic.json was collected on build %s, this library is %s: traffic withheld" % (traffic_build, build_id)
             traffic, traffic_all = None, None
         out = {
-            "metric": "env-steps/sec (whole node) at 65 536 envs, 32x16 mini-dungeon" if args.workload == "mini" and n == 65536
+            "metric": "env-steps/sec (whole node) at 65 536 envs, 32x16 mini-dungeon" if args.workload == "mini" and n == 65536 and not args.persistent_obs
                       else "env-steps/sec (whole node), workload %s, %d envs per GPU" % (args.workload, n),
             "value": n * world * K / dt_max,
             "unit": "env-steps/s",
@@ -680,6 +682,32 @@ def main():
                 del x
             except Exception as e:
                 out["fixed_seed_spares_kept"] = {"error": str(e)}
+        if args.workload == "mini" and not args.no_extra:
+            # Opt-in, NOT the headline: the observation tensor BOUND to the stepper (rg_obs_bind; HipVecRogueEnv(persistent_obs=True)) -- the same f32 batch in the same
+            # buffer, kept current in place: the observation pass rewrites only the envs whose screen changed in this step.  `value` re-encodes every env every step.
+            try:
+                x = Harness(torch, "mini", 0, 0, local_rank, persistent_obs=True)
+                for _ in range(1500 + 50):
+                    x.step()
+                x.timing(7)
+                x.env.counters(reset=True)
+                torch.cuda.synchronize()
+                x0 = time.perf_counter()
+                for _ in range(600):
+                    x.step()
+                torch.cuda.synchronize()
+                xdt = time.perf_counter() - x0
+                pk = x.read_timing()
+                x.env.check_errors()
+                out["bound_observation_tensor"] = {"value": x.n * 600 / xdt, "unit": "env-steps/s", "steps": 600, "preroll": 1500, "warmup": 50, "ms_per_step": xdt / 600 * 1e3,
+                                                   "per_kernel": pk,
+                                                   "note": "opt-in rg_obs_bind: the caller's observation tensor is updated IN PLACE -- only the envs whose screen changed are re-encoded "
+                                                           "(bit-identical contents, tests/test_gpu_features.py::test_bound_observation_tensor_is_the_full_encode); NOT the headline, "
+                                                           "which writes all 65 536 images every step"}
+                x.close()
+                del x
+            except Exception as e:
+                out["bound_observation_tensor"] = {"error": str(e)}
         if not args.no_cpu_baseline and WORKLOADS[args.workload][2] == "gray":
             out["cpu_baseline"] = cpu_baseline(golden_config(WORKLOADS[args.workload][0]), WORKLOADS[args.workload][5])
     if rank == 0:

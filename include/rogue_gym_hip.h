@@ -34,6 +34,7 @@ typedef struct rg_handle rg_t;
 #define RG_FLAG_HIST_STALE 0x00000008u  /* internal: this Redraw keeps the old level's history */
 #define RG_FLAG_HIST_LAG   0x00000010u  /* internal: the history mirror still shows the level before the current one */
 #define RG_FLAG_HIST_DIRTY 0x00000020u  /* internal: the visited set changed since the history mirror was last written */
+#define RG_FLAG_SCR_CHANGED 0x00000040u /* internal: the turn itself changed bytes of the screen mirror since the bound observation tensor was last written (rg_obs_bind) */
 #define RG_FLAG_MSG_SHIFT  8            /* bits 8..14: MessageFlagInner (python/src/flags.rs:6-39) */
 #define RG_FLAG_MSG_MASK   0x00007f00u
 #define RG_FLAG_ERR_KEY    0x00010000u  /* ErrorKind::InvalidInput: key not in KeyMap::ai (input.rs:73-100) */
@@ -90,6 +91,15 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
  * PlayerState::gray_image, python/src/lib.rs:72-87,251-256): one trip through the binding instead of two.  (A step kernel whose waves also drew and
  * encoded their own envs was built and measured in round 5: 196 us against 52 + 44 us for the two launches -- profiles/r05_experiments.txt.) */
 int rg_step_obs_gray(rg_t *h, const uint8_t *keys, int keys_on_device, uint32_t status_flag, int with_hist, float *out_dev);
+/* A BOUND observation tensor (opt-in): `out_dev` becomes the handle's standing observation batch for exactly this image setting (kind 0 gray / 1 symbol,
+ * no status planes, no history plane) -- what the reference's learner rebuilds from the PlayerState values after every step (parallel.py:44-66 ->
+ * ImageSetting.expand -> PlayerState::gray_image / symbol_image, python/src/lib.rs:72-205).  While bound, every rg_step_obs_gray / rg_obs_gray / rg_obs_symbol
+ * call with the same arguments keeps the tensor CURRENT IN PLACE: it rewrites the images of the envs whose screen changed since the last such call (a Redraw
+ * drawn from the tiles, or bytes the turn wrote into the screen mirror itself) and leaves the others -- whose f32 image is already what a full encode would
+ * write -- untouched; the contents after the call are bit-identical to the unbound call's.  The caller must not write to the tensor.  The first call after
+ * binding, and the first after anything else drew the mirrors (rg_fetch_states, an observation call with other arguments, rg_screen ...), encodes every env.
+ * out_dev = NULL unbinds.  Not for handles with config groups.  (65 536 mini envs: 57 % of the envs of a step of the random policy change nothing on screen.) */
+int rg_obs_bind(rg_t *h, int kind, uint32_t status_flag, int with_hist, float *out_dev);
 /* Wait for the stream; returns non-zero (and sets the error text) if any env raised an error flag
  * since the last call (invalid key / action while dead), like the PyRuntimeError of lib.rs:20-26. */
 int rg_sync(rg_t *h);

@@ -43,7 +43,7 @@ void rgk_encode(const uint8_t *screen, const uint8_t *hist, const int32_t *statu
 void rgk_pack(const RgState *S, int with_hist, uint8_t *out, hipStream_t st);
 void rgk_scatter_rows(const void *src, void *dst, const int32_t *ext, int n, int row_bytes, hipStream_t st);
 void rgk_gather_keys(const uint8_t *keys, const int32_t *ext, uint8_t *dst, int n, hipStream_t st);
-int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, int planes_sym, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, int planes_sym, int bound, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 }
 
 #define RG_TIMED_KERNELS 5   // k_step, k_render, k_obs (or the unfused encode), k_build, k_regen
@@ -71,6 +71,10 @@ struct rg_handle {
     uint32_t *d_err = nullptr;
     uint8_t *d_keys = nullptr;
     bool render_pending = false;
+    // rg_obs_bind: the caller's standing observation tensor and whether its contents are the current screens of every env up to the SCR_CHANGED / REDRAW flags
+    float *bound_out = nullptr; int bound_kind = 0; bool bound_valid = false;
+    int32_t *obs_list_mem = nullptr; uint32_t *obs_cnt_mem = nullptr;
+    int bound_steps = 0;   // k_step launches since the bound tensor was last written: its in-place pass works from the list of exactly ONE
     int stair_gen = 0;           // producers of the stair set launched so far (k_build, k_step, the debug descent; rg_state.h)
     float *obs_scratch = nullptr;  // rg_obs_host: device-side observation buffer, kept between calls
     size_t obs_scratch_cap = 0;
@@ -169,6 +173,7 @@ static int flush_render(rg_handle *h) {
         { TimedLaunch t(h, 1); rgk_render(&h->S, &h->cfg, h->stream); }
         HIPCHK(h, hipGetLastError());
         h->render_pending = false;
+        h->bound_valid = false;  // (Redraw flags were consumed without the bound observation tensor being written: its next call encodes every env)
     }
     return 0;
 }
@@ -255,9 +260,6 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
     if (ok && nr <= RG_OBS_MAX_ROOMS) ok = dev_alloc(h, &S.obs_rec, n * (size_t)RG_OBS_REC_WORDS(nr));
     if (ok && nr <= RG_OVL_MAX && getenv("ROGUE_GYM_HIP_NO_MIRROR_UPDATE") == nullptr)  // (the A side: every Redraw drawn from the tiles by the observation pass)
         ok = dev_alloc(h, &S.ovl, (nr + 1) * n) && hipMemset(S.ovl, 0xff, (nr + 1) * n * 2) == hipSuccess;
-    // the envs' window records (rg_state.h win_rec; zero = invalid).  ROGUE_GYM_HIP_NO_WINDOW_RECORDS: every turn loads its window from the tiles (the A side)
-    if (ok && getenv("ROGUE_GYM_HIP_NO_WINDOW_RECORDS") == nullptr) ok = dev_alloc(h, &S.win_rec, n * RG_WREC_WORDS);
-    S.win_check = RG_DEV_ENV("ROGUE_GYM_HIP_WINREC_CHECK") != nullptr;
     h->spares = auto_reset != 0 && getenv("ROGUE_GYM_HIP_NO_SPARES") == nullptr;
     // which producer refills the consumed spares: one level per LANE (rg_regen_lanes.hip; two spares per env, rg_state.h sp_slots) where it applies,
     // else -- or with ROGUE_GYM_HIP_WAVE_REGEN=1 -- one level per wave (k_regen, one spare per env)
@@ -309,7 +311,7 @@ static int create_homog(const RgParsed &parsed, const EnvSeed *seeds, int n_env,
              dev_alloc(h, &P.mon_w0, nr * ns) && dev_alloc(h, &P.mon_hp, nr * ns) && dev_alloc(h, &P.mon_exp, nr * ns) &&
              dev_alloc(h, &P.mon_cnt, ns) && dev_alloc(h, &P.gold_pos, nr * ns) && dev_alloc(h, &P.gold_amt, nr * ns) &&
              dev_alloc(h, &P.edge_a, ne * n) && dev_alloc(h, &P.edge_b, ne * n) && dev_alloc(h, &P.maze_stack, (size_t)maze_cap * n) &&
-             dev_alloc(h, &P.on_stairs, ns) && (!S.win_rec || dev_alloc(h, &P.win_rec, ns * RG_WREC_WORDS));  // (the spares' window records: their own array, never the live one)
+             dev_alloc(h, &P.on_stairs, ns);
         P.prof = nullptr;
         int lo = 0, hi = 0;
         if (ok && (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, RG_DEV_ENV("ROGUE_GYM_HIP_SIDE_HIPRIO") ? hi : lo) != hipSuccess)) {
@@ -602,6 +604,7 @@ int rg_step_prefix(rg_t *h, const uint8_t *keys, int n_keys, int keys_on_device)
     {   // stair isolation (rg_kernels.hip, k_step): on unless ROGUE_GYM_HIP_NO_STAIR_WAVES is set (the A/B knob of DESIGN.md's measurement)
         TimedLaunch t(h, 0, true);
         h->S.stair_gen = h->stair_gen++;  // reads the stair set its predecessor produced, produces the next one
+        h->S.obs_par = (int32_t)(h->step_count & 1); h->bound_steps++;  // (rg_obs_bind: this launch's half of the work list)
         (void)rgk_step(&h->S, h->d_SP, &h->cfg, dk, h->spares ? 1 : 0, no_stair_waves ? -1 : 0, h->stream, t.start_ev(), t.stop_ev());
     }
     HIPCHK(h, hipGetLastError());
@@ -698,13 +701,18 @@ static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, fl
     }
     {   // steady state: one fused pass refreshes the mirrors of Redraw envs and encodes every env
         TimedLaunch t(h, 2, true);
-        if (rgk_obs(&h->S, &h->cfg, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->d_err, h->planes_sym, h->stream, t.start_ev(), t.stop_ev())) {
+        // the bound tensor with its own image setting: in place (only the envs whose screen changed), once its contents are known to be current
+        const bool bound = h->bound_out && out_dev == h->bound_out && kind == h->bound_kind && (status_flag & 0x1ffu) == 0 && !with_hist;
+        if (rgk_obs(&h->S, &h->cfg, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->d_err, h->planes_sym, bound && h->bound_valid && h->bound_steps == 1, h->stream, t.start_ev(), t.stop_ev())) {
             HIPCHK(h, hipGetLastError());
             h->render_pending = false;
+            h->bound_valid = bound;  // (any other observation call consumed Redraw flags the bound tensor has not seen)
+            h->bound_steps = 0;
             return 0;
         }
         t.cancel();  // H*W % 8 != 0: nothing was launched, the fallback below brackets its own pair
     }
+    h->bound_valid = false;
     if (flush_render(h)) return 1;
     {
         TimedLaunch t(h, 2);
@@ -712,6 +720,19 @@ static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, fl
                    status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->S.ext, h->stream);
     }
     HIPCHK(h, hipGetLastError());
+    return 0;
+}
+int rg_obs_bind(rg_t *h, int kind, uint32_t status_flag, int with_hist, float *out_dev) {
+    if (!h->sub.empty()) { h->err = "rg_obs_bind: not for a handle with config groups"; return 1; }
+    if (out_dev && ((status_flag & 0x1ffu) || with_hist || (kind != 0 && kind != 1))) { h->err = "rg_obs_bind: gray or symbol image without status planes and history plane"; return 1; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (out_dev && !h->obs_list_mem) {  // the work list k_step leaves for the in-place pass (rg_state.h obs_list)
+        if (!dev_alloc(h, &h->obs_list_mem, 2 * (size_t)h->S.n) || !dev_alloc(h, &h->obs_cnt_mem, 2)) return 1;
+    }
+    if (out_dev) HIPCHK(h, hipMemsetAsync(h->obs_cnt_mem, 0, 8, h->stream));
+    h->S.obs_list = out_dev ? h->obs_list_mem : nullptr; h->S.obs_cnt = out_dev ? h->obs_cnt_mem : nullptr;
+    h->S.bound_gray = (out_dev && kind == 0) ? out_dev : nullptr;  // (k_step's mirror update writes a gray image's changed pixels itself)
+    h->bound_out = out_dev; h->bound_kind = kind; h->bound_valid = false; h->bound_steps = 0;
     return 0;
 }
 int rg_obs_gray(rg_t *h, uint32_t status_flag, int with_hist, float *out_dev) { return obs_common(h, status_flag, with_hist, 0, out_dev); }

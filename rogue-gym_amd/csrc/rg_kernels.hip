@@ -1016,20 +1016,6 @@ __device__ __forceinline__ void gen_service(const RgState &S, const RgConfig &c,
             }
             if (GM < 2) break;
         }
-        if (S.win_rec) {
-            // the env's window record (rg_state.h win_rec) for its first key on this level: the 5x5 around the player's placement from the staging grid -- lane k
-            // holds cell k, word m of the record is assembled in lane m.  (The spare view's records are the spares': take_spares moves them with the level.)
-            const int k = lane < 25 ? lane : 0, x = U.px + k % 5 - 2, y = U.py + k / 5 - 2;
-            const bool in = lane < 25 && in_bounds(c, x, y);
-            const uint32_t v = in ? (uint32_t)U.lc[y * c.width + x] : 0u;
-            const uint32_t inb = (uint32_t)__ballot(in);
-            const int m = lane < 13 ? lane : 0;
-            uint32_t word = (uint32_t)__shfl((int)v, 2 * m) | ((uint32_t)__shfl((int)v, 2 * m + 1) << 16);  // (lane 12: cell 24 | cell "25" = 0)
-            if (lane == 12) word |= POS(U.px, U.py) << 16;
-            if (lane == 13) word = inb | RG_WREC_VALID;
-            if (lane > 13) word = 0;
-            if (lane < RG_WREC_WORDS) st_pub<WT>(&S.win_rec[(size_t)real_e * RG_WREC_WORDS + lane], word);
-        }
         {
             uint16_t *dst = S.cell + (size_t)real_e * HW;
             const uint16_t *srcp = reinterpret_cast<const uint16_t *>(slot);
@@ -1957,43 +1943,14 @@ __device__ __forceinline__ void win_flush(const RgConfig &c, uint16_t *cell, Win
             if ((w.dirty >> WIN_K(i, j)) & 1u) cell[(w.oy + j) * c.width + w.ox + i] = (uint16_t)WV(w, WIN_K(i, j));
     w.dirty = 0;
 }
-__device__ __forceinline__ int clamp3(int v, int lo, int hi) { return min(max(v, lo), hi); }  // (v_med3_i32)
-// ---- the window travels with the env (rg_state.h win_rec) ----
-// LDS behind the parked overlay words of a step wave: the re-centred window the tail assembles [25][64] u16, the (up to) ten cells that enter it when the
-// player moves one cell -- a column of five and a row of five, fetched by LDS-DMA right after the move -- [10][64] u32
-// LDS of a step wave: every per-lane column FIRST, at compile-time offsets -- window, parked overlay words + glyph bytes, window-record staging, monster
-// cache (its length is the config's) -- so that a column's address is lane * 4 (or * 2) + an immediate of the DS instruction: ONE live register for all of
-// them, where run-time offsets behind the generator's staging area (rounds 2-5) took a VGPR per column from the top of the wave to its tail.  The staging
-// area (generator grid + tables, BFS planes of wide grids) follows at `stage_off`, a kernel argument.
+// LDS of a step wave: every per-lane column FIRST, at compile-time offsets -- window, parked overlay words + glyph bytes, monster cache (its length is the
+// config's) -- so that a column's address is lane * 4 (or * 2) + an immediate of the DS instruction: ONE live register for all of them, where run-time offsets
+// behind the generator's staging area (rounds 2-5) took a VGPR per column from the top of the wave to its tail.  The staging area (generator grid + tables, BFS
+// planes of wide grids) follows at `stage_off`, a kernel argument.
 #define STEP_LDS_WIN 0
 #define STEP_LDS_OVL (STEP_LDS_WIN + WIN_SLOTS * WAVE * 2)
-#define STEP_LDS_WREC (STEP_LDS_OVL + (RG_OVL_MAX + 6) * WAVE * 4 + 64)
-#define STEP_LDS_MC (STEP_LDS_WREC + WREC_LDS_BYTES)
-#define WREC_LDS_NEW 0
-#define WREC_LDS_DMA (WIN_SLOTS * WAVE * 2)
-#define WREC_LDS_BYTES (WREC_LDS_DMA + 10 * WAVE * 4)
-#define WREC_COL_HI 0x1084210u  // window cells of column i = +2 (k % 5 == 4), ... i = -2, row j = +2 (k >= 20), row j = -2
-#define WREC_COL_LO 0x0108421u
-#define WREC_ROW_HI 0x1f00000u
-#define WREC_ROW_LO 0x000001fu
-// the window from the env's record: 13 words in registers -> the lane's LDS column; centred on the player (the record's validity test, step_wave)
-__device__ __forceinline__ void win_from_rec(Win &w, const uint4 &q0, const uint4 &q1, const uint4 &q2, const uint4 &q3, int px, int py) {
-    w.ox = px; w.oy = py; w.dirty = 0;
-    const uint32_t q[13] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x};
-#pragma unroll
-    for (int k = 0; k < 25; k++) WSET(w, k, (k & 1) ? q[k >> 1] >> 16 : q[k >> 1] & 0xffffu);
-    const uint32_t inb = q3.y & 0x1ffffffu;
-    bool st = false;
-#pragma unroll
-    for (int j = -RG_NX_NEAR; j <= RG_NX_NEAR; j++)
-#pragma unroll
-        for (int i = -RG_NX_NEAR; i <= RG_NX_NEAR; i++) {
-            const int k = WIN_K(i, j);
-            const uint32_t val = (k & 1) ? q[k >> 1] >> 16 : q[k >> 1] & 0xffffu;
-            st = st || (((inb >> k) & 1u) && (val & C_SURF_MASK) == S_STAIR);
-        }
-    w.inb = (w.inb & WIN_STAIR) | inb | (st ? WIN_STAIR : 0u);
-}
+#define STEP_LDS_LUT (STEP_LDS_OVL + (RG_OVL_MAX + 6) * WAVE * 4 + 64)   // glyph -> gray value, 128 floats (a bound gray observation tensor: mirror_update)
+#define STEP_LDS_MC (STEP_LDS_LUT + 128 * 4)
 __device__ __forceinline__ uint32_t win_get(const Win &w, int k) { return WV(w, k); }  // run-time index
 __device__ __forceinline__ void win_set(Win &w, int k, uint32_t val) {
     WSET(w, k, val);
@@ -2393,6 +2350,11 @@ __device__ __forceinline__ bool mirror_update(const RgState &S, const RgConfig &
     int e = E.e;
     asm volatile("" : "+v"(e));
     uint8_t *scr = S.screen + (size_t)e * S.hw;
+    // a bound GRAY observation tensor (rg_obs_bind): every byte written to the mirror below is also written to the env's image as the f32 the observation pass
+    // would encode it to (the wave's LDS table, filled at the top of step_wave: the same expression) -- the env then needs no pass at all
+    float *og = S.bound_gray ? S.bound_gray + (size_t)e * S.hw : nullptr;
+    const __attribute__((address_space(3))) float *lutg = (const __attribute__((address_space(3))) float *)(g_smem + STEP_LDS_LUT);
+    auto put = [&](int idx, uint32_t g) { scr[idx] = (uint8_t)g; if (og) og[idx] = lutg[g & 0x7fu]; };
     // (the lane's LDS columns from the lane id, here: a pointer carried from the top of the wave is one more spilled register to reload)
     int ln = threadIdx.x;
     asm volatile("" : "+v"(ln));
@@ -2452,20 +2414,20 @@ __device__ __forceinline__ bool mirror_update(const RgState &S, const RgConfig &
         const int k = __ffs((int)d) - 1;
         d &= d - 1;
         const int j = k / 5, i = k - j * 5, x = w.ox + i - 2, y = w.oy + j - 2;
-        scr[y * W + x] = (uint8_t)(base_glyph(c, WV(w, k), y) & 0x7fu);
+        put(y * W + x, base_glyph(c, WV(w, k), y) & 0x7fu);
     }
     if (react & R_HIST_CHANGED) S.hist[(size_t)e * S.hw + py * W + px] = 1;  // (the one way a cell becomes VISITED: the player steps on it, move_player)
     // 2. the player's old cell, the cells monsters left or stopped showing on
     if (pl_moved && pl != OVL_NONE) {
         const int x = POS_X(plp), y = POS_Y(plp);
-        scr[y * W + x] = (uint8_t)(base_glyph(c, WV(w, WIN_K(x - w.ox, y - w.oy)), y) & 0x7fu);  // (one turn: the old cell is the window's centre or next to it)
+        put(y * W + x, base_glyph(c, WV(w, WIN_K(x - w.ox, y - w.oy)), y) & 0x7fu);  // (one turn: the old cell is the window's centre or next to it)
     }
 #pragma nounroll
     for (int s0 = 0; s0 < nrooms; s0++)
         if ((actp >> (3 * s0)) & 1u) {
             const uint32_t pp = ovl_l[(1 + s0) * WAVE] & 0xff3fu;
             const int x = POS_X(pp), y = POS_Y(pp);
-            scr[y * W + x] = (uint8_t)(base_glyph(c, WV(w, WIN_K(x - w.ox, y - w.oy)), y) & 0x7fu);
+            put(y * W + x, base_glyph(c, WV(w, WIN_K(x - w.ox, y - w.oy)), y) & 0x7fu);
         }
     // 3. the monsters that (newly) show: draw priority monster < gold < player (core/src/lib.rs:271-283)
 #pragma nounroll
@@ -2474,71 +2436,11 @@ __device__ __forceinline__ bool mirror_update(const RgState &S, const RgConfig &
             const uint32_t m = mc[s0 * WAVE];
             const int x = POS_X(m), y = POS_Y(m);
             const uint32_t under = base_glyph(c, WV(w, WIN_K(x - w.ox, y - w.oy)), y);
-            if ((under & 0x80u) && under != (0x80u | '*')) scr[y * W + x] = mt[(m >> 16) & 0xff];
+            if ((under & 0x80u) && under != (0x80u | '*')) put(y * W + x, mt[(m >> 16) & 0xff]);
         }
     // 4. the player
-    if (pl_moved && (base_glyph(c, WV(w, WIN_K(px - w.ox, py - w.oy)), py) & 0x80u)) scr[py * W + px] = '@';
+    if (pl_moved && (base_glyph(c, WV(w, WIN_K(px - w.ox, py - w.oy)), py) & 0x80u)) put(py * W + px, '@');
     return true;
-}
-
-// The env's window record for its next key (rg_state.h win_rec), written by the turn itself (step_wave, first iteration of the turn loop, right behind the
-// player's action: the monsters move no tile).  keep = false: the key is a run -- the record is marked invalid and the next turn loads its window from the
-// tiles.  The player stands within one cell of the window's centre: the new window is the old one shifted by that step -- LDS to LDS, this lane's column --
-// plus the column / row that entered, fetched mid-turn (step_wave) and corrected for the move's whole-room fills (leaves_room clears VISIBLE in its
-// rectangle, then enters_room sets DRAWN | VISIBLE in its: set / clear, the same result whether the fetch saw the fill or not).  Loops over LDS, no register arrays.
-__device__ __forceinline__ void win_rec_store(const RgState &S, const RgConfig &c, const Env &E, const Win &w, const FillReq &fr, bool keep, bool current) {
-    uint32_t *rec = S.win_rec + (size_t)E.e * RG_WREC_WORDS;
-    if (!keep) { rec[13] = 0; return; }
-    const int px = E.px, py = E.py, dxm = px - w.ox, dym = py - w.oy, sh = dxm + 5 * dym;
-    if (current && sh == 0 && w.dirty == 0) return;  // the record in memory is this window already
-    const int ln = threadIdx.x;
-    uint8_t *wr = g_smem + STEP_LDS_WREC;
-    lds_u16 *nw = (lds_u16 *)(wr + WREC_LDS_NEW) + ln;
-    const lds_u32 *dma = (const lds_u32 *)(wr + WREC_LDS_DMA) + ln;
-    // new cell k = old cell k + sh wherever that lies inside the old window
-    const uint32_t inside = 0x1ffffffu & ~(dxm > 0 ? WREC_COL_HI : (dxm < 0 ? WREC_COL_LO : 0u)) & ~(dym > 0 ? WREC_ROW_HI : (dym < 0 ? WREC_ROW_LO : 0u));
-    const uint32_t old_inb = w.inb & 0x1ffffffu;
-    uint32_t inb = (sh >= 0 ? old_inb >> sh : old_inb << -sh) & inside;
-    const lds_u16 *src = w.v + sh * WAVE;
-#pragma unroll
-    for (int k = 0; k < 25; k++) nw[k * WAVE] = ((inside >> k) & 1u) ? src[k * WAVE] : (uint16_t)0;
-    if (sh != 0) {  // the cells that entered: in-grid bit and value
-#pragma unroll
-        for (int t = 0; t < 10; t++) {
-            const bool col = t < 5;
-            if (col ? dxm != 0 : dym != 0) {
-                const int i = col ? 2 * dxm : t - 5 - 2, j = col ? t - 2 : 2 * dym;
-                const int x = px + i, y = py + j;
-                if (in_bounds(c, x, y)) {
-                    nw[WIN_K(i, j) * WAVE] = (uint16_t)dma[t * WAVE];
-                    inb |= 1u << WIN_K(i, j);
-                }
-            }
-        }
-        if (fr.leave | fr.enter) {  // (rare: a door was passed) the move's whole-room fills on the cells that entered
-            int lx0, ly0, lx1, ly1, ex0, ey0, ex1, ey1;
-            unpack_rect(fr.leave, lx0, ly0, lx1, ly1);
-            unpack_rect(fr.enter, ex0, ey0, ex1, ey1);
-#pragma nounroll
-            for (int k = 0; k < 25; k++) {
-                if (((inside | ~inb) >> k) & 1u) continue;
-                const int x = px + k % 5 - 2, y = py + k / 5 - 2;
-                uint32_t v = nw[k * WAVE];
-                if (x >= lx0 && x < lx1 && y >= ly0 && y < ly1) v &= ~C_VISIBLE;
-                if (x >= ex0 && x < ex1 && y >= ey0 && y < ey1) v |= C_DRAWN | C_VISIBLE;
-                nw[k * WAVE] = (uint16_t)v;
-            }
-        }
-    }
-    uint4 *r4 = reinterpret_cast<uint4 *>(rec);
-#pragma unroll
-    for (int g = 0; g < 3; g++) {
-        uint32_t q[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) q[m] = (uint32_t)nw[(8 * g + 2 * m) * WAVE] | ((uint32_t)nw[(8 * g + 2 * m + 1) * WAVE] << 16);
-        r4[g] = make_uint4(q[0], q[1], q[2], q[3]);
-    }
-    r4[3] = make_uint4((uint32_t)nw[24 * WAVE] | (POS(px, py) << 16), inb | RG_WREC_VALID, 0u, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2613,12 +2515,6 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
         const int32_t hp = SP.p_hp[es], hpm = SP.p_hpmax[es], lv = SP.p_lvl[es];
         const uint32_t ex = SP.p_exp[es], fd = SP.food[es], qu = SP.quiet[es], pg = SP.pack_gold[es], dl = SP.dlevel[es], mc = SP.mon_cnt[es];
         on_stairs = SP.on_stairs[es] != 0;
-        if (S.win_rec) {  // the spare's window record (written with the spare: gen_service / k_regen_lanes)
-            const uint4 *sr = reinterpret_cast<const uint4 *>(SP.win_rec + (size_t)es * RG_WREC_WORDS);
-            uint4 *dr = reinterpret_cast<uint4 *>(S.win_rec + (size_t)e * RG_WREC_WORDS);
-            const uint4 a0 = sr[0], a1 = sr[1], a2 = sr[2], a3 = sr[3];
-            dr[0] = a0; dr[1] = a1; dr[2] = a2; dr[3] = a3;
-        }
 #pragma unroll
         for (int k = 0; k < 12; k++) S.rng[k * n + e] = r[k];
         S.p_pos[e] = pp; S.p_hp[e] = hp; S.p_hpmax[e] = hpm; S.p_lvl[e] = lv;
@@ -2679,12 +2575,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     const int nrooms_k = c.room_num_x * c.room_num_y;
     E.mc = (lds_u32 *)(g_smem + STEP_LDS_MC) + lane;
     const uint32_t glyph_r = S.ovl ? c.mon[lane & 31].tile : 0u;  // (the monster glyphs by type, for the wave's LDS table: requested with the first round of loads)
-    uint4 wq0 = make_uint4(0, 0, 0, 0), wq1 = wq0, wq2 = wq0, wq3 = wq0;  // the env's window record (rg_state.h win_rec)
     if (valid_in) {
-        if (S.win_rec) {  // ... requested first: one line per env, with the scalars -- not behind them like the window's 25 scattered cells
-            const uint4 *rp = reinterpret_cast<const uint4 *>(S.win_rec + (size_t)e * RG_WREC_WORDS);
-            wq0 = rp[0]; wq1 = rp[1]; wq2 = rp[2]; wq3 = rp[3];
-        }
         // ONE round of independent loads: the step's inputs, the env's scalars and its monster words together.  (Whether the lane plays at all is
         // only known from the first few -- loading the env behind that decision was a second dependent round trip in every wave; a lane that turns
         // out to be somebody else's (stair_role 2), dead or past max_steps just drops what it loaded.)
@@ -2742,6 +2633,11 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     // Redraw (S.ovl) -- parked here from the first load round to the incremental mirror update at the end of the turn
     lds_u32 *ovl_l = (lds_u32 *)(g_smem + STEP_LDS_OVL) + lane;
     ovl_l[0] = 0;
+    if (S.bound_gray) {  // glyph -> gray value as the observation pass encodes it (rg_obs.hip k_obs `lutf`, python/src/lib.rs:84: the same single division)
+        __attribute__((address_space(3))) float *lutg = (__attribute__((address_space(3))) float *)(g_smem + STEP_LDS_LUT);
+        lutg[lane] = (float)(uint8_t)tile_to_sym((uint32_t)lane) / (float)(uint8_t)c.symbols;
+        lutg[lane + 64] = (float)(uint8_t)tile_to_sym((uint32_t)lane + 64u) / (float)(uint8_t)c.symbols;
+    }
     if (S.ovl && lane < RG_MAX_ENEMY_KINDS + 6)
         ((__attribute__((address_space(3))) uint8_t *)(g_smem + STEP_LDS_OVL + (RG_OVL_MAX + 6) * WAVE * 4))[lane] = (uint8_t)glyph_r;
     if (S.ovl) {
@@ -2774,23 +2670,8 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         __builtin_amdgcn_global_load_lds((gptr)(S.room_rect + ab), (lptr)(base + (RG_OVL_MAX + 4) * WAVE), 4, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr)(S.room_meta + ab), (lptr)(base + (RG_OVL_MAX + 5) * WAVE), 1, 0, 0);
     }
-    // The window: from the env's record when it is current (flag set, centred on the player) -- it came with the scalars -- else from the tiles, one more
-    // dependent round of loads (the first turn after a new level, a reset, a run; ROGUE_GYM_HIP_NO_WINDOW_RECORDS: always)
-    const bool has_win = live && stair_role != 1;
-    const bool rec_ok = has_win && (wq3.y & RG_WREC_VALID) && (wq3.x >> 16) == POS(E.px, E.py);
-    if (rec_ok) win_from_rec(w, wq0, wq1, wq2, wq3, E.px, E.py);
-    else if (has_win) win_load(c, E.cell, w, E.px, E.py);
+    if (live && stair_role != 1) win_load(c, E.cell, w, E.px, E.py);
     else { w.inb = 0; w.dirty = 0; w.ox = w.oy = 0; }
-#ifdef RG_DEV_KNOBS
-    if (S.win_check && rec_ok) {  // development library: a record that is used must be what win_load would have fetched
-        for (int k = 0; k < 25; k++) {
-            const int x = E.px + k % 5 - 2, y = E.py + k / 5 - 2;
-            const bool in = in_bounds(c, x, y);
-            const uint32_t val = in ? (uint32_t)E.cell[y * c.width + x] : 0u;
-            if (val != WV(w, k) || in != (((w.inb >> k) & 1u) != 0)) E.err |= RG_FLAG_ERR_INTERNAL;
-        }
-    }
-#endif
     pf.mark(26);
     if (live && act == ACT_DOWNSTAIR) {
         if (stair_role == 1 || (WV(w, WIN_K(0, 0)) & C_SURF_MASK) == S_STAIR) {
@@ -2874,26 +2755,6 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
                 }
             }
             if constexpr (BW == 1 || BW == 2) { if (__any(opened) && S.dc_walk) snapshot_walk_service(S, c, lane, e, opened); }
-            if (S.win_rec && iter == 0) {  // (a lane's own turn is the loop's first iteration; a run -- the later ones -- leaves no record)
-                // The window of the NEXT key is this one moved by the player's step: the column and / or row of five cells that enter it are requested now,
-                // straight into LDS (no register), and consumed a few microseconds on, behind the monsters' prepass (win_rec_store).  Nothing in this turn
-                // writes them except a whole-room fill, applied to them there.  Unconditional for every lane, clamped into the grid -- an idle lane fetches
-                // cell 0 of its env -- LDS-DMA under divergent control flow is what the compiler merges into one instruction with a per-lane M0.
-                typedef const __attribute__((address_space(1))) void *gptr;
-                typedef __attribute__((address_space(3))) void *lptr;
-                lds_u32 *dma = (lds_u32 *)(g_smem + STEP_LDS_WREC + WREC_LDS_DMA);
-                const int W1 = c.width - 1, H1 = c.height - 1;
-                const int cx = has_win ? E.px : 0, cy = has_win ? E.py : 0;
-                const int xc = clamp3(has_win ? 3 * E.px - 2 * w.ox : 0, 0, W1);            // column px + 2 (px - ox), clamped
-                const int yr = clamp3(has_win ? 3 * E.py - 2 * w.oy : 0, 0, H1) * c.width;  // row py + 2 (py - oy)
-                const uint16_t *gc = S.cell + (size_t)(valid_in ? e : 0) * S.hw;
-#pragma unroll
-                for (int t = 0; t < 5; t++)
-                    __builtin_amdgcn_global_load_lds((gptr)(gc + (clamp3(cy + t - 2, 0, H1) * c.width + xc)), (lptr)(dma + t * WAVE), 2, 0, 0);
-#pragma unroll
-                for (int t = 0; t < 5; t++)
-                    __builtin_amdgcn_global_load_lds((gptr)(gc + (yr + clamp3(cx + t - 2, 0, W1))), (lptr)(dma + (5 + t) * WAVE), 2, 0, 0);
-            }
             pf.mark(28);
             if (do_turn) turn_passed(c, E, react);  // actions::after_turn (actions.rs:67-80)
             pf.mark(29);
@@ -2914,10 +2775,6 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
                 }
             }
             pf.mark(3);
-            // The env's window record for its next key: HERE -- the player's action is over, the cells fetched above have landed behind the prepass's own waits
-            // (at the tail of the wave their LDS reads waited for every store of the turn: vmcnt is in order, +3.9 us per wave) -- and before the window
-            // write-back clears the dirty mask.  A lane that dies later in this turn gets its new level's record from take_spares / gen_service.
-            if (S.win_rec && iter == 0 && has_win && !descends) win_rec_store(S, c, E, w, fr, act != ACT_MOVE_UNTIL, rec_ok);
             // whole-room reveals / hides by the wave, then the lanes' changed window cells (the final word on those cells); both before any
             // monster or BFS read of the grid
             // (for the incremental mirror update.  A lane's own turn is the loop's FIRST iteration unless it runs (MoveUntil); the later iterations -- driven by some
@@ -2957,7 +2814,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             flags = (react & 0x7f00u);                       // message flags of this key only
             if (react & R_REDRAW) flags |= RG_FLAG_REDRAW | ((react & R_HIST_STALE) ? RG_FLAG_HIST_STALE : 0);
             else flags |= old_flags & (RG_FLAG_REDRAW | RG_FLAG_HIST_STALE);
-            flags |= old_flags & (RG_FLAG_HIST_LAG | RG_FLAG_HIST_DIRTY);
+            flags |= old_flags & (RG_FLAG_HIST_LAG | RG_FLAG_HIST_DIRTY | RG_FLAG_SCR_CHANGED);
             if ((react & R_HIST_CHANGED) || descends) flags |= RG_FLAG_HIST_DIRTY;
             if (react & R_STATUS) write_status(S, c, E);
             if (ui_dead) flags |= RG_FLAG_DEAD;
@@ -2973,7 +2830,9 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             // (one turn per key = every action but a run: a per-LANE property -- one running lane in the wave no longer sends the other 63 to the tile-drawn Redraw)
             if (S.ovl && (react & R_REDRAW) && !descends && !need_gen && act != ACT_MOVE_UNTIL &&
                 !(old_flags & (RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | RG_FLAG_HIST_DIRTY)) && !(ovl_l[0] >> 31)) {
-                if (mirror_update(S, c, E, w, react, room_id_of(c, w.ox, w.oy))) flags &= ~(RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY);
+                // (SCR_CHANGED: bytes of the mirror changed without a Redraw flag -- what a bound observation tensor, rg_obs_bind, re-encodes this env for)
+                // (... unless the update wrote the image's pixels too: a bound gray tensor)
+                if (mirror_update(S, c, E, w, react, room_id_of(c, w.ox, w.oy))) flags = (flags & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY)) | (S.bound_gray ? 0u : RG_FLAG_SCR_CHANGED);
                 inc_done = true;  // (the overlays' positions and how they show are recorded either way)
             }
         }
@@ -2985,6 +2844,16 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     int et = e;
     asm volatile("" : "+v"(et));
     E.e = et;
+    // A bound observation tensor's work list (rg_state.h obs_list): this wave's slots are taken HERE -- one returning atomic per wave -- and filled at the very
+    // end: its return value is first needed behind all the stores of the tail, and vmcnt being in order it is there by then (asked for at the end, the wave
+    // waited 2.6 us for it: it returns behind every store issued before it).
+    bool pend = false; uint64_t pm = 0; uint32_t lbase = 0;
+    if (S.obs_list) {
+        const uint32_t fw = (live ? ((terminal && c.auto_reset) ? RG_FLAG_REDRAW : flags) : old_flags);
+        pend = valid && (fw & (RG_FLAG_REDRAW | RG_FLAG_SCR_CHANGED));
+        pm = __ballot(pend);
+        if (pm && lane == 0) lbase = atomicAdd(&S.obs_cnt[S.obs_par], (uint32_t)__popcll(pm));
+    }
     if (S.stats) {
         // per-BLOCK rows (one atomicAdd per wave and counter on a SHARED 64-byte line -- 7 000 same-line atomics per launch -- cost the kernel 20 us,
         // measured in round 2).  On the block's own line a no-return atomic is a fire-and-forget add; the plain `+=` of rounds 2-3 was a load the
@@ -3089,6 +2958,10 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             if (ask) __hip_atomic_store(&S.nx_state[et], RG_NX_ASKED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (pm) {
+        const uint32_t lb = uni(lbase);  // (lane 0's: read with every lane active, not inside the `pend` branch -- readfirstlane takes the first ACTIVE lane)
+        if (pend) S.obs_list[(size_t)S.obs_par * S.n + lb + lanes_below(pm)] = et;
+    }
     take_spares(S, SPd, c, lane, et, taken, on_next);
     stair_publish(S, lane, et, valid, on_next);
     pf.mark(7);
@@ -3116,6 +2989,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     const int lane = threadIdx.x; \
     if (blockIdx.x == 0 && lane == 0) { \
         stair_recycle(S); \
+        if (S.obs_cnt) S.obs_cnt[S.obs_par ^ 1] = 0;  /* (rg_state.h obs_list: the half the NEXT k_step appends to) */ \
         __hip_atomic_store(S.launch_mark, (uint32_t)S.stair_gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  /* this launch has started: k_regen_gate */ \
     } \
     const bool stair = parity >= 0 && (int)blockIdx.x < STAIR_BLOCKS; \
@@ -3196,7 +3070,7 @@ int rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const u
     const size_t bfs_hi = n32 ? 0 : (size_t)10 * ((c->width + 63) / 64) * WAVE * 8;  // ... the BFS high distance planes
     if (bfs_hi > stage) stage = bfs_hi;
     stage = (stage + 15) & ~(size_t)15;
-    // the per-lane columns first (STEP_LDS_*: window, parked overlay words, window-record staging, monster cache), then the staging area
+    // the per-lane columns first (STEP_LDS_*: window, parked overlay words, monster cache), then the staging area
     const int stage_off = STEP_LDS_MC + c->room_num_x * c->room_num_y * WAVE * 4;
     const size_t smem = (size_t)stage_off + stage;
     const int epw = rgk_step_epw(S->n, (c->width <= 32 && gen_mode_of(c) == 0) ? 2 : 1);

@@ -195,7 +195,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // GROUPS: the batch is one config group of a handle with several (RgState::ext maps its envs to the handle's env order, and the one-hot depth is the
 // handle's): compiled separately so that the ordinary kernel carries none of it (its 72 registers = 7 waves per SIMD are what its bandwidth rests on)
-template <int KIND, bool GROUPS>
+// BOUND (rg_obs_bind): `out` is the handle's bound observation tensor and its contents are current up to the last k_step: only the envs that k_step listed
+// (RgState::obs_list: final flag word with REDRAW or SCR_CHANGED) are encoded -- work item i is env list[i] -- and their SCR_CHANGED bit is cleared; every other
+// env's image is already what a full encode would write.  A separate instance: the ordinary kernel carries none of it.
+template <int KIND, bool GROUPS, bool BOUND = false>
 __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint32_t sflag, int with_hist, float *__restrict__ out,
                                                     uint32_t *__restrict__ err_any, int tpe, int epb, int planes_sym, int hi_prio) {
     // Wide grids: above the background generator's waves (k_regen, priority 0), which otherwise take issue slots from this bandwidth-bound pass for as long
@@ -208,7 +211,10 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
     uint8_t *luts = smem + 512;                            // glyph -> symbol id
     uint8_t *mtile = smem + 512 + 128;                     // monster type -> glyph (RgConfig::mon[].tile: indexed per lane, so not from the kernarg segment)
     uint8_t *envs = smem + 512 + 128 + 64;                 // epb x {HW staged screen bytes, ObsTabs}
-    const int tid = threadIdx.x, W = c.width, H = c.height, HW = W * H, n = S.n, Q8 = HW >> 3;
+    const int tid = threadIdx.x, W = c.width, H = c.height, HW = W * H, Q8 = HW >> 3;
+    // (BOUND: the work items are the entries of the last k_step's list)
+    const int32_t *list = BOUND ? S.obs_list + (size_t)S.obs_par * S.n : nullptr;
+    const int n = BOUND ? (int)S.obs_cnt[S.obs_par] : S.n;
     const int nrooms = c.room_num_x * c.room_num_y;
     const int symbols = c.symbols;
     for (int g = tid; g < 128; g += blockDim.x) {
@@ -229,14 +235,18 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
     const int rec_words = RG_OBS_REC_WORDS(nrooms);
     const uint32_t *rec_all = S.obs_rec;  // (rgk_obs: rec_words <= tpe, one word per thread)
     const int stride = gridDim.x * epb;
-    auto load_flag = [&](int base) -> uint32_t {
-        const int e = base + le;
-        return (le < epb && e < n) ? S.flags[e] : 0u;
+    // item -> env: the identity, or (BOUND) the list entry -- one more dependent load, fetched one iteration earlier than the flag word
+    auto load_env = [&](int base) -> int {
+        const int i = base + le;
+        if (!BOUND) return i;
+        return (le < epb && i < n) ? list[i] : 0;
     };
-    auto prefetch = [&](int base, uint32_t fl) {
+    auto load_flag = [&](int base, int e) -> uint32_t {
+        return (le < epb && base + le < n) ? S.flags[e] : 0u;
+    };
+    auto prefetch = [&](int base, int e, uint32_t fl) {
         Pre p; p.v0 = make_uint4(0, 0, 0, 0); p.rec = 0;
-        const int e = base + le;
-        if (le < epb && e < n) {
+        if (le < epb && base + le < n) {
             if (fl & RG_FLAG_REDRAW) {
                 if (lt < Q8) p.v0 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW)[lt];
                 if (lt < rec_words) p.rec = rec_all[(size_t)e * rec_words + lt];
@@ -248,16 +258,19 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
         return p;
     };
     const int base0 = blockIdx.x * epb;
-    uint32_t fl_cur = load_flag(base0), fl_nxt = load_flag(base0 + stride);
-    Pre nxt = prefetch(base0, fl_cur);
+    int e_cur = load_env(base0), e_nxt = load_env(base0 + stride), e_nn = load_env(base0 + 2 * stride);
+    uint32_t fl_cur = load_flag(base0, e_cur), fl_nxt = load_flag(base0 + stride, e_nxt);
+    Pre nxt = prefetch(base0, e_cur, fl_cur);
     for (int base = base0; base < n; base += stride) {
-        const int e = base + le;
-        const bool valid = le < epb && e < n;
+        const int e = e_cur;
+        const bool valid = le < epb && base + le < n;
         const Pre cur = nxt;
         const uint32_t fl = fl_cur;
+        e_cur = e_nxt; e_nxt = e_nn;
         fl_cur = fl_nxt;
-        fl_nxt = load_flag(base + 2 * stride);
-        if (base + stride < n) nxt = prefetch(base + stride, fl_cur);
+        fl_nxt = load_flag(base + 2 * stride, e_nxt);
+        e_nn = load_env(base + 3 * stride);
+        if (base + stride < n) nxt = prefetch(base + stride, e_cur, fl_cur);
         const bool redraw = valid && (fl & RG_FLAG_REDRAW);
         const uint4 *cell4 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW);
         const uint4 v0 = cur.v0;
@@ -371,9 +384,11 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
                 }
             }
             if (KIND == 1 && bad) { atomicOr(&S.flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
+            const uint32_t seen = BOUND ? RG_FLAG_SCR_CHANGED : 0u;  // (the bound tensor now shows this env's screen)
             if (redraw && lt == 0)  // a stale Redraw leaves the history mirror one level behind (k_step refreshes it before the next descent)
-                S.flags[e] = (fl & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | ((fl & RG_FLAG_HIST_STALE) ? 0u : RG_FLAG_HIST_DIRTY))) |
+                S.flags[e] = (fl & ~(seen | RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | ((fl & RG_FLAG_HIST_STALE) ? 0u : RG_FLAG_HIST_DIRTY))) |
                              ((fl & RG_FLAG_HIST_STALE) ? RG_FLAG_HIST_LAG : 0u) | (KIND == 1 && bad ? RG_FLAG_ERR_TILE : 0);
+            else if (BOUND && !redraw && lt == 0) atomicAnd(&S.flags[e], ~RG_FLAG_SCR_CHANGED);  // (atomic: the one-hot kind ORs its error bit into the same word)
         }
     }
 }
@@ -481,7 +496,7 @@ void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st) {
     hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RENDER_THREADS), 0, st, *S, *c);
 }
 // fused mirror refresh + encode; returns 0 if the geometry is not supported (caller falls back to k_render + encode)
-int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, int planes_sym, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, int kind, float *out, uint32_t *err_any, int planes_sym, int bound, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     int hw = c->width * c->height;
     if (hw & 7) return 0;
     if (c->room_num_x * c->room_num_y > RG_OBS_MAX_ROOMS || !S->obs_rec) return 0;  // the fused kernel's LDS overlay tables hold 64 rooms (one thread per room + the player): unfused path
@@ -504,7 +519,9 @@ int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, 
     const int hi_prio = !(c->width <= 32 && c->room_num_x * c->room_num_y <= 32);  // (rg_kernels.hip rgk_step: those configs step with k_step_w32)
 #define RG_LAUNCH_OBS(...) do { if (ev0 || ev1) hipExtLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(bthreads), (uint32_t)smem, st, ev0, ev1, 0, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym, hi_prio); \
                                else hipLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym, hi_prio); } while (0)
-    if (!kind && !groups) RG_LAUNCH_OBS(k_obs<0, false>);
+    if (bound && !groups && !kind) RG_LAUNCH_OBS(k_obs<0, false, true>);       // (rg_obs_bind: the in-place pass over the last k_step's list)
+    else if (bound && !groups) RG_LAUNCH_OBS(k_obs<1, false, true>);
+    else if (!kind && !groups) RG_LAUNCH_OBS(k_obs<0, false>);
     else if (!kind) RG_LAUNCH_OBS(k_obs<0, true>);
     else if (!groups) RG_LAUNCH_OBS(k_obs<1, false>);
     else RG_LAUNCH_OBS(k_obs<1, true>);

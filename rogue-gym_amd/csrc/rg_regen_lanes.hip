@@ -594,36 +594,6 @@ k_regen_lanes(RgState SP, RgConfig c, const uint32_t *__restrict__ q, const int3
             st_pub<true>(&SP.mon_w0[g], (uint32_t)LT(G, LT_MONW, s)); st_pub<true>(&SP.mon_hp[g], (int32_t)LT(G, LT_MONHP, s)); st_pub<true>(&SP.mon_exp[g], (uint32_t)LT(G, LT_MONEXP, s));
             st_pub<true>(&SP.gold_pos[g], (uint32_t)LT(G, LT_GOLDPOS, s)); st_pub<true>(&SP.gold_amt[g], (uint32_t)LT(G, LT_GOLDAMT, s));
         }
-        if (SP.win_rec) {
-            // the spare's window record (rg_state.h win_rec): the 5x5 around the player's placement from this lane's grid (hide_dungeon = false sets VISIBLE on
-            // rows 1..H-2 on the way out, below: here too), two words per store
-            const uint32_t vis_w = c.hide_dungeon ? 0u : (uint32_t)C_VISIBLE;
-            unsigned long long *rec8 = reinterpret_cast<unsigned long long *>(SP.win_rec + (size_t)e * RG_WREC_WORDS);
-            uint32_t inb = 0;
-#pragma unroll
-            for (int m = 0; m < 7; m++) {
-                uint32_t wd[2];
-#pragma unroll
-                for (int hh = 0; hh < 2; hh++) {
-                    uint32_t word = 0;
-#pragma unroll
-                    for (int q2 = 0; q2 < 2; q2++) {
-                        const int k = 4 * m + 2 * hh + q2;
-                        if (k < 25) {
-                            const int x = px + k % 5 - 2, y = py + k / 5 - 2;
-                            if (x >= 0 && y >= 0 && x < W && y < H) {
-                                inb |= 1u << k;
-                                word |= ((uint32_t)G.g[y * W + x] | ((y >= 1 && y < H - 1) ? vis_w : 0u)) << (16 * q2);
-                            }
-                        }
-                    }
-                    wd[hh] = word;
-                }
-                if (m == 6) { wd[0] |= POS(px, py) << 16; wd[1] = inb | RG_WREC_VALID; }
-                st_pub<true>(&rec8[m], (unsigned long long)wd[0] | ((unsigned long long)wd[1] << 32));
-            }
-            st_pub<true>(&rec8[7], 0ull);
-        }
         if (G.err) atomicOr(SP.err_any, G.err);  // (the env's flag word belongs to the k_step running beside this launch)
         LGM(G, 10);
     }

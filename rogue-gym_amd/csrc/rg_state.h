@@ -50,8 +50,6 @@ enum { RK_NORMAL = 0, RK_MAZE = 1, RK_EMPTY = 2 };
 // ... and which configs step in that class: rows of <= 96 columns with H * W <= 4096, except the 32-column grids of <= 32 rooms (k_step_w32: whole maps)
 #define RG_PARTIAL_MAPS(w, h, rooms) ((w) <= 96 && (w) * (h) <= 4096 && (rooms) <= 64 && !((w) <= 32 && (rooms) <= 32))
 
-#define RG_WREC_WORDS 16
-#define RG_WREC_VALID 0x80000000u
 #define RG_STAT_COLS 16   /* counters per row of RgState::stats: one 128-byte line */
 #define RG_NX_ASKED 1u    /* k_step: the player is next to the stairs, generate the structure (the request's streams and level are written, drained, then this) */
 #define RG_NX_CLAIMED 6u  /* k_regen is generating it */
@@ -133,13 +131,14 @@ struct RgState {
     // [rooms + 1][n]: where the overlays of the env's screen mirror stand -- the monsters' and (last row) the player's position as of the env's last Redraw,
     // 0xFFFF = none: what k_step's incremental mirror update restores before it draws the overlays anew.  NULL: more than RG_OVL_MAX rooms.
     uint16_t *ovl;
-    // window records [n][RG_WREC_WORDS] (rg_kernels.hip "the window travels with the env"): the 5x5 tiles around the player as the env's last turn left them,
-    // one 64-byte line per env -- 25 cells (u16; cell k in half k & 1 of word k >> 1), the window's centre x << 8 | y in the high half of word 12, word 13 =
-    // in-grid bits of the 25 cells | RG_WREC_VALID.  Loaded WITH the env's scalars (its address needs no player position), where the 25 scattered two-byte
-    // loads of win_load wait for them; valid iff the flag is set and the centre is the player's position.  Whoever moves the player or changes tiles without
-    // rewriting the record clears the flag.  NULL = off (ROGUE_GYM_HIP_NO_WINDOW_RECORDS).
-    uint32_t *win_rec;
-    int32_t win_check;  // development library only (ROGUE_GYM_HIP_WINREC_CHECK): every record that is used is compared with the tiles; a difference raises RG_FLAG_ERR_INTERNAL
+    // A bound observation tensor (rg_obs_bind): the envs whose screen this k_step changed -- final flag word with REDRAW or SCR_CHANGED -- appended to
+    // obs_list[obs_par][..] (one atomic per wave; count in obs_cnt[obs_par]), for the in-place observation pass right behind it (k_obs<.., BOUND>), which
+    // zeroes the other counter.  NULL = no bound tensor.
+    float *bound_gray;   // the bound tensor itself when it is a GRAY image [n][1][H][W]: the turn's incremental mirror update writes the pixels it changes straight
+                         // into it (k_step mirror_update), so such an env needs no observation pass at all; NULL otherwise
+    int32_t *obs_list;   // [2][n]
+    uint32_t *obs_cnt;   // [2]
+    int32_t obs_par;     // which half this launch writes (set by the host before every k_step)
     // action-history log (RunTime::saved_inputs, core/src/lib.rs:288): the keys of the current and of the previous episode, NULL = off
     uint8_t *klog;      // [n][2][klog_cap]
     uint32_t *klog_len; // [2][n] keys accepted in episode buffer 0 / 1 (may exceed klog_cap: the tail is then not stored)

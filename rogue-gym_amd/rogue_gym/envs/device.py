@@ -26,7 +26,11 @@ class HipVecRogueEnv:
     ACTIONS = RogueEnv.ACTIONS
 
     def __init__(self, config_dicts: Iterable[dict], max_steps: int = 1000,
-                 image_setting: ImageSetting = ImageSetting(DungeonType.GRAY, StatusFlag.EMPTY, False), device: Optional[int] = None):
+                 image_setting: ImageSetting = ImageSetting(DungeonType.GRAY, StatusFlag.EMPTY, False), device: Optional[int] = None,
+                 persistent_obs: bool = False):
+        """persistent_obs (opt-in; image settings without status planes and history plane): `self.obs` is BOUND to the stepper (rg_obs_bind) -- every step
+        keeps it current in place, rewriting only the envs whose screen changed; its contents are bit-identical to the unbound encode's.  The caller
+        must not write to `self.obs`."""
         import torch
 
         self.torch = torch
@@ -56,6 +60,9 @@ class HipVecRogueEnv:
             self._h.check(L.rg_screen(h, C.byref(p)))
             self._screen = torch.as_tensor(_DevArray(p.value, (self.num_envs, self.height, self.width), "|u1"), device=self.device)
         self._scratch = {}
+        self.persistent_obs = bool(persistent_obs)
+        if self.persistent_obs:
+            self._h.check(L.rg_obs_bind(h, int(self._sym), image_setting.status.value, int(image_setting.includes_hist), C.c_void_p(self.obs.data_ptr())))
         self._encode()
 
     @property

@@ -42,7 +42,7 @@ _lib = None
 
 _INT_FUNCS = (
     "rg_create", "rg_dims", "rg_env_dims", "rg_env_symbols", "rg_set_stream", "rg_seed", "rg_reset", "rg_step", "rg_step_prefix", "rg_step_obs_gray", "rg_step_fetch", "rg_sync", "rg_screen", "rg_hist", "rg_status", "rg_flags",
-    "rg_reward", "rg_done", "rg_set_stair_reward", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_encode_host_batch", "rg_obs_host",
+    "rg_reward", "rg_done", "rg_set_stair_reward", "rg_obs_bind", "rg_obs_gray", "rg_obs_symbol", "rg_obs_channels", "rg_fetch_states", "rg_encode_host", "rg_encode_host_batch", "rg_obs_host",
     "rg_host_alloc", "rg_dev_alloc", "rg_snapshot_take", "rg_dev_read", "rg_dev_read_rows", "rg_compact_record_bytes", "rg_pack_compact", "rg_expand_compact", "rg_comm_unique_id", "rg_comm_init", "rg_comm_destroy", "rg_comm_count", "rg_allgather_compact", "rg_status_vec", "rg_history_enable", "rg_history_keys",
     "rg_dump_history", "rg_counters", "rg_counters_ex", "rg_probe_sclk", "rg_dump_config", "rg_config_canonical", "rg_config_resolved", "rg_config_schema", "rg_debug_fetch", "rg_debug_descend", "rg_timing_enable", "rg_timing_read", "rg_timing_read_all", "rg_timing_read_samples",
 )
@@ -83,7 +83,7 @@ def load_library():
         "rg_sync": [vp],
         "rg_screen": [vp, C.POINTER(vp)], "rg_hist": [vp, C.POINTER(vp)], "rg_status": [vp, C.POINTER(vp)], "rg_flags": [vp, C.POINTER(vp)],
         "rg_reward": [vp, C.POINTER(vp)], "rg_done": [vp, C.POINTER(vp)], "rg_set_stair_reward": [vp, C.c_float],
-        "rg_obs_gray": [vp, u32, i32, vp], "rg_obs_symbol": [vp, u32, i32, vp], "rg_obs_channels": [vp, i32, u32, i32],
+        "rg_obs_bind": [vp, i32, u32, i32, vp], "rg_obs_gray": [vp, u32, i32, vp], "rg_obs_symbol": [vp, u32, i32, vp], "rg_obs_channels": [vp, i32, u32, i32],
         "rg_fetch_states": [vp, vp, vp, vp, vp],
         "rg_encode_host": [i32, vp, vp, vp, i32, i32, i32, u32, i32, i32, vp],
         "rg_encode_host_batch": [i32, i32, vp, vp, vp, i32, i32, i32, u32, i32, i32, vp],

@@ -509,11 +509,8 @@ def test_index_order_mapping_without_stair_waves_is_bit_exact(goldens):
     {"ROGUE_GYM_HIP_WAVE_REGEN": "1"},
     {"DEV": "1", "ROGUE_GYM_HIP_LANE_WAVES": "3", "ROGUE_GYM_HIP_LANE_EVERY": "3"},
     {"ROGUE_GYM_HIP_SP_SLOTS": "1"},
-    {"DEV": "1", "ROGUE_GYM_HIP_WINREC_CHECK": "1"},
-    {"ROGUE_GYM_HIP_NO_WINDOW_RECORDS": "1"},
 ], ids=["dev build: round-2/3 generator scheduling", "dev build: sparse generator launches", "24 envs per step wave", "spares one level per wave (k_regen)",
-        "dev build: three level-per-lane waves every third step", "one spare per env",
-        "dev build: every window record that is used is compared with the tiles", "no window records"])
+        "dev build: three level-per-lane waves every third step", "one spare per env"])
 def test_results_do_not_depend_on_where_the_background_generator_runs(knobs):
     """When and where the spare levels are regenerated (behind which kernel, how often, at which priority, how many envs per generator wave) and how many
     envs a step wave holds decide only whether an auto-reset finds its spare or generates inline -- never what the env looks like afterwards: the
@@ -982,5 +979,51 @@ def test_step_fetch_equals_step_sync_fetch(goldens, n, device_screens):
     assert b"Invalid input" in L.rg_last_error(a.h)
     good = np.full(n, ord("h"), np.uint8)
     a.check(L.rg_step_fetch(a.h, good.ctypes.data, n, None, None, status.ctypes.data, flags.ctypes.data))  # (the error word was cleared)
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,sym,n", [("mini", False, 16384), ("default", False, 4096), ("nohide", True, 512)], ids=["mini gray", "default 80x24 gray", "nohide one-hot"])
+def test_bound_observation_tensor_is_the_full_encode(goldens, name, sym, n):
+    """rg_obs_bind (HipVecRogueEnv(persistent_obs=True)): the bound tensor is kept current IN PLACE -- only the envs whose screen changed since the last call are
+    rewritten (a Redraw drawn from the tiles, or bytes the turn wrote into the mirror itself: RG_FLAG_SCR_CHANGED) -- and must hold, after every step, exactly what
+    the unbound call writes: the whole batch compared bit for bit at every step over moves, runs, searches, descents, 30-step episodes, a reset of the batch, and
+    with the calls that consume Redraw flags behind the bound tensor's back mixed in (reading the screen mirror, an observation of another kind into another
+    buffer): the next bound call then has to encode every env again."""
+    import ctypes as C
+
+    import torch
+    from rogue_gym.envs import DungeonType, HipVecRogueEnv, ImageSetting, StatusFlag
+
+    st = ImageSetting(DungeonType.SYMBOL if sym else DungeonType.GRAY, StatusFlag.EMPTY, False)
+    cfgs = [dict(goldens["configs"][name], seed=i % 5000) for i in range(n)]
+    a = HipVecRogueEnv(cfgs, max_steps=30, image_setting=st, persistent_obs=True)
+    b = HipVecRogueEnv(cfgs, max_steps=30, image_setting=st)
+    assert torch.equal(a.obs, b.obs)
+    table = torch.tensor(list(b"hjklyubnhjklyubnhjklyubnHJKL>>ss."), dtype=torch.uint8, device=a.device)
+    gen = torch.Generator(device=a.device).manual_seed(5)
+    other = torch.empty((n, a._h.L.rg_obs_channels(a._h.h, int(not sym), 0, 0), a.height, a.width), dtype=torch.float32, device=a.device)
+    changed = []
+    for t in range(160):
+        keys = table[torch.randint(0, len(table), (n,), generator=gen, device=a.device)].contiguous()
+        before = a.obs.clone() if t % 16 == 5 else None
+        oa, ra, da = a.step_keys(keys)
+        ob, rb, db = b.step_keys(keys)
+        assert oa.data_ptr() == a.obs.data_ptr()
+        assert torch.equal(oa, ob), (t, int((oa != ob).flatten(1).any(1).sum()))
+        assert torch.equal(ra, rb) and torch.equal(da, db)
+        if before is not None:
+            changed.append(float((before != oa).flatten(1).any(1).float().mean()))
+        if t % 37 == 11:
+            _ = a.screen, b.screen                      # flushes the pending render: Redraw flags consumed without the bound tensor
+        if t % 53 == 17:
+            fn = a._h.L.rg_obs_gray if sym else a._h.L.rg_obs_symbol   # an observation of the OTHER kind, into another buffer
+            for env in (a, b):
+                env._h.check(fn(env._h.h, 0, 0, C.c_void_p(other.data_ptr())))
+        if t == 90:
+            assert torch.equal(a.reset(), b.reset())
+    assert 0.05 < sum(changed) / len(changed) < 0.9, changed   # (the premise: a good part of the envs of a step change nothing on screen)
+    a.check_errors()
     a.close()
     b.close()

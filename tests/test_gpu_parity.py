@@ -232,43 +232,6 @@ def test_mirror_kept_by_the_turn_equals_the_mirror_drawn_from_the_tiles(goldens,
     b.close()
 
 
-@pytest.mark.parametrize("name,n,max_steps", [("mini", 65536, 40), ("default", 16384, 50), ("nohide", 4096, 12)], ids=["mini", "default 80x24", "nohide, 12-step episodes"])
-def test_window_records_equal_windows_loaded_from_the_tiles(goldens, name, n, max_steps):
-    """The 5x5 window of a turn comes from the env's window record (one line per env, written by the previous turn's tail, by whoever made the level, by the
-    spare hand-off) instead of 25 scattered tile loads behind the scalars.  Against a handle without records (ROGUE_GYM_HIP_NO_WINDOW_RECORDS: every turn loads
-    its window from the tiles): screen, history, status and flags of every env, and -- every 20th step -- the tile grids and scalars of a sample, over moves
-    in all eight directions, run keys, searches, rooms entered and left, descents and short episodes (resets that take spares and resets that generate inline)."""
-    import os
-
-    from rogue_gym_python import _rogue_gym as inner
-
-    steps = 200
-    cfgs = [json.dumps(dict(goldens["configs"][name], seed=i % 9000)) for i in range(n)]
-    a = inner._Handle(cfgs, max_steps, auto_reset=True)
-    os.environ["ROGUE_GYM_HIP_NO_WINDOW_RECORDS"] = "1"
-    try:
-        b = inner._Handle(cfgs, max_steps, auto_reset=True)
-    finally:
-        del os.environ["ROGUE_GYM_HIP_NO_WINDOW_RECORDS"]
-    rng = np.random.RandomState(77)
-    table = np.frombuffer(b"hjklyubnhjklyubnhjklyubnhjklyubnHJKLYUBN>>sss.", np.uint8)
-    sample = list(range(0, n, max(1, n // 97)))
-    for t in range(steps):
-        keys = np.ascontiguousarray(table[rng.randint(0, len(table), n)])
-        for h in (a, b):
-            h.check(h.L.rg_step(h.h, keys.ctypes.data, 0))
-        if t % 2 == 1:
-            for x, y, what in zip(a.fetch(), b.fetch(), ("screen", "hist", "status", "flags")):
-                assert np.array_equal(x, y), (t, what, [i for i in range(n) if not np.array_equal(x[i], y[i])][:8])
-        if t % 20 == 19:
-            for i in sample:
-                (da, ca), (db, cb) = a.debug_state(i), b.debug_state(i)
-                assert np.array_equal(ca, cb), (t, i, "tiles")
-                assert (da.px, da.py, da.hp, da.dungeon_level, list(da.rng)) == (db.px, db.py, db.hp, db.dungeon_level, list(db.rng)), (t, i, "scalars")
-    a.close()
-    b.close()
-
-
 def test_urgent_spares_of_envs_that_die_fast(goldens):
     """The bulk of the consumed spares is rebuilt every 16th step (one level per lane, rg_regen_lanes.hip); an env that is down to its last ready spare gets
     one built beside the very next step by the wave-per-level producer (k_regen, spares == 2).  Episodes of 3 steps consume a spare every 3 steps -- five
