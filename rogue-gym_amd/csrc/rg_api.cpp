@@ -35,6 +35,7 @@ void rgk_regen(const RgState *SP, const RgConfig *c, int bulk, int spares, const
 void rgk_regen_gate(const uint32_t *mark, uint32_t target, uint32_t *err_any, hipStream_t st);
 void rgk_export(const RgState *S, uint32_t *err_any, void *o_screen, void *o_hist, void *o_status, void *o_flags, uint32_t *o_err, hipStream_t st);
 int rgk_regen_lanes_supported(const RgConfig *c, int maze_cap);
+int rgk_step_bound_capable(const RgConfig *c);
 int rgk_regen_lanes(const RgState *SP, const RgConfig *c, uint32_t *q, int32_t *list, int bulk, int waves, int slots, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 void rgk_debug_descend(const RgState *S, const RgConfig *c, hipStream_t st);
 void rgk_render(const RgState *S, const RgConfig *c, hipStream_t st);
@@ -703,7 +704,7 @@ static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, fl
         TimedLaunch t(h, 2, true);
         // the bound tensor with its own image setting: in place (only the envs whose screen changed), once its contents are known to be current
         const bool bound = h->bound_out && out_dev == h->bound_out && kind == h->bound_kind && (status_flag & 0x1ffu) == 0 && !with_hist;
-        if (rgk_obs(&h->S, &h->cfg, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->d_err, h->planes_sym, bound && h->bound_valid && h->bound_steps == 1, h->stream, t.start_ev(), t.stop_ev())) {
+        if (rgk_obs(&h->S, &h->cfg, status_flag & 0x1ffu, with_hist ? 1 : 0, kind, out_dev, h->d_err, h->planes_sym, bound && h->S.obs_list && h->bound_valid && h->bound_steps == 1, h->stream, t.start_ev(), t.stop_ev())) {
             HIPCHK(h, hipGetLastError());
             h->render_pending = false;
             h->bound_valid = bound;  // (any other observation call consumed Redraw flags the bound tensor has not seen)
@@ -726,6 +727,8 @@ int rg_obs_bind(rg_t *h, int kind, uint32_t status_flag, int with_hist, float *o
     if (!h->sub.empty()) { h->err = "rg_obs_bind: not for a handle with config groups"; return 1; }
     if (out_dev && ((status_flag & 0x1ffu) || with_hist || (kind != 0 && kind != 1))) { h->err = "rg_obs_bind: gray or symbol image without status planes and history plane"; return 1; }
     HIPCHK(h, hipSetDevice(h->device));
+    const bool capable = rgk_step_bound_capable(&h->cfg) != 0;  // (else: bound, but every call re-encodes every env)
+    if (!capable) { h->S.obs_list = nullptr; h->S.obs_cnt = nullptr; h->S.bound_gray = nullptr; h->bound_out = out_dev; h->bound_kind = kind; h->bound_valid = false; h->bound_steps = 0; return 0; }
     if (out_dev && !h->obs_list_mem) {  // the work list k_step leaves for the in-place pass (rg_state.h obs_list)
         if (!dev_alloc(h, &h->obs_list_mem, 2 * (size_t)h->S.n) || !dev_alloc(h, &h->obs_cnt_mem, 2)) return 1;
     }

@@ -2343,6 +2343,7 @@ __device__ __forceinline__ uint32_t base_glyph(const RgConfig &c, uint32_t v, in
 #define OVL_NONE 0xffffu
 // Returns false -- nothing written -- when a cell it would have to write lies outside the window: its tile is not at hand, and a load here would wait for every
 // store of the turn; the Redraw then goes to the observation pass as before.
+template <bool BND>  // BND: the handle has a bound observation tensor (rg_obs_bind) -- a step-kernel instance of its own, so that the ordinary one carries none of it
 __device__ __forceinline__ bool mirror_update(const RgState &S, const RgConfig &c, const Env &E, const Win &w, uint32_t react, int rid0) {
     const int W = c.width, nrooms = c.room_num_x * c.room_num_y, n = E.n;
     // (the env index through an opaque move: the addresses below are then computed HERE -- left alone, the compiler computes `S.ovl + ... + e`, `S.hist + e * hw`
@@ -2352,9 +2353,12 @@ __device__ __forceinline__ bool mirror_update(const RgState &S, const RgConfig &
     uint8_t *scr = S.screen + (size_t)e * S.hw;
     // a bound GRAY observation tensor (rg_obs_bind): every byte written to the mirror below is also written to the env's image as the f32 the observation pass
     // would encode it to (the wave's LDS table, filled at the top of step_wave: the same expression) -- the env then needs no pass at all
-    float *og = S.bound_gray ? S.bound_gray + (size_t)e * S.hw : nullptr;
+    float *og = (BND && S.bound_gray) ? S.bound_gray + (size_t)e * S.hw : nullptr;
     const __attribute__((address_space(3))) float *lutg = (const __attribute__((address_space(3))) float *)(g_smem + STEP_LDS_LUT);
-    auto put = [&](int idx, uint32_t g) { scr[idx] = (uint8_t)g; if (og) og[idx] = lutg[g & 0x7fu]; };
+    auto put = [&](int idx, uint32_t g) {
+        scr[idx] = (uint8_t)g;
+        if constexpr (BND) { if (og) og[idx] = lutg[g & 0x7fu]; }
+    };
     // (the lane's LDS columns from the lane id, here: a pointer carried from the top of the wave is one more spilled register to reload)
     int ln = threadIdx.x;
     asm volatile("" : "+v"(ln));
@@ -2552,7 +2556,7 @@ __device__ __forceinline__ void take_spares(const RgState &S, const RgState *__r
 
 // One wave's share of a step: lane i plays the key of env `e` (any env index -- the lanes of a wave need not hold consecutive envs), `valid`
 // lanes only; the other lanes still take part in the wave-cooperative services.
-template <int BW, int GM>
+template <int BW, int GM, bool BND = false>
 __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__restrict__ SPd, const RgConfig &c, const uint8_t *__restrict__ keys, int use_spares, int stage_off,
                                           const int e, const bool valid_in, const int stair_role) {
     // stair_role: 0 = no stair isolation, 1 = this wave serves listed (on-stairs) envs, 2 = index-order wave: listed envs are somebody else's
@@ -2633,7 +2637,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     // Redraw (S.ovl) -- parked here from the first load round to the incremental mirror update at the end of the turn
     lds_u32 *ovl_l = (lds_u32 *)(g_smem + STEP_LDS_OVL) + lane;
     ovl_l[0] = 0;
-    if (S.bound_gray) {  // glyph -> gray value as the observation pass encodes it (rg_obs.hip k_obs `lutf`, python/src/lib.rs:84: the same single division)
+    if (BND && S.bound_gray) {  // glyph -> gray value as the observation pass encodes it (rg_obs.hip k_obs `lutf`, python/src/lib.rs:84: the same single division)
         __attribute__((address_space(3))) float *lutg = (__attribute__((address_space(3))) float *)(g_smem + STEP_LDS_LUT);
         lutg[lane] = (float)(uint8_t)tile_to_sym((uint32_t)lane) / (float)(uint8_t)c.symbols;
         lutg[lane + 64] = (float)(uint8_t)tile_to_sym((uint32_t)lane + 64u) / (float)(uint8_t)c.symbols;
@@ -2814,7 +2818,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             flags = (react & 0x7f00u);                       // message flags of this key only
             if (react & R_REDRAW) flags |= RG_FLAG_REDRAW | ((react & R_HIST_STALE) ? RG_FLAG_HIST_STALE : 0);
             else flags |= old_flags & (RG_FLAG_REDRAW | RG_FLAG_HIST_STALE);
-            flags |= old_flags & (RG_FLAG_HIST_LAG | RG_FLAG_HIST_DIRTY | RG_FLAG_SCR_CHANGED);
+            flags |= old_flags & (RG_FLAG_HIST_LAG | RG_FLAG_HIST_DIRTY | (BND ? RG_FLAG_SCR_CHANGED : 0u));
             if ((react & R_HIST_CHANGED) || descends) flags |= RG_FLAG_HIST_DIRTY;
             if (react & R_STATUS) write_status(S, c, E);
             if (ui_dead) flags |= RG_FLAG_DEAD;
@@ -2832,7 +2836,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
                 !(old_flags & (RG_FLAG_REDRAW | RG_FLAG_HIST_STALE | RG_FLAG_HIST_LAG | RG_FLAG_HIST_DIRTY)) && !(ovl_l[0] >> 31)) {
                 // (SCR_CHANGED: bytes of the mirror changed without a Redraw flag -- what a bound observation tensor, rg_obs_bind, re-encodes this env for)
                 // (... unless the update wrote the image's pixels too: a bound gray tensor)
-                if (mirror_update(S, c, E, w, react, room_id_of(c, w.ox, w.oy))) flags = (flags & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY)) | (S.bound_gray ? 0u : RG_FLAG_SCR_CHANGED);
+                if (mirror_update<BND>(S, c, E, w, react, room_id_of(c, w.ox, w.oy))) flags = (flags & ~(RG_FLAG_REDRAW | RG_FLAG_HIST_DIRTY)) | ((!BND || S.bound_gray) ? 0u : RG_FLAG_SCR_CHANGED);
                 inc_done = true;  // (the overlays' positions and how they show are recorded either way)
             }
         }
@@ -2848,7 +2852,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     // end: its return value is first needed behind all the stores of the tail, and vmcnt being in order it is there by then (asked for at the end, the wave
     // waited 2.6 us for it: it returns behind every store issued before it).
     bool pend = false; uint64_t pm = 0; uint32_t lbase = 0;
-    if (S.obs_list) {
+    if (BND && S.obs_list) {
         const uint32_t fw = (live ? ((terminal && c.auto_reset) ? RG_FLAG_REDRAW : flags) : old_flags);
         pend = valid && (fw & (RG_FLAG_REDRAW | RG_FLAG_SCR_CHANGED));
         pm = __ballot(pend);
@@ -2958,7 +2962,7 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
             if (ask) __hip_atomic_store(&S.nx_state[et], RG_NX_ASKED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (pm) {
+    if (BND && pm) {
         const uint32_t lb = uni(lbase);  // (lane 0's: read with every lane active, not inside the `pend` branch -- readfirstlane takes the first ACTIVE lane)
         if (pend) S.obs_list[(size_t)S.obs_par * S.n + lb + lanes_below(pm)] = et;
     }
@@ -2984,12 +2988,12 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
 
 // (the body is spelled out twice -- below for the capped W <= 32 instance -- rather than shared through a device function: routing the template through
 // one more inlined call changed the allocation of the wider instances for the worse, 141 -> 153 us on the default 80x24 dungeon)
-#define RG_STEP_BLOCK_BODY(BWV, GMV) \
+#define RG_STEP_BLOCK_BODY(BWV, GMV, BNDV) \
     __builtin_amdgcn_s_setprio(3); \
     const int lane = threadIdx.x; \
     if (blockIdx.x == 0 && lane == 0) { \
         stair_recycle(S); \
-        if (S.obs_cnt) S.obs_cnt[S.obs_par ^ 1] = 0;  /* (rg_state.h obs_list: the half the NEXT k_step appends to) */ \
+        if (BNDV && S.obs_cnt) S.obs_cnt[S.obs_par ^ 1] = 0;  /* (rg_state.h obs_list: the half the NEXT k_step appends to) */ \
         __hip_atomic_store(S.launch_mark, (uint32_t)S.stair_gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  /* this launch has started: k_regen_gate */ \
     } \
     const bool stair = parity >= 0 && (int)blockIdx.x < STAIR_BLOCKS; \
@@ -3001,36 +3005,38 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
         bool v; int e; \
         if (stair) { e = list[i0]; v = lane == 0 && e < S.n_keys && keys[e] == '>'; } \
         else { v = lane < epw && i0 + lane < items; e = v ? i0 + lane : 0; } \
-        if (!stair || __any(v)) step_wave<BWV, GMV>(S, SPd, c, keys, use_spares, stage_off, e, v, parity >= 0 ? (stair ? 1 : 2) : 0); \
+        if (!stair || __any(v)) step_wave<BWV, GMV, BNDV>(S, SPd, c, keys, use_spares, stage_off, e, v, parity >= 0 ? (stair ? 1 : 2) : 0); \
         if (!stair || items <= STAIR_BLOCKS) break; \
         __syncthreads(); \
         uint32_t t = 0; \
         if (lane == 0) t = atomicAdd(next, 1u); \
         i0 = STAIR_BLOCKS + (int)uni(t); \
     }
-template <int BW>
+template <int BW, bool BND = false>
 __global__ void __launch_bounds__(WAVE) k_step(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int stage_off, int epw,
                                                int parity) {
     // this block's work: ONE call site of the turn code, whatever the role.  Stair block b looks at entry b of the stair list; entries beyond the first
     // STAIR_BLOCKS are handed out one at a time through a counter, so that a block busy with a descent (60 us) never has a second one queued behind
     // it while its neighbours sit idle.  An entry whose env does not press '>' stays with its index-order wave (step_wave's rule, applied here before
     // anything else of the env is loaded: such a block is gone in ~2 us).
-    RG_STEP_BLOCK_BODY(BW, (BW != 0 ? 1 : 0))
+    RG_STEP_BLOCK_BODY(BW, (BW != 0 ? 1 : 0), BND)
 }
 // The W <= 32 instance with the register allocation capped for TWO waves per SIMD (256 VGPRs).  With the 5x5 window in LDS it needs ~250: told to,
 // the allocator fits it without a spill (left alone it lands on either side of the line from build to build).  Every block of a 65 536-env launch
 // (1024 index-order + the stair blocks) is then resident from t = 0.  At one wave per SIMD the ~20 stair waves that really descend kept their SIMDs
 // for the whole launch, as many index-order blocks started only when the first waves ended (33-38 us) and finished last (84 us against 57-67 us
 // for every other wave).  The wider instances spill under the cap (15-136 VGPRs: a measured loss) and keep their natural allocation.
+// (BND: the instance for handles with a bound observation tensor, rg_obs_bind -- the list of redrawn envs, the gray pixels of the incremental mirror update)
+template <bool BND>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_step_w32(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int stage_off, int epw, int parity) {
-    RG_STEP_BLOCK_BODY(0, 0)
+    RG_STEP_BLOCK_BODY(0, 0, BND)
 }
 // More than 64 rooms (only possible on wide grids: 65 rooms need W >= 65): the generic row-width class with the 384-room generator.  Its LDS
 // monster table (a column of `rooms` words per lane) exceeds the 64 KB default, see rgk_step.
 __global__ void __launch_bounds__(WAVE) k_step_huge(RgState S, const RgState *__restrict__ SPd, RgConfig c, const uint8_t *__restrict__ keys, int use_spares, int stage_off,
                                                     int epw, int parity) {
-    RG_STEP_BLOCK_BODY(4, 2)
+    RG_STEP_BLOCK_BODY(4, 2, false)
 }
 #undef RG_STEP_BLOCK_BODY
 
@@ -3063,8 +3069,10 @@ int rgk_step_epw(int n, int slots_per_simd) {
     if (epw_env >= 16 && epw_env <= 64) epw = epw_env;  // (>= 16: S.stats has one row per block of the largest grid, STAIR_BLOCKS + ceil(n / 16); rg_api.cpp)
     return epw;
 }
-int rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-    int hw = c->width * c->height;
+// LDS of one step wave for this config, and how many of them a CU holds when every block of a launch is resident (two per SIMD for the capped W <= 32
+// instance, else one): what the level-per-lane producer must leave free on a CU (rg_regen_lanes.hip lanes_plan)
+static size_t step_lds(const RgConfig *c, int *stage_off_out) {
+    const int hw = c->width * c->height;
     size_t stage = GEN_SLOT_BYTES(hw, c->room_num_x * c->room_num_y);  // the generator's staging grid + tables (inline descents, spare misses), shared with ...
     const bool n32 = c->width <= 96 && hw <= 4096;  // BFS rows as 32-bit words in registers (bfs_rows_n32): no LDS planes
     const size_t bfs_hi = n32 ? 0 : (size_t)10 * ((c->width + 63) / 64) * WAVE * 8;  // ... the BFS high distance planes
@@ -3072,7 +3080,24 @@ int rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const u
     stage = (stage + 15) & ~(size_t)15;
     // the per-lane columns first (STEP_LDS_*: window, parked overlay words, monster cache), then the staging area
     const int stage_off = STEP_LDS_MC + c->room_num_x * c->room_num_y * WAVE * 4;
-    const size_t smem = (size_t)stage_off + stage;
+    if (stage_off_out) *stage_off_out = stage_off;
+    return (size_t)stage_off + stage;
+}
+size_t rgk_step_lds_per_cu(const RgConfig *c) { return step_lds(c, nullptr) * ((c->width <= 32 && gen_mode_of(c) == 0) ? 8 : 4); }
+// the step-kernel classes that have an instance for a bound observation tensor (rg_obs_bind): the capped W <= 32 one and the 33..96-column one (BASELINE.json's
+// mini and default grids); elsewhere a bound tensor is simply re-encoded in full
+int rgk_step_bound_capable(const RgConfig *c) {
+    const int hw = c->width * c->height;
+    if (gen_mode_of(c) == 2) return 0;
+    if (c->width <= 32 && gen_mode_of(c) == 0) return 1;
+    return (c->width <= 96 && hw <= 4096 && c->width > 64) ? 1 : 0;
+}
+int rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const uint8_t *keys, int use_spares, int parity, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    const bool bnd = S->obs_list != nullptr && rgk_step_bound_capable(c);
+    int hw = c->width * c->height;
+    const bool n32 = c->width <= 96 && hw <= 4096;
+    int stage_off = 0;
+    const size_t smem = step_lds(c, &stage_off);
     const int epw = rgk_step_epw(S->n, (c->width <= 32 && gen_mode_of(c) == 0) ? 2 : 1);
     // parity >= 0: stair isolation with the list the last render / observation pass wrote into set `parity`
     const int nb = (S->n + epw - 1) / epw;
@@ -3090,9 +3115,9 @@ int rgk_step(const RgState *S, const RgState *SP_dev, const RgConfig *c, const u
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_huge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess && dev >= 0 && dev < 64) raised[dev] = smem;
         }
         RG_LAUNCH_STEP(k_step_huge);
-    } else if (c->width <= 32 && gen_mode_of(c) == 0) RG_LAUNCH_STEP(k_step_w32);   // (its generator instance holds 32-bit room sets)
+    } else if (c->width <= 32 && gen_mode_of(c) == 0) { if (bnd) RG_LAUNCH_STEP(k_step_w32<true>); else RG_LAUNCH_STEP(k_step_w32<false>); }   // (its generator instance holds 32-bit room sets)
     else if (n32 && c->width <= 64) RG_LAUNCH_STEP(k_step<1>);                        // ... a 32-column grid with 33..64 rooms (e.g. 32x48 with 8x5) steps here
-    else if (n32) RG_LAUNCH_STEP(k_step<2>);
+    else if (n32) { if (bnd) RG_LAUNCH_STEP((k_step<2, true>)); else RG_LAUNCH_STEP(k_step<2>); }
     else if (c->width <= 128) RG_LAUNCH_STEP(k_step<3>);
     else RG_LAUNCH_STEP(k_step<4>);
 #undef RG_LAUNCH_STEP

@@ -639,6 +639,7 @@ k_regen_lanes(RgState SP, RgConfig c, const uint32_t *__restrict__ q, const int3
 extern "C" {
 // Geometry of a launch for this config; lanes = 0 when the level-per-lane producer does not apply (more than 32 rooms: the room sets are 32-bit masks;
 // a grid so large that fewer than 16 lanes' worth fits the CU's LDS) -- the caller then keeps the wave-per-level producer.
+size_t rgk_step_lds_per_cu(const RgConfig *c);  // rg_kernels.hip
 struct RgLanesPlan { int lanes, lane_stride, tab_off, stk_off, smem; };
 static RgLanesPlan lanes_plan(const RgConfig *c, int maze_cap) {
     RgLanesPlan p = {0, 0, 0, 0, 0};
@@ -646,7 +647,15 @@ static RgLanesPlan lanes_plan(const RgConfig *c, int maze_cap) {
     if (nr > 32) return p;
     const int stride = ((hw * 2 + 3) & ~3) + 4;            // an odd number of 4-byte words when hw is even: conflict-free lock-step accesses
     const int fixed = LG_TABS_PER_ROOM * nr * WAVE * 4 + maze_cap * WAVE * 2 + 64;
-    const int budget = 150 * 1024;                          // of the CU's 160 KB: the step waves beside it keep theirs
+    // Of the CU's 160 KB, what the step waves of a fully resident launch leave (four waves of k_step<2> on the 80x24 dungeon: 58 KB; eight of the capped
+    // W <= 32 instance): with 150 KB for a producer wave whatever the config (round 5) a CU holding one had room for no step wave at all -- 25 CUs out of
+    // 256 on the default workload, ~70 of its 993 one-per-SIMD step waves waiting for a second round: k_step<2> p99 153 us / max 380 us against 96 us p50
+    // (profiles/r06_experiments.txt).  Fewer lanes per wave is the price (80x24: 36 -> 24).
+    int budget = 160 * 1024 - (int)rgk_step_lds_per_cu(c) - 1024;
+    if (budget > 150 * 1024) budget = 150 * 1024;
+#ifdef RG_DEV_KNOBS
+    if (const char *ev = getenv("ROGUE_GYM_HIP_LANE_LDS_KB")) budget = atoi(ev) * 1024;  // (the sweep of profiles/r06_experiments.txt)
+#endif
     int lanes = (budget - fixed) / stride;
     if (lanes > WAVE) lanes = WAVE;
     lanes &= ~3;

@@ -103,7 +103,12 @@ def load_library():
         "rg_config_resolved": [C.c_char_p, C.c_char_p, sz], "rg_config_schema": [C.c_char_p, sz, C.POINTER(sz)],
         "rg_debug_fetch": [vp, i32, C.POINTER(RgDebugState), vp], "rg_debug_descend": [vp],
     }
+    # (entry points added in round 6: a library named by ROGUE_GYM_HIP_LIB -- an older build in a same-box A/B run -- may lack them; the product library
+    # exports every symbol of the header, tests/test_cabi_load.py)
+    optional = {"rg_timing_read_samples", "rg_obs_bind"} if os.environ.get("ROGUE_GYM_HIP_LIB") else set()
     for name, argtypes in sig.items():
+        if name in optional and not hasattr(L, name):
+            continue
         getattr(L, name).argtypes = argtypes
     L.rg_destroy.restype = None
     L.rg_host_free.restype = None
@@ -112,6 +117,8 @@ def load_library():
     L.rg_build_id.restype = C.c_char_p
     L.rg_build_id.argtypes = []
     for name in _INT_FUNCS:
+        if name in optional and not hasattr(L, name):
+            continue
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
