@@ -74,7 +74,7 @@ struct rg_handle {
     bool render_pending = false;
     // rg_obs_bind: the caller's standing observation tensor and whether its contents are the current screens of every env up to the SCR_CHANGED / REDRAW flags
     float *bound_out = nullptr; int bound_kind = 0; bool bound_valid = false;
-    int32_t *obs_list_mem = nullptr; uint32_t *obs_cnt_mem = nullptr;
+    int32_t *obs_list_mem = nullptr; uint32_t *obs_cnt_mem = nullptr; float *gray_lut_mem = nullptr;
     int bound_steps = 0;   // k_step launches since the bound tensor was last written: its in-place pass works from the list of exactly ONE
     int stair_gen = 0;           // producers of the stair set launched so far (k_build, k_step, the debug descent; rg_state.h)
     float *obs_scratch = nullptr;  // rg_obs_host: device-side observation buffer, kept between calls
@@ -723,6 +723,15 @@ static int obs_common(rg_t *h, uint32_t status_flag, int with_hist, int kind, fl
     HIPCHK(h, hipGetLastError());
     return 0;
 }
+// Symbol::from_tile (core/src/symbol.rs:17-40) on the host, as rg_device.h tile_to_sym; 255 = not a symbol
+static uint32_t host_tile_to_sym(uint32_t t) {
+    switch (t) {
+    case ' ': return 0; case '@': return 1; case '#': return 2; case '.': return 3; case '-': case '|': return 4;
+    case '%': return 5; case '+': return 6; case '^': return 7; case '!': return 8; case '?': return 9; case ']': return 10;
+    case ')': return 11; case '/': return 12; case '*': return 13; case ':': return 14; case '=': return 15; case ',': return 16;
+    default: return (t >= 'A' && t <= 'Z') ? t - 'A' + 17 : 255u;
+    }
+}
 int rg_obs_bind(rg_t *h, int kind, uint32_t status_flag, int with_hist, float *out_dev) {
     if (!h->sub.empty()) { h->err = "rg_obs_bind: not for a handle with config groups"; return 1; }
     if (out_dev && ((status_flag & 0x1ffu) || with_hist || (kind != 0 && kind != 1))) { h->err = "rg_obs_bind: gray or symbol image without status planes and history plane"; return 1; }
@@ -735,6 +744,13 @@ int rg_obs_bind(rg_t *h, int kind, uint32_t status_flag, int with_hist, float *o
     if (out_dev) HIPCHK(h, hipMemsetAsync(h->obs_cnt_mem, 0, 8, h->stream));
     h->S.obs_list = out_dev ? h->obs_list_mem : nullptr; h->S.obs_cnt = out_dev ? h->obs_cnt_mem : nullptr;
     h->S.bound_gray = (out_dev && kind == 0) ? out_dev : nullptr;  // (k_step's mirror update writes a gray image's changed pixels itself)
+    if (h->S.bound_gray && !h->gray_lut_mem) {  // ... through this table: the value k_obs encodes a glyph to (rg_obs.hip `lutf`: the same single IEEE division)
+        float lut[128];
+        for (uint32_t g = 0; g < 128; g++) lut[g] = (float)(uint8_t)host_tile_to_sym(g) / (float)(uint8_t)h->cfg.symbols;
+        if (!dev_alloc(h, &h->gray_lut_mem, 128)) return 1;
+        HIPCHK(h, hipMemcpy(h->gray_lut_mem, lut, sizeof lut, hipMemcpyHostToDevice));
+    }
+    h->S.gray_lut = h->gray_lut_mem;
     h->bound_out = out_dev; h->bound_kind = kind; h->bound_valid = false; h->bound_steps = 0;
     return 0;
 }

@@ -2637,10 +2637,13 @@ __device__ __forceinline__ void step_wave(const RgState &S, const RgState *__res
     // Redraw (S.ovl) -- parked here from the first load round to the incremental mirror update at the end of the turn
     lds_u32 *ovl_l = (lds_u32 *)(g_smem + STEP_LDS_OVL) + lane;
     ovl_l[0] = 0;
-    if (BND && S.bound_gray) {  // glyph -> gray value as the observation pass encodes it (rg_obs.hip k_obs `lutf`, python/src/lib.rs:84: the same single division)
-        __attribute__((address_space(3))) float *lutg = (__attribute__((address_space(3))) float *)(g_smem + STEP_LDS_LUT);
-        lutg[lane] = (float)(uint8_t)tile_to_sym((uint32_t)lane) / (float)(uint8_t)c.symbols;
-        lutg[lane + 64] = (float)(uint8_t)tile_to_sym((uint32_t)lane + 64u) / (float)(uint8_t)c.symbols;
+    if (BND && S.bound_gray) {
+        // glyph -> gray value as the observation pass encodes it (rg_obs.hip k_obs `lutf`, python/src/lib.rs:84), for the pixels mirror_update writes into the bound
+        // tensor: the host's table straight into LDS (computed per wave -- two tile_to_sym + two IEEE divisions per lane -- it cost every wave 1.1 us)
+        typedef const __attribute__((address_space(1))) void *gptr;
+        typedef __attribute__((address_space(3))) void *lptr;
+        __builtin_amdgcn_global_load_lds((gptr)(S.gray_lut + lane), (lptr)(g_smem + STEP_LDS_LUT), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(S.gray_lut + 64 + lane), (lptr)(g_smem + STEP_LDS_LUT + 256), 4, 0, 0);
     }
     if (S.ovl && lane < RG_MAX_ENEMY_KINDS + 6)
         ((__attribute__((address_space(3))) uint8_t *)(g_smem + STEP_LDS_OVL + (RG_OVL_MAX + 6) * WAVE * 4))[lane] = (uint8_t)glyph_r;

@@ -136,6 +136,7 @@ struct RgState {
     // zeroes the other counter.  NULL = no bound tensor.
     float *bound_gray;   // the bound tensor itself when it is a GRAY image [n][1][H][W]: the turn's incremental mirror update writes the pixels it changes straight
                          // into it (k_step mirror_update), so such an env needs no observation pass at all; NULL otherwise
+    const float *gray_lut;  // [128] glyph -> gray value as the observation pass encodes it (rg_obs_bind fills it on the host: symbol id / symbols, one IEEE division)
     int32_t *obs_list;   // [2][n]
     uint32_t *obs_cnt;   // [2]
     int32_t obs_par;     // which half this launch writes (set by the host before every k_step)

@@ -79,8 +79,15 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
     table = torch.tensor(list(keys_table), dtype=torch.uint8, device=dev)
     gen = torch.Generator(device=dev).manual_seed(0)
     keys = table[torch.randint(0, len(keys_table), (64, n), generator=gen, device=dev)].contiguous()
+    bound = None
+    if os.environ.get("RG_PROF_BOUND"):  # the step-kernel instance of a handle with a bound observation tensor (rg_obs_bind): its tensor is kept current after every step
+        bound = torch.empty((n, 1, h.height, h.width), dtype=torch.float32, device=dev)
+        h.check(L.rg_obs_bind(h.h, 0, 0, 0, C.c_void_p(bound.data_ptr())))
+        h.check(L.rg_obs_gray(h.h, 0, 0, C.c_void_p(bound.data_ptr())))
     for t in range(warm):
         L.rg_step(h.h, C.c_void_p(keys[t % 64].data_ptr()), 1)
+        if bound is not None:
+            L.rg_obs_gray(h.h, 0, 0, C.c_void_p(bound.data_ptr()))
     nw = (n + 15) // 16  # rows: one per wave of the launch (16..64 envs per wave); unused rows stay zero
     buf = np.zeros(((n + 15) // 16, 64), np.uint64)  # rg_prof copies one row per 16 envs (the smallest envs-per-wave)
     L.rg_prof(h.h, 1, None)
@@ -92,6 +99,8 @@ def prof(name, cfg, keys_table, n=65536, launches=20, max_steps=1000, do_reset=F
             L.rg_reset(h.h)
         else:
             L.rg_step(h.h, C.c_void_p(keys[t % 64].data_ptr()), 1)
+            if bound is not None:
+                L.rg_obs_gray(h.h, 0, 0, C.c_void_p(bound.data_ptr()))
         L.rg_prof(h.h, 1, buf.ctypes.data_as(C.c_void_p))
         buf_used = buf[buf[:, 63] > 0]
         n_waves = max(n_waves, len(buf_used))
