@@ -235,6 +235,12 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
     const int rec_words = RG_OBS_REC_WORDS(nrooms);
     const uint32_t *rec_all = S.obs_rec;  // (rgk_obs: rec_words <= tpe, one word per thread)
     const int stride = gridDim.x * epb;
+    // An env WITHOUT a pending Redraw -- nine in ten since the turn keeps the mirror itself -- is a plain stream: mirror word -> table -> float4.  With one env per
+    // block (always) and at most two words per thread, such an env takes no LDS staging and none of the four barriers of the Redraw path: its words go from
+    // the prefetch registers straight to the stores (round 6: the pass was latency-bound per block -- LDS round trips and barriers between the load and the
+    // store of every env -- at 5.0 TB/s where a plain fill of the same 134 MB runs at 6.5).
+    const int Q4 = HW >> 2;
+    const bool fast_ok = epb == 1 && Q4 <= 2 * tpe && sflag == 0 && !with_hist;  // (status / history planes: the general path)
     // item -> env: the identity, or (BOUND) the list entry -- one more dependent load, fetched one iteration earlier than the flag word
     auto load_env = [&](int base) -> int {
         const int i = base + le;
@@ -250,6 +256,10 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
             if (fl & RG_FLAG_REDRAW) {
                 if (lt < Q8) p.v0 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW)[lt];
                 if (lt < rec_words) p.rec = rec_all[(size_t)e * rec_words + lt];
+            } else if (fast_ok) {  // the two words this thread ENCODES (phase C's layout: word lt and word lt + tpe), see the fast path below
+                const uint32_t *m4 = reinterpret_cast<const uint32_t *>(S.screen + (size_t)e * HW);
+                if (lt < Q4) p.v0.x = m4[lt];
+                if (lt + tpe < Q4) p.v0.y = m4[lt + tpe];
             } else if (lt < Q8) {
                 const uint2 m = reinterpret_cast<const uint2 *>(S.screen + (size_t)e * HW)[lt];
                 p.v0.x = m.x; p.v0.y = m.y;
@@ -257,6 +267,42 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
         }
         return p;
     };
+    const uint32_t smax = (uint32_t)symbols - 1;  // construct_symbol_map fills channels 0..symbols-2 (symbol.rs:51-71)
+    // one word (4 cells) of an env's image(s): glyph planes, status planes, history plane -- whole-line float4 stores (lanes contiguous in q)
+    auto emit_glyphs = [&](float4 *o, int q, uint32_t g, bool &bad) {
+        const int q4 = Q4;
+        const uint32_t b0 = g & 0x7f, b1 = (g >> 8) & 0x7f, b2 = (g >> 16) & 0x7f, b3 = g >> 24;
+        if (KIND == 0) {
+            float4 v; v.x = lutf[b0]; v.y = lutf[b1]; v.z = lutf[b2]; v.w = lutf[b3];
+            store_obs(&o[q], v);
+        } else {
+            const uint32_t s0 = luts[b0], s1 = luts[b1], s2 = luts[b2], s3 = luts[b3];
+            bad = bad || s0 >= smax || s1 >= smax || s2 >= smax || s3 >= smax;
+            for (uint32_t ch = 0; ch < smax; ch++) {
+                float4 v;
+                v.x = s0 == ch ? 1.f : 0.f; v.y = s1 == ch ? 1.f : 0.f; v.z = s2 == ch ? 1.f : 0.f; v.w = s3 == ch ? 1.f : 0.f;
+                store_obs(&o[(size_t)ch * q4 + q], v);
+            }
+            float4 z; z.x = z.y = z.z = z.w = 0.f;
+            for (uint32_t ch = smax; ch < (uint32_t)base_planes; ch++) store_obs(&o[(size_t)ch * q4 + q], z);  // the last channel is never set
+        }
+    };
+    auto emit = [&](float4 *o, int q, uint32_t g, const float *stf, int nst, const uint32_t *hist4, bool &bad) {
+        const int q4 = Q4;
+        emit_glyphs(o, q, g, bad);
+        int p = base_planes;
+        for (int b = 0; b < nst; b++, p++) {
+            float4 sv; sv.x = sv.y = sv.z = sv.w = stf[b];
+            store_obs(&o[(size_t)p * q4 + q], sv);
+        }
+        if (with_hist) {
+            const uint32_t h4 = hist4[q];  // (a redrawn env: written in phase A by this block, barrier in between)
+            float4 a;
+            a.x = (h4 & 0xff) ? 1.f : 0.f; a.y = (h4 & 0xff00) ? 1.f : 0.f; a.z = (h4 & 0xff0000) ? 1.f : 0.f; a.w = (h4 >> 24) ? 1.f : 0.f;
+            store_obs(&o[(size_t)p * q4 + q], a);
+        }
+    };
+    lds_barrier();  // the tables are ready (the fast path below has no barrier of its own)
     const int base0 = blockIdx.x * epb;
     int e_cur = load_env(base0), e_nxt = load_env(base0 + stride), e_nn = load_env(base0 + 2 * stride);
     uint32_t fl_cur = load_flag(base0, e_cur), fl_nxt = load_flag(base0 + stride, e_nxt);
@@ -275,7 +321,19 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
         const uint4 *cell4 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW);
         const uint4 v0 = cur.v0;
         const uint32_t t_rec = cur.rec;
-        lds_barrier();  // LUTs ready / previous iteration's LDS reads done
+        if (fast_ok && !(fl & RG_FLAG_REDRAW)) {  // (block-uniform: one env per block)
+            if (valid) {
+                const int xe = GROUPS ? __builtin_amdgcn_readfirstlane(S.ext[e]) : e;
+                float4 *o = reinterpret_cast<float4 *>(out + (size_t)xe * nplanes * HW);
+                bool bad = false;
+                if (lt < Q4) emit_glyphs(o, lt, v0.x & 0x7f7f7f7fu, bad);
+                if (lt + tpe < Q4) emit_glyphs(o, lt + tpe, v0.y & 0x7f7f7f7fu, bad);
+                if (KIND == 1 && bad) { atomicOr(&S.flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
+                if (BOUND && lt == 0) atomicAnd(&S.flags[e], ~RG_FLAG_SCR_CHANGED);
+            }
+            continue;
+        }
+        lds_barrier();  // previous iteration's LDS reads done
         if (valid) {
             if (redraw) {
                 if (lt < rec_words) tb->w[lt] = t_rec;
@@ -346,42 +404,15 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
             const uint32_t *hist4 = reinterpret_cast<const uint32_t *>(S.hist + (size_t)e * HW);
             const int xe = GROUPS ? __builtin_amdgcn_readfirstlane(S.ext[e]) : e;  // config-group handles write at the handle's env index (one env per block: uniform)
             float4 *o = reinterpret_cast<float4 *>(out + (size_t)xe * nplanes * HW);
-            const int q4 = HW >> 2;
-            const uint32_t smax = (uint32_t)symbols - 1;  // construct_symbol_map fills channels 0..symbols-2 (symbol.rs:51-71)
             float stf[9];
             int nst = 0;
             for (int b = 0; b < 9; b++)
                 if (sflag & (1u << b)) stf[nst++] = (float)S.status[(size_t)e * 10 + kStatusIdx[b]];
             bool bad = false;
-            for (int q = lt; q < q4; q += tpe) {
+            for (int q = lt; q < Q4; q += tpe) {
                 const uint32_t g = scr4[q] & 0x7f7f7f7fu;
                 if (redraw) m4[q] = g;
-                const uint32_t b0 = g & 0x7f, b1 = (g >> 8) & 0x7f, b2 = (g >> 16) & 0x7f, b3 = g >> 24;
-                if (KIND == 0) {
-                    float4 v; v.x = lutf[b0]; v.y = lutf[b1]; v.z = lutf[b2]; v.w = lutf[b3];
-                    store_obs(&o[q], v);
-                } else {
-                    const uint32_t s0 = luts[b0], s1 = luts[b1], s2 = luts[b2], s3 = luts[b3];
-                    bad = bad || s0 >= smax || s1 >= smax || s2 >= smax || s3 >= smax;
-                    for (uint32_t ch = 0; ch < smax; ch++) {
-                        float4 v;
-                        v.x = s0 == ch ? 1.f : 0.f; v.y = s1 == ch ? 1.f : 0.f; v.z = s2 == ch ? 1.f : 0.f; v.w = s3 == ch ? 1.f : 0.f;
-                        store_obs(&o[(size_t)ch * q4 + q], v);
-                    }
-                    float4 z; z.x = z.y = z.z = z.w = 0.f;
-                    for (uint32_t ch = smax; ch < (uint32_t)base_planes; ch++) store_obs(&o[(size_t)ch * q4 + q], z);  // the last channel is never set
-                }
-                int p = base_planes;
-                for (int b = 0; b < nst; b++, p++) {
-                    float4 sv; sv.x = sv.y = sv.z = sv.w = stf[b];
-                    store_obs(&o[(size_t)p * q4 + q], sv);
-                }
-                if (with_hist) {
-                    const uint32_t h4 = hist4[q];  // written in phase A by this block when the env was redrawn (barrier in between)
-                    float4 a;
-                    a.x = (h4 & 0xff) ? 1.f : 0.f; a.y = (h4 & 0xff00) ? 1.f : 0.f; a.z = (h4 & 0xff0000) ? 1.f : 0.f; a.w = (h4 >> 24) ? 1.f : 0.f;
-                    store_obs(&o[(size_t)p * q4 + q], a);
-                }
+                emit(o, q, g, stf, nst, hist4, bad);
             }
             if (KIND == 1 && bad) { atomicOr(&S.flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
             const uint32_t seen = BOUND ? RG_FLAG_SCR_CHANGED : 0u;  // (the bound tensor now shows this env's screen)

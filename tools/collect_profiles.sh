@@ -47,6 +47,21 @@ cp "$(find /tmp/${tag}_trace_drv -name '*kernel_stats.csv' | head -1)" $out/${ta
 python tools/microbench.py prof1 2>&1 | grep -v amdgpu | cut -c1-400 > $out/${tag}_wave_profile.txt
 python tools/microbench.py profd 2>&1 | grep -v amdgpu | cut -c1-400 > $out/${tag}_wave_profile_default.txt
 python tools/bench_value_api.py 64 1024 8192 65536 2>&1 | grep -v amdgpu > $out/${tag}_value_api.txt
+# 4b. round 6: the bound observation tensor (opt-in, never the headline): bench lines of the three workloads, kernel stats of the mini run, the bound step kernel's wave profile;
+#     step-latency percentiles against the producer's launch shape (development library)
+for wl in mini default nohide-symbol; do
+  case $wl in
+    mini) S="--steps 2000 --warmup 200";;
+    default) S="--steps 400 --warmup 50 --preroll-steps 500";;
+    *) S="--steps 80 --warmup 10 --preroll-steps 100";;
+  esac
+  python bench.py --workload $wl --no-extra --no-cpu-baseline --no-repeats --persistent-obs $S > $out/${tag}_bench_bound_${wl}.json 2>> $out/${tag}_bench.err
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${tag}_trace_bound -- python bench.py --workload mini $Q --clock-warm-s 0 --persistent-obs --steps 2000 --warmup 200 > $out/${tag}_trace_bound.log 2>&1
+cp "$(find /tmp/${tag}_trace_bound -name '*kernel_stats.csv' | head -1)" $out/${tag}_kernel_stats_bound_mini.csv
+RG_PROF_BOUND=1 python tools/microbench.py prof1 2>&1 | grep -v amdgpu | cut -c1-400 > $out/${tag}_wave_profile_bound.txt
+python tools/jitter_sweep.py mini > $out/${tag}_jitter_mini.txt 2>&1
+python tools/jitter_sweep.py default > $out/${tag}_jitter_default.txt 2>&1
 # 5. ONE fuzz soak (random valid configs, HIP vs oracle in lock step)
 python tools/fuzz_parity.py --minutes 4 --seed 404 2>&1 | grep -v amdgpu | tail -40 > $out/${tag}_fuzz_parity.txt
 echo "$commit" > $out/${tag}_commit.txt
