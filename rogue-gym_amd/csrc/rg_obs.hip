@@ -179,7 +179,11 @@ __global__ void __launch_bounds__(256) k_symbol(const uint8_t *__restrict__ scre
 __device__ __forceinline__ void store_obs(float4 *p, float4 v) {
     typedef float f4v __attribute__((ext_vector_type(4)));
     f4v nv = {v.x, v.y, v.z, v.w};
+#ifdef RG_EXP_OBS_PLAIN_STORES
+    *reinterpret_cast<f4v *>(p) = nv;  // (experiment build: profiles/r06_experiments.txt)
+#else
     __builtin_nontemporal_store(nv, reinterpret_cast<f4v *>(p));
+#endif
 }
 // Per-env overlay inputs staged in LDS, in the layout of the env's OBSERVATION RECORD (RgState::obs_rec, RG_OBS_REC_WORDS): words [0, nr) the monster
 // words, [nr] the player's position, [nr + 1, 2 nr + 1) the room rects, then the room metas one byte each.  The record is what an ordinary Redraw reads --
