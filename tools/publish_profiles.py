@@ -40,7 +40,7 @@ shutil.copy("profiles/%s_kernel_stats_mini.txt" % tag, "profiles/%s_kernel_stats
 if os.path.exists("gpurun_out/%s_kernel_stats_bound_mini.csv" % tag):
     stats_txt("gpurun_out/%s_kernel_stats_bound_mini.csv" % tag, "profiles/%s_kernel_stats_bound_mini.txt" % tag)
 for n in ("bench.json", "bench_driver_cmd.json", "pmc_calibration.json", "wave_profile.txt", "wave_profile_default.txt", "value_api.txt", "fuzz_parity.txt",
-          "bench_bound_mini.json", "bench_bound_default.json", "bench_bound_nohide-symbol.json", "wave_profile_bound.txt", "jitter_mini.txt", "jitter_default.txt"):
+          "bench_bound_mini.json", "bench_bound_default.json", "bench_bound_nohide-symbol.json", "wave_profile_bound.txt", "jitter_mini.txt", "jitter_default.txt", "eight_ranks_wall.txt"):
     if not os.path.exists("gpurun_out/%s_%s" % (tag, n)):
         continue
     shutil.copy("gpurun_out/%s_%s" % (tag, n), "profiles/%s_%s" % (tag, n))
