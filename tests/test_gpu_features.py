@@ -984,7 +984,8 @@ def test_step_fetch_equals_step_sync_fetch(goldens, n, device_screens):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,sym,n", [("mini", False, 16384), ("default", False, 4096), ("nohide", True, 512)], ids=["mini gray", "default 80x24 gray", "nohide one-hot"])
+@pytest.mark.parametrize("name,sym,n", [("mini", False, 16384), ("default", False, 4096), ("nohide", True, 512), ("mini48", False, 2048)],
+                         ids=["mini gray", "default 80x24 gray", "nohide one-hot", "48x20 gray (a step class without a bound instance: re-encoded in full)"])
 def test_bound_observation_tensor_is_the_full_encode(goldens, name, sym, n):
     """rg_obs_bind (HipVecRogueEnv(persistent_obs=True)): the bound tensor is kept current IN PLACE -- only the envs whose screen changed since the last call are
     rewritten (a Redraw drawn from the tiles, or bytes the turn wrote into the mirror itself: RG_FLAG_SCR_CHANGED) -- and must hold, after every step, exactly what
@@ -997,7 +998,8 @@ def test_bound_observation_tensor_is_the_full_encode(goldens, name, sym, n):
     from rogue_gym.envs import DungeonType, HipVecRogueEnv, ImageSetting, StatusFlag
 
     st = ImageSetting(DungeonType.SYMBOL if sym else DungeonType.GRAY, StatusFlag.EMPTY, False)
-    cfgs = [dict(goldens["configs"][name], seed=i % 5000) for i in range(n)]
+    base = dict(goldens["configs"]["mini"], width=48, height=20) if name == "mini48" else goldens["configs"][name]
+    cfgs = [dict(base, seed=i % 5000) for i in range(n)]
     a = HipVecRogueEnv(cfgs, max_steps=30, image_setting=st, persistent_obs=True)
     b = HipVecRogueEnv(cfgs, max_steps=30, image_setting=st)
     assert torch.equal(a.obs, b.obs)
