@@ -244,7 +244,11 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
     // the prefetch registers straight to the stores (round 6: the pass was latency-bound per block -- LDS round trips and barriers between the load and the
     // store of every env -- at 5.0 TB/s where a plain fill of the same 134 MB runs at 6.5).
     const int Q4 = HW >> 2;
-    const bool fast_ok = epb == 1 && Q4 <= 2 * tpe && sflag == 0 && !with_hist;  // (status / history planes: the general path)
+    // Up to four words per thread: on the 32x16 grid a thread carries 16 cells and ONE wave serves TWO envs per iteration (tpe = 32, epb = 2: rgk_obs) -- twice the
+    // bytes in flight per wave of a pass whose blocks are latency-bound (one env per memory round trip).  Two envs per block only where the block is a single wave:
+    // its halves then take the two paths under lane masks and the staged path's barriers are the wave's own.
+    const bool one_wave = blockDim.x == WAVE;
+    const bool fast_ok = (epb == 1 || one_wave) && Q4 <= 4 * tpe && sflag == 0 && !with_hist;  // (status / history planes: the general path)
     // item -> env: the identity, or (BOUND) the list entry -- one more dependent load, fetched one iteration earlier than the flag word
     auto load_env = [&](int base) -> int {
         const int i = base + le;
@@ -260,10 +264,12 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
             if (fl & RG_FLAG_REDRAW) {
                 if (lt < Q8) p.v0 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW)[lt];
                 if (lt < rec_words) p.rec = rec_all[(size_t)e * rec_words + lt];
-            } else if (fast_ok) {  // the two words this thread ENCODES (phase C's layout: word lt and word lt + tpe), see the fast path below
+            } else if (fast_ok) {  // the words this thread ENCODES (phase C's layout: words lt, lt + tpe, ...), see the fast path below
                 const uint32_t *m4 = reinterpret_cast<const uint32_t *>(S.screen + (size_t)e * HW);
                 if (lt < Q4) p.v0.x = m4[lt];
                 if (lt + tpe < Q4) p.v0.y = m4[lt + tpe];
+                if (lt + 2 * tpe < Q4) p.v0.z = m4[lt + 2 * tpe];
+                if (lt + 3 * tpe < Q4) p.v0.w = m4[lt + 3 * tpe];
             } else if (lt < Q8) {
                 const uint2 m = reinterpret_cast<const uint2 *>(S.screen + (size_t)e * HW)[lt];
                 p.v0.x = m.x; p.v0.y = m.y;
@@ -321,24 +327,27 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
         fl_nxt = load_flag(base + 2 * stride, e_nxt);
         e_nn = load_env(base + 3 * stride);
         if (base + stride < n) nxt = prefetch(base + stride, e_cur, fl_cur);
-        const bool redraw = valid && (fl & RG_FLAG_REDRAW);
         const uint4 *cell4 = reinterpret_cast<const uint4 *>(S.cell + (size_t)e * HW);
         const uint4 v0 = cur.v0;
         const uint32_t t_rec = cur.rec;
-        if (fast_ok && !(fl & RG_FLAG_REDRAW)) {  // (block-uniform: one env per block)
-            if (valid) {
-                const int xe = GROUPS ? __builtin_amdgcn_readfirstlane(S.ext[e]) : e;
-                float4 *o = reinterpret_cast<float4 *>(out + (size_t)xe * nplanes * HW);
-                bool bad = false;
-                if (lt < Q4) emit_glyphs(o, lt, v0.x & 0x7f7f7f7fu, bad);
-                if (lt + tpe < Q4) emit_glyphs(o, lt + tpe, v0.y & 0x7f7f7f7fu, bad);
-                if (KIND == 1 && bad) { atomicOr(&S.flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
-                if (BOUND && lt == 0) atomicAnd(&S.flags[e], ~RG_FLAG_SCR_CHANGED);
-            }
-            continue;
+        // the register-to-store path of an env without a pending Redraw (a half-wave of a one-wave block, else the whole block: one env per block there)
+        const bool my_fast = fast_ok && valid && !(fl & RG_FLAG_REDRAW);
+        if (my_fast) {
+            const int xe = GROUPS ? __builtin_amdgcn_readfirstlane(S.ext[e]) : e;
+            float4 *o = reinterpret_cast<float4 *>(out + (size_t)xe * nplanes * HW);
+            bool bad = false;
+            if (lt < Q4) emit_glyphs(o, lt, v0.x & 0x7f7f7f7fu, bad);
+            if (lt + tpe < Q4) emit_glyphs(o, lt + tpe, v0.y & 0x7f7f7f7fu, bad);
+            if (lt + 2 * tpe < Q4) emit_glyphs(o, lt + 2 * tpe, v0.z & 0x7f7f7f7fu, bad);
+            if (lt + 3 * tpe < Q4) emit_glyphs(o, lt + 3 * tpe, v0.w & 0x7f7f7f7fu, bad);
+            if (KIND == 1 && bad) { atomicOr(&S.flags[e], RG_FLAG_ERR_TILE); atomicOr(err_any, RG_FLAG_ERR_TILE); }
+            if (BOUND && lt == 0) atomicAnd(&S.flags[e], ~RG_FLAG_SCR_CHANGED);
         }
+        const bool staged = valid && !my_fast;  // the lanes that take the staged path below
+        if (fast_ok && !(one_wave ? __any(staged) : staged)) continue;  // (block-uniform: a one-wave block votes; several waves serve ONE env)
+        const bool redraw = staged && (fl & RG_FLAG_REDRAW);
         lds_barrier();  // previous iteration's LDS reads done
-        if (valid) {
+        if (staged) {
             if (redraw) {
                 if (lt < rec_words) tb->w[lt] = t_rec;
                 // the history plane is rewritten only when the visited set changed since it was last written (k_step: HIST_DIRTY), never on a
@@ -372,9 +381,9 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
         lds_barrier();
         // ---- phase B: entity overlays from LDS only; draw priority monster < gold < player (core/src/lib.rs:271-283): a monster never replaces the
         //      '*' the decode put there (no other glyph is '*'), the player replaces anything ----
-        const uint32_t ppos = (valid && redraw) ? tb->w[nrooms] : 0;
+        const uint32_t ppos = redraw ? tb->w[nrooms] : 0;
         const int px = POS_X(ppos), py = POS_Y(ppos);
-        if (valid && redraw && lt < nrooms) {
+        if (redraw && lt < nrooms) {
             uint32_t w = tb->w[lt];
             if ((w >> 24) & MF_ALIVE) {
                 int x = POS_X(w), y = POS_Y(w);
@@ -397,12 +406,12 @@ __global__ void __launch_bounds__(OBS_THREADS) k_obs(RgState S, RgConfig c, uint
             }
         }
         lds_barrier();
-        if (valid && redraw && lt == 0 && (scr[py * W + px] & 0x80u)) scr[py * W + px] = (uint8_t)(0x80u | '@');
+        if (redraw && lt == 0 && (scr[py * W + px] & 0x80u)) scr[py * W + px] = (uint8_t)(0x80u | '@');
         lds_barrier();
         if (with_hist) __syncthreads();  // the history plane is re-read from global memory below (written in phase A by other lanes)
         // ---- phase C: mirror write-back + encode.  One float4 (4 cells) per lane per plane, lanes contiguous: every wave-level store
         //      covers whole 128-byte lines (1 KB per instruction) ----
-        if (valid) {
+        if (staged) {
             uint32_t *m4 = reinterpret_cast<uint32_t *>(S.screen + (size_t)e * HW);
             const uint32_t *scr4 = reinterpret_cast<const uint32_t *>(scr);
             const uint32_t *hist4 = reinterpret_cast<const uint32_t *>(S.hist + (size_t)e * HW);
@@ -539,7 +548,9 @@ int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, 
     int tpe = q8 >= OBS_THREADS ? OBS_THREADS : ((q8 + 63) / 64) * 64;  // threads per env: a whole number of waves
     if (tpe > OBS_THREADS) tpe = OBS_THREADS;
     if (RG_OBS_REC_WORDS(c->room_num_x * c->room_num_y) > tpe) return 0;  // the env's observation record is fetched one word per thread (a <= 512-cell grid with more than 28 rooms: unfused path)
-    const int bthreads = tpe, epb = 1;  // one env per block: no cross-env barrier coupling (4 envs per 256-thread block measured 10-20 % slower)
+    const int bthreads = tpe, epb = 1;  // one env per block: no cross-env barrier coupling (4 envs per 256-thread block measured 10-20 % slower; two envs per one-wave
+                                        // block on the 32x16 grid -- half a wave and four words per thread each, which k_obs supports -- 30.0 against 28.9 us: round 6)
+    const bool groups = S->ext != nullptr;
     size_t smem = 512 + 128 + 64 + (size_t)epb * OBS_ENV_BYTES(hw);
     int blocks = (S->n + epb - 1) / epb;
     // persistent grid: launching one tiny workgroup per env is dispatch-rate bound (65 536 one-wave blocks: 71 us; 16 384 looping blocks: 51 us)
@@ -550,7 +561,6 @@ int rgk_obs(const RgState *S, const RgConfig *c, uint32_t sflag, int with_hist, 
 #endif
         if (blocks > cap) blocks = cap;
     }
-    const bool groups = S->ext != nullptr;
     const int hi_prio = !(c->width <= 32 && c->room_num_x * c->room_num_y <= 32);  // (rg_kernels.hip rgk_step: those configs step with k_step_w32)
 #define RG_LAUNCH_OBS(...) do { if (ev0 || ev1) hipExtLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(bthreads), (uint32_t)smem, st, ev0, ev1, 0, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym, hi_prio); \
                                else hipLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(bthreads), smem, st, *S, *c, sflag, with_hist, out, err_any, tpe, epb, planes_sym, hi_prio); } while (0)

@@ -2,7 +2,7 @@
 
 Two of the stepper's performance properties are decided by the compiler's register allocation and are easy to lose without noticing: the W <= 32 step
 kernel must fit 256 registers (two waves per SIMD: every block of a 65 536-env launch resident from t = 0), and the observation
-kernel must stay at 72 (seven waves per SIMD: 27 more cost it 17 us).  No kernel may use scratch memory."""
+kernel must stay at 80 or fewer (six waves per SIMD; at 99 it lost 17 us, DESIGN_HISTORY.md 5.2).  No kernel may use scratch memory."""
 import os
 import re
 import subprocess
@@ -59,10 +59,12 @@ def test_register_and_scratch_budget_of_the_built_kernels():
         # LDS columns sit at compile-time offsets, reciprocals of config constants come from RgConfig: 68 bytes of scratch -> 16, none of it reloaded behind
         # the turn's stores (the one parked pair is the address of the glyph table load, read back before the first store).
         assert m["vgpr_spill_count"] <= 5 and m["private_segment_fixed_size"] <= 20, (k, m)
-    obs = [k for k in md if re.search(r"k_obsILi0ELb0E", k)]       # k_obs<gray, no config groups>: the kernel of the headline workload
+    obs = [k for k in md if re.search(r"k_obsILi0ELb0ELb0E", k)]   # k_obs<gray, no config groups, not bound>: the kernel of the headline workload
     assert obs, sorted(md)
     for k in obs:
-        assert md[k]["vgpr_count"] <= 72 and md[k]["agpr_count"] == 0, (k, md[k])  # seven waves per SIMD
+        # (rounds 2-5: 72 registers = seven waves per SIMD.  Round 6: with the register-to-store path of envs without a Redraw the kernel takes 79 -- six waves -- and
+        # is FASTER for it: 28.9 us against 29.9 us for the 72-register form of the same path, same box; profiles/r06_experiments.txt)
+        assert md[k]["vgpr_count"] <= 80 and md[k]["agpr_count"] == 0, (k, md[k])
     regen = [k for k in md if "k_regen" in k]
     assert regen, sorted(md)
     for k in regen:
