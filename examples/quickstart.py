@@ -58,3 +58,18 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print("HipVecRogueEnv: %d envs, obs %s on %s, %.0f M env-steps/s" % (n, tuple(obs.shape), obs.device, n * 500 / dt / 1e6))
 venv.close()
+
+# 3b. the same with the observation tensor BOUND to the stepper (opt-in): `obs` is kept current in place -- only the envs whose screen changed are rewritten;
+#     contents identical, the caller must not write to it ----------------------------------------------------------------------------------------------
+venv = HipVecRogueEnv([dict(MINI, seed=i) for i in range(n)], max_steps=1000, image_setting=ImageSetting(DungeonType.GRAY, StatusFlag.EMPTY, False), device=0,
+                      persistent_obs=True)
+for t in range(100):
+    obs, reward, done = venv.step(actions[t % 64])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for t in range(500):
+    obs, reward, done = venv.step(actions[t % 64])
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("HipVecRogueEnv(persistent_obs=True): %.0f M env-steps/s" % (n * 500 / dt / 1e6))
+venv.close()
