@@ -1026,6 +1026,13 @@ def test_bound_observation_tensor_is_the_full_encode(goldens, name, sym, n):
         if t == 90:
             assert torch.equal(a.reset(), b.reset())
     assert 0.05 < sum(changed) / len(changed) < 0.9, changed   # (the premise: a good part of the envs of a step change nothing on screen)
+    # what cannot be bound is refused loudly: status planes, a history plane
+    assert a._h.L.rg_obs_bind(a._h.h, int(sym), 1, 0, C.c_void_p(a.obs.data_ptr())) != 0 and b"status" in a._h.L.rg_last_error(a._h.h)
+    assert a._h.L.rg_obs_bind(a._h.h, int(sym), 0, 1, C.c_void_p(a.obs.data_ptr())) != 0
+    # ... and unbinding returns the handle to full encodes of any buffer
+    a._h.check(a._h.L.rg_obs_bind(a._h.h, 0, 0, 0, None))
+    keys = table[torch.randint(0, len(table), (n,), generator=gen, device=a.device)].contiguous()
+    assert torch.equal(a.step_keys(keys)[0], b.step_keys(keys)[0])
     a.check_errors()
     a.close()
     b.close()
